@@ -1,0 +1,165 @@
+/*
+ * zippy_hip.h -- C ABI of the MI355X-native batched DEFLATE engine.
+ *
+ * This is the drop-in boundary for guzba/zippy's compress()/uncompress() path.
+ * zippy has no FFI/plugin interface of its own: the boundary is its exported
+ * Nim procs, so every entry point below cites the Nim proc it stands behind
+ * (file:line under the reference tree).  A Nim shim that binds these symbols
+ * and re-exposes zippy's exact signatures is in INTEGRATION.md.
+ *
+ * Plain C: pointers, sizes, status codes.  No torch types, no C++ types.
+ * All work runs on one GPU through hand-written gfx950 kernels; there is no
+ * CPU fallback (calls fail with ZH_ERR_DEVICE if no GPU is usable).
+ */
+#ifndef ZIPPY_HIP_H
+#define ZIPPY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* CompressedDataFormat, src/zippy/common.nim:4-5 (same ordinals) */
+enum { ZH_DF_DETECT = 0, ZH_DF_ZLIB = 1, ZH_DF_GZIP = 2, ZH_DF_DEFLATE = 3 };
+
+/* Levels, src/zippy/common.nim:7-12; valid range -2..9 (deflate.nim:208-209) */
+enum {
+  ZH_NO_COMPRESSION = 0,
+  ZH_BEST_SPEED = 1,
+  ZH_BEST_COMPRESSION = 9,
+  ZH_DEFAULT_COMPRESSION = -1,
+  ZH_HUFFMAN_ONLY = -2
+};
+
+/* Status codes.  1..18 map one-to-one onto the ZippyError raise sites of the
+ * reference; zh_strerror() returns the reference's message. */
+enum {
+  ZH_OK = 0,
+  ZH_ERR_INVALID_LEVEL = 1,      /* deflate.nim:208-209 */
+  ZH_ERR_INVALID_FORMAT = 2,     /* zippy.nim:83-84 */
+  ZH_ERR_DETECT = 3,             /* zippy.nim:125 */
+  ZH_ERR_UNSUPPORTED_METHOD = 4, /* zippy.nim:141, gzip.nim:26 */
+  ZH_ERR_COMPRESSION_INFO = 5,   /* zippy.nim:144 */
+  ZH_ERR_INVALID_HEADER = 6,     /* zippy.nim:147 */
+  ZH_ERR_PRESET_DICT = 7,        /* zippy.nim:150 */
+  ZH_ERR_CHECKSUM = 8,           /* zippy.nim:162, gzip.nim:81 */
+  ZH_ERR_SIZE = 9,               /* gzip.nim:85,88 */
+  ZH_ERR_GZIP_ID = 10,           /* gzip.nim:23 */
+  ZH_ERR_RESERVED_FLAGS = 11,    /* gzip.nim:29 */
+  ZH_ERR_UNSUPPORTED_FLAGS = 12, /* gzip.nim:41 */
+  ZH_ERR_INVALID_BUFFER = 13,    /* internal.nim:191-192 */
+  ZH_ERR_COMPRESS_INTERNAL = 14, /* internal.nim:194-195 */
+  ZH_ERR_END_OF_BUFFER = 15,     /* bitstreams.nim:16-17 */
+  ZH_ERR_BYTE_BOUNDARY = 16,     /* bitstreams.nim:66,113 */
+  ZH_ERR_BLOCK_HEADER = 17,      /* inflate.nim:289 */
+  ZH_ERR_INVALID_SYMBOL = 18,    /* inflate.nim:165 */
+  ZH_ERR_NOMEM = 19,             /* host or device allocation failed */
+  ZH_ERR_DEVICE = 20,            /* no usable GPU / HIP runtime error (zh_last_error) */
+  ZH_ERR_DST_TOO_SMALL = 21,     /* device API: output slot capacity exceeded */
+  ZH_ERR_ARGUMENT = 22           /* NULL pointer, bad plan, ... */
+};
+
+/* Engine context: one GPU, one HIP stream, reusable scratch. Thread-compatible
+ * (one thread at a time per context; separate contexts are independent), like
+ * the reference's re-entrant pure procs (SURVEY.md 8b "Threading"). */
+typedef struct zh_ctx zh_ctx;
+
+/* device < 0: current device.  stream: a hipStream_t to enqueue on, or NULL to
+ * let the context create its own. */
+int zh_create(int device, void *stream, zh_ctx **out);
+void zh_destroy(zh_ctx *ctx);
+const char *zh_strerror(int status);
+const char *zh_last_error(zh_ctx *ctx); /* detail of the last ZH_ERR_DEVICE */
+void *zh_stream(zh_ctx *ctx);           /* the hipStream_t work is enqueued on */
+
+/* gzip FNAME length: the reference inserts 0..25 letters chosen at random per
+ * call (zippy.nim:26-42).  k < 0 (default): random per buffer like the
+ * reference; 0..25: fixed (deterministic output for tests). */
+void zh_set_gzip_fname_len(zh_ctx *ctx, int k);
+
+/* Upper bound of compress() output for len input bytes: stored form
+ * len + 5*ceil(len/65535) (deflate.nim:179-205) + container + slack. */
+size_t zh_compress_bound(size_t len, int data_format);
+
+/* ------------------------------------------------------------------ *
+ * Host-buffer API: what the Nim shim binds.                           *
+ * Inputs are borrowed read-only for the call; outputs are freshly     *
+ * allocated by the library (release with zh_free) -- the ownership    *
+ * model of `compress*(...): string` (zippy.nim:11-16).               *
+ * ------------------------------------------------------------------ */
+
+/* compress*(src: pointer, len, level, dataFormat): string -- zippy.nim:11-84,
+ * for n independent buffers at once.  statuses[i] is per buffer; the return
+ * value is ZH_OK unless the call as a whole could not run. */
+int zh_compress_batch(zh_ctx *ctx, const void *const *srcs, const size_t *lens, size_t n,
+                      int level, int data_format, void **dsts, size_t *dst_lens,
+                      int32_t *statuses);
+
+/* uncompress*(src: pointer, len, dataFormat): string -- zippy.nim:100-165,
+ * gzip.nim:3-88, for n independent streams at once.  A bad stream only fails
+ * its own slot. */
+int zh_uncompress_batch(zh_ctx *ctx, const void *const *srcs, const size_t *lens, size_t n,
+                        int data_format, void **dsts, size_t *dst_lens, int32_t *statuses);
+
+/* Single-buffer forms (batch of 1); return the buffer's status. */
+int zh_compress(zh_ctx *ctx, const void *src, size_t len, int level, int data_format,
+                void **dst, size_t *dst_len);
+int zh_uncompress(zh_ctx *ctx, const void *src, size_t len, int data_format, void **dst,
+                  size_t *dst_len);
+
+/* crc32*(src: pointer, len): uint32 -- crc.nim:53-72 ; adler32* -- adler32.nim:6 */
+int zh_crc32(zh_ctx *ctx, const void *src, size_t len, uint32_t *out);
+int zh_adler32(zh_ctx *ctx, const void *src, size_t len, uint32_t *out);
+
+void zh_free(void *p);
+
+/* ------------------------------------------------------------------ *
+ * Device-resident API: buffers already in HBM (pipelines, bench.py).  *
+ * A plan owns the device-side descriptors and scratch for one batch   *
+ * geometry; running it only enqueues kernels on the context's stream  *
+ * (no host synchronisation), so it can be timed with HIP events or    *
+ * captured in a hipGraph.                                             *
+ * ------------------------------------------------------------------ */
+typedef struct zh_plan zh_plan;
+
+/* Buffer i is d_src[src_off[i] .. +src_len[i]); its output slot is
+ * d_dst[dst_off[i] .. +dst_cap[i]).  Offsets are in bytes. */
+int zh_plan_compress(zh_ctx *ctx, size_t n, const uint64_t *src_off, const uint64_t *src_len,
+                     const uint64_t *dst_off, const uint64_t *dst_cap, int level,
+                     int data_format, zh_plan **out);
+int zh_plan_uncompress(zh_ctx *ctx, size_t n, const uint64_t *src_off, const uint64_t *src_len,
+                       const uint64_t *dst_off, const uint64_t *dst_cap, int data_format,
+                       zh_plan **out);
+/* Enqueue the plan. d_src/d_dst are device pointers. */
+int zh_plan_run(zh_plan *plan, const void *d_src, void *d_dst);
+/* Wait for the stream and fetch per-buffer output lengths and statuses. */
+int zh_plan_results(zh_plan *plan, uint64_t *out_lens, int32_t *statuses);
+/* Device arrays of the same (uint64 lens[n], int32 statuses[n]); valid after run. */
+const uint64_t *zh_plan_device_lens(zh_plan *plan);
+const int32_t *zh_plan_device_statuses(zh_plan *plan);
+/* Re-point an uncompress plan at new per-stream compressed lengths (same
+ * offsets/capacities), e.g. after a compress plan produced them on device. */
+int zh_plan_set_src_lens_device(zh_plan *plan, const uint64_t *d_lens);
+void zh_plan_destroy(zh_plan *plan);
+
+/* Per-kernel timing of the LAST zh_plan_run when profiling is on (HIP events on
+ * the context's stream around every launch).  names[i] are static strings. */
+void zh_plan_set_profiling(zh_plan *plan, int on);
+int zh_plan_kernel_times(zh_plan *plan, const char **names, float *ms, int max_entries);
+
+/* ------------------------------------------------------------------ *
+ * Introspection for parity tests (not part of the drop-in surface).   *
+ * ------------------------------------------------------------------ */
+/* Level-1 parse of one buffer as the u16 token stream of SURVEY.md 8a row a4
+ * (snappy.nim:33-64 format), block by block, fragment by fragment: lets tests
+ * compare the device matcher with the oracle token-for-token.  tokens is
+ * library-allocated (zh_free). */
+int zh_debug_tokens(zh_ctx *ctx, const void *src, size_t len, int level, uint16_t **tokens,
+                    size_t *num_tokens);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,19 @@
+"""Test helper: the engine built from the SAME kernel sources with g++ against
+the fiber emulator in tests/hipemu (no GPU needed).  Test infrastructure only."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "hipemu"))
+
+_engine = None
+
+
+def engine():
+    global _engine
+    if _engine is None:
+        import build_emu
+        from zippy_amd._binding import Engine
+        _engine = Engine(build_emu.build())
+        _engine.set_gzip_fname_len(0)
+    return _engine

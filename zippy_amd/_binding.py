@@ -1,0 +1,236 @@
+"""ctypes binding of the C ABI in include/zippy_hip.h.
+
+`Engine(lib_path)` wraps one zh_ctx.  The product entry point (zippy_amd.api)
+always passes zippy_amd/libzippy_hip.so; the test-suite also points this class at
+the g++/emulator build of the same sources (tests/hipemu) to check kernel logic
+without a GPU.  There is no fallback between the two.
+"""
+import ctypes
+import os
+
+from .common import ZippyError, dfDetect, dfGzip, DefaultCompression
+
+_c = ctypes
+_SIGS = {
+    "zh_create": (_c.c_int, [_c.c_int, _c.c_void_p, _c.POINTER(_c.c_void_p)]),
+    "zh_destroy": (None, [_c.c_void_p]),
+    "zh_strerror": (_c.c_char_p, [_c.c_int]),
+    "zh_last_error": (_c.c_char_p, [_c.c_void_p]),
+    "zh_stream": (_c.c_void_p, [_c.c_void_p]),
+    "zh_set_gzip_fname_len": (None, [_c.c_void_p, _c.c_int]),
+    "zh_compress_bound": (_c.c_size_t, [_c.c_size_t, _c.c_int]),
+    "zh_compress_batch": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
+                                     _c.c_size_t, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p),
+                                     _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_int32)]),
+    "zh_uncompress_batch": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p),
+                                       _c.POINTER(_c.c_size_t), _c.c_size_t, _c.c_int,
+                                       _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
+                                       _c.POINTER(_c.c_int32)]),
+    "zh_compress": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int,
+                               _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t)]),
+    "zh_uncompress": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int,
+                                 _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t)]),
+    "zh_crc32": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_uint32)]),
+    "zh_adler32": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_uint32)]),
+    "zh_free": (None, [_c.c_void_p]),
+    "zh_plan_compress": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_uint64),
+                                    _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64),
+                                    _c.POINTER(_c.c_uint64), _c.c_int, _c.c_int,
+                                    _c.POINTER(_c.c_void_p)]),
+    "zh_plan_uncompress": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_uint64),
+                                      _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64),
+                                      _c.POINTER(_c.c_uint64), _c.c_int, _c.POINTER(_c.c_void_p)]),
+    "zh_plan_run": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "zh_plan_results": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_int32)]),
+    "zh_plan_device_lens": (_c.c_void_p, [_c.c_void_p]),
+    "zh_plan_device_statuses": (_c.c_void_p, [_c.c_void_p]),
+    "zh_plan_set_src_lens_device": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "zh_plan_destroy": (None, [_c.c_void_p]),
+    "zh_plan_set_profiling": (None, [_c.c_void_p, _c.c_int]),
+    "zh_plan_kernel_times": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_char_p),
+                                        _c.POINTER(_c.c_float), _c.c_int]),
+    "zh_debug_tokens": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int,
+                                   _c.POINTER(_c.POINTER(_c.c_uint16)), _c.POINTER(_c.c_size_t)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)  # every entry point include/zippy_hip.h declares
+
+
+def load_library(path):
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: build it with `python -m zippy_amd.build` (hipcc, gfx950). "
+            "zippy_amd has no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def _u64(seq):
+    arr = (_c.c_uint64 * len(seq))(*[int(x) for x in seq])
+    return arr
+
+
+class Plan:
+    """A zh_plan: device-resident batch geometry (include/zippy_hip.h)."""
+
+    def __init__(self, engine, handle, n):
+        self.engine, self._h, self.n = engine, handle, n
+
+    def run(self, d_src, d_dst):
+        self.engine._check(self.engine.lib.zh_plan_run(self._h, d_src, d_dst))
+
+    def results(self):
+        lens = (_c.c_uint64 * self.n)()
+        sts = (_c.c_int32 * self.n)()
+        self.engine._check(self.engine.lib.zh_plan_results(self._h, lens, sts))
+        return list(lens), list(sts)
+
+    def device_lens(self):
+        return self.engine.lib.zh_plan_device_lens(self._h)
+
+    def set_src_lens_device(self, d_lens):
+        self.engine._check(self.engine.lib.zh_plan_set_src_lens_device(self._h, d_lens))
+
+    def set_profiling(self, on=True):
+        self.engine.lib.zh_plan_set_profiling(self._h, 1 if on else 0)
+
+    def kernel_times(self):
+        names = (_c.c_char_p * 32)()
+        ms = (_c.c_float * 32)()
+        k = self.engine.lib.zh_plan_kernel_times(self._h, names, ms, 32)
+        return [(names[i].decode(), ms[i]) for i in range(k)]
+
+    def close(self):
+        if self._h:
+            self.engine.lib.zh_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    def __init__(self, lib_path, device=-1, stream=None):
+        self.lib = load_library(lib_path)
+        h = _c.c_void_p()
+        st = self.lib.zh_create(device, stream, _c.byref(h))
+        if st != 0:
+            raise ZippyError(st, "zh_create: %s (no usable MI355X? zippy_amd has no CPU fallback)" %
+                             self.lib.zh_strerror(st).decode())
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self.lib.zh_destroy(self._h)
+            self._h = None
+
+    def _check(self, st):
+        if st != 0:
+            msg = self.lib.zh_strerror(st).decode()
+            if st == 20:
+                msg += ": " + self.lib.zh_last_error(self._h).decode()
+            raise ZippyError(st, msg)
+
+    def set_gzip_fname_len(self, k):
+        self.lib.zh_set_gzip_fname_len(self._h, k)
+
+    def compress_bound(self, n, data_format=dfGzip):
+        return self.lib.zh_compress_bound(n, data_format)
+
+    # ---- host-buffer batch API ----
+    def _batch(self, fn, bufs, *mid):
+        n = len(bufs)
+        keep = [bytes(b) for b in bufs]
+        srcs = (_c.c_void_p * n)(*[_c.cast(_c.c_char_p(k), _c.c_void_p) for k in keep])
+        lens = (_c.c_size_t * n)(*[len(k) for k in keep])
+        dsts = (_c.c_void_p * n)()
+        dlens = (_c.c_size_t * n)()
+        sts = (_c.c_int32 * n)()
+        rc = fn(self._h, srcs, lens, n, *mid, dsts, dlens, sts)
+        outs = []
+        try:
+            for i in range(n):
+                outs.append(_c.string_at(dsts[i], dlens[i]) if dsts[i] and sts[i] == 0 else None)
+        finally:
+            for i in range(n):
+                if dsts[i]:
+                    self.lib.zh_free(dsts[i])
+        self._check(rc)
+        return outs, list(sts)
+
+    def compress_batch(self, bufs, level=DefaultCompression, data_format=dfGzip):
+        """-> (list of bytes | None, list of statuses)"""
+        return self._batch(self.lib.zh_compress_batch, bufs, level, data_format)
+
+    def uncompress_batch(self, bufs, data_format=dfDetect):
+        return self._batch(self.lib.zh_uncompress_batch, bufs, data_format)
+
+    def _raise_first(self, outs, sts):
+        for st in sts:
+            if st != 0:
+                raise ZippyError(st, self.lib.zh_strerror(st).decode())
+        return outs
+
+    def compress(self, src, level=DefaultCompression, data_format=dfGzip):
+        try:
+            outs, sts = self.compress_batch([src], level, data_format)
+        except ZippyError:
+            raise
+        return self._raise_first(outs, sts)[0]
+
+    def uncompress(self, src, data_format=dfDetect):
+        outs, sts = self.uncompress_batch([src], data_format)
+        return self._raise_first(outs, sts)[0]
+
+    def crc32(self, src):
+        src = bytes(src)
+        out = _c.c_uint32()
+        self._check(self.lib.zh_crc32(self._h, src, len(src), _c.byref(out)))
+        return out.value
+
+    def adler32(self, src):
+        src = bytes(src)
+        out = _c.c_uint32()
+        self._check(self.lib.zh_adler32(self._h, src, len(src), _c.byref(out)))
+        return out.value
+
+    # ---- device-resident API ----
+    def plan_compress(self, src_off, src_len, dst_off, dst_cap, level, data_format):
+        h = _c.c_void_p()
+        n = len(src_off)
+        self._check(self.lib.zh_plan_compress(self._h, n, _u64(src_off), _u64(src_len),
+                                              _u64(dst_off), _u64(dst_cap), level, data_format,
+                                              _c.byref(h)))
+        return Plan(self, h, n)
+
+    def plan_uncompress(self, src_off, src_len, dst_off, dst_cap, data_format=dfDetect):
+        h = _c.c_void_p()
+        n = len(src_off)
+        self._check(self.lib.zh_plan_uncompress(self._h, n, _u64(src_off), _u64(src_len),
+                                                _u64(dst_off), _u64(dst_cap), data_format,
+                                                _c.byref(h)))
+        return Plan(self, h, n)
+
+    def stream(self):
+        return self.lib.zh_stream(self._h)
+
+    # ---- parity introspection ----
+    def debug_tokens(self, src, level):
+        import numpy as np
+        src = bytes(src)
+        toks = _c.POINTER(_c.c_uint16)()
+        n = _c.c_size_t()
+        self._check(self.lib.zh_debug_tokens(self._h, src, len(src), level, _c.byref(toks),
+                                             _c.byref(n)))
+        try:
+            return np.ctypeslib.as_array(toks, shape=(n.value,)).copy() if n.value else np.zeros(
+                0, np.uint16)
+        finally:
+            self.lib.zh_free(toks)

@@ -1,0 +1,52 @@
+"""Host-side mirror of the reference interface for the hot path (src/zippy.nim):
+
+    compress(src, level=DefaultCompression, dataFormat=dfGzip) -> bytes     zippy.nim:11-16,86-98
+    uncompress(src, dataFormat=dfDetect) -> bytes                          zippy.nim:100-104,167-177
+    crc32(src) / adler32(src)                                              crc.nim:53,74 / adler32.nim:6,65
+
+plus the batch forms the engine is built for.  Same names, argument meaning and
+error behaviour (ZippyError) as the reference; every call goes through the C ABI
+in include/zippy_hip.h into the gfx950 kernels.  No CPU fallback: importing this
+module without the built library, or without a usable GPU, raises.
+"""
+import os
+
+from ._binding import Engine
+from .common import (ZippyError, dfDetect, dfZlib, dfGzip, dfDeflate, NoCompression, BestSpeed,
+                     BestCompression, DefaultCompression, HuffmanOnly)
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libzippy_hip.so")
+
+_engine = None
+
+
+def engine():
+    global _engine
+    if _engine is None:
+        _engine = Engine(LIB_PATH)
+    return _engine
+
+
+def compress(src, level=DefaultCompression, dataFormat=dfGzip):
+    return engine().compress(src, level, dataFormat)
+
+
+def uncompress(src, dataFormat=dfDetect):
+    return engine().uncompress(src, dataFormat)
+
+
+def compress_batch(bufs, level=DefaultCompression, dataFormat=dfGzip):
+    """n independent compress() calls in one launch sequence -> (outputs, statuses)."""
+    return engine().compress_batch(bufs, level, dataFormat)
+
+
+def uncompress_batch(bufs, dataFormat=dfDetect):
+    return engine().uncompress_batch(bufs, dataFormat)
+
+
+def crc32(src):
+    return engine().crc32(src)
+
+
+def adler32(src):
+    return engine().adler32(src)

@@ -1,0 +1,897 @@
+// Host side of the C ABI (include/zippy_hip.h): contexts, plans (device
+// descriptors + scratch), kernel sequencing on one HIP stream, and the
+// host-buffer batch entry points.  No compute happens here.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "zh_common.h"
+#include "zh_tables.h"
+
+// ---- kernel launchers (defined next to their kernels) ----
+extern "C" {
+const void* zh_checksum_tables(int device);
+void zh_launch_checksum_pieces(hipStream_t, const void* tabs, const uint8_t* d_data,
+                               const ZhPieceDesc* pieces, uint32_t npieces, const uint64_t* dyn_len,
+                               int want_crc, int want_adler, uint32_t* out_crc, uint32_t* out_adler,
+                               uint32_t* out_len);
+void zh_launch_checksum_combine(hipStream_t, const ZhBufDesc* bufs, uint32_t nbufs,
+                                const uint32_t* piece_crc, const uint32_t* piece_adler,
+                                const uint32_t* piece_len, int want_crc, int want_adler,
+                                uint32_t* buf_crc, uint32_t* buf_adler);
+void zh_launch_unwrap(hipStream_t, const uint8_t* d_src, ZhInflateArgs a);
+void zh_launch_inflate(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a);
+void zh_launch_verify(hipStream_t, ZhInflateArgs a, const uint32_t* buf_crc, const uint32_t* buf_adler);
+void zh_launch_l1_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int huffman_only);
+void zh_launch_chain_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
+                           int max_chain, uint16_t* head_scratch);
+void zh_launch_frag_stats(hipStream_t, const uint8_t* d_src, ZhCompressArgs a);
+void zh_launch_huffman(hipStream_t, ZhCompressArgs a);
+void zh_launch_layout(hipStream_t, uint8_t* d_dst, ZhCompressArgs a, const uint32_t* buf_crc,
+                      const uint32_t* buf_adler);
+void zh_launch_emit(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhCompressArgs a);
+}
+
+// internal.nim:177-189 configurationTable (good, nice, chain); `lazy` is unused by the reference
+static const int kChainConfig[10][3] = {{0, 0, 0},     {4, 8, 4},      {4, 16, 8},    {4, 32, 32},
+                                        {4, 16, 16},   {8, 32, 32},    {8, 128, 128}, {8, 256, 256},
+                                        {32, 258, 1024}, {32, 258, 4096}};
+
+struct zh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int fname_len = -1;
+  std::string last_error;
+  const void* cktabs = nullptr;
+  std::mt19937 rng{std::random_device{}()};
+};
+
+#define ZH_HIP(ctx, call)                                                            \
+  do {                                                                               \
+    hipError_t e_ = (call);                                                          \
+    if (e_ != hipSuccess) {                                                          \
+      (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);         \
+      return ZH_ERR_DEVICE;                                                          \
+    }                                                                                \
+  } while (0)
+
+extern "C" const char* zh_strerror(int status) {
+  switch (status) {
+    case ZH_OK: return "ok";
+    case ZH_ERR_INVALID_LEVEL: return "Invalid compression level";
+    case ZH_ERR_INVALID_FORMAT: return "Invalid data format";
+    case ZH_ERR_DETECT: return "Unable to detect compressed data format";
+    case ZH_ERR_UNSUPPORTED_METHOD: return "Unsupported compression method";
+    case ZH_ERR_COMPRESSION_INFO: return "Invalid compression info";
+    case ZH_ERR_INVALID_HEADER: return "Invalid header";
+    case ZH_ERR_PRESET_DICT: return "Preset dictionary is not yet supported";
+    case ZH_ERR_CHECKSUM: return "Checksum verification failed";
+    case ZH_ERR_SIZE: return "Size verification failed";
+    case ZH_ERR_GZIP_ID: return "Failed gzip identification values check";
+    case ZH_ERR_RESERVED_FLAGS: return "Reserved flag bits set";
+    case ZH_ERR_UNSUPPORTED_FLAGS: return "Currently unsupported flags are set";
+    case ZH_ERR_INVALID_BUFFER: return "Invalid buffer, unable to uncompress";
+    case ZH_ERR_COMPRESS_INTERNAL: return "Unexpected error while compressing";
+    case ZH_ERR_END_OF_BUFFER: return "Cannot read further, at end of buffer";
+    case ZH_ERR_BYTE_BOUNDARY: return "Must be at a byte boundary";
+    case ZH_ERR_BLOCK_HEADER: return "Invalid block header";
+    case ZH_ERR_INVALID_SYMBOL: return "Invalid symbol";
+    case ZH_ERR_NOMEM: return "Out of memory";
+    case ZH_ERR_DEVICE: return "GPU/HIP error";
+    case ZH_ERR_DST_TOO_SMALL: return "Output slot too small";
+    case ZH_ERR_ARGUMENT: return "Invalid argument";
+    default: return "Unknown status";
+  }
+}
+
+extern "C" int zh_create(int device, void* stream, zh_ctx** out) {
+  if (!out) return ZH_ERR_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZH_ERR_DEVICE;
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) return ZH_ERR_DEVICE;
+  }
+  if (device >= count) return ZH_ERR_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return ZH_ERR_DEVICE;
+  zh_ctx* c = new zh_ctx;
+  c->device = device;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreate(&c->stream) != hipSuccess) {
+      delete c;
+      return ZH_ERR_DEVICE;
+    }
+    c->own_stream = true;
+  }
+  c->cktabs = zh_checksum_tables(device);
+  if (!c->cktabs) {
+    delete c;
+    return ZH_ERR_DEVICE;
+  }
+  *out = c;
+  return ZH_OK;
+}
+
+extern "C" void zh_destroy(zh_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+extern "C" const char* zh_last_error(zh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+extern "C" void* zh_stream(zh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" void zh_set_gzip_fname_len(zh_ctx* ctx, int k) {
+  if (ctx) ctx->fname_len = k > 25 ? 25 : k;
+}
+extern "C" void zh_free(void* p) { free(p); }
+
+static size_t container_overhead(int fmt) {
+  return fmt == ZH_DF_GZIP ? 10 + 26 + 8 : fmt == ZH_DF_ZLIB ? 6 : 0;
+}
+// Worst case of the reference's encoder: it has no "stored if larger" fallback, so
+// a block that escapes the 98 % literal test can still use up to 15 bits per
+// literal; every block adds a <= 1 KiB header.
+extern "C" size_t zh_compress_bound(size_t len, int data_format) {
+  size_t nblocks = (len + ZH_BLOCK_SIZE - 1) / ZH_BLOCK_SIZE;
+  if (!nblocks) nblocks = 1;
+  return len * 2 + 1024 * nblocks + 5 * (len / ZH_STORED_MAX + 1) + container_overhead(data_format) + 64;
+}
+static size_t typical_cap(size_t len, int fmt) {
+  size_t nblocks = (len + ZH_BLOCK_SIZE - 1) / ZH_BLOCK_SIZE;
+  if (!nblocks) nblocks = 1;
+  return len + len / 8 + 1024 * nblocks + 5 * (len / ZH_STORED_MAX + 1) + container_overhead(fmt) + 64;
+}
+
+// ---------------------------------------------------------------------------
+// plans
+// ---------------------------------------------------------------------------
+struct Arena {
+  size_t size = 0;
+  uint8_t* base = nullptr;
+  size_t reserve(size_t bytes) {
+    size_t off = (size + 255) & ~(size_t)255;
+    size = off + bytes;
+    return off;
+  }
+};
+
+struct zh_plan {
+  zh_ctx* ctx = nullptr;
+  bool is_compress = true;
+  size_t n = 0;
+  int level = 0, fmt = 0;
+  int count_only = 0;
+  uint8_t* arena = nullptr;
+  ZhCompressArgs ca{};
+  ZhInflateArgs ia{};
+  ZhBufDesc* d_bufs = nullptr;
+  ZhPieceDesc* d_pieces = nullptr;
+  uint32_t npieces = 0;
+  uint32_t *piece_crc = nullptr, *piece_adler = nullptr, *piece_len = nullptr;
+  uint32_t *buf_crc = nullptr, *buf_adler = nullptr;
+  uint16_t* head_scratch = nullptr;
+  size_t head_bytes = 0;
+  uint64_t dst_lo = 0, dst_hi = 0;  // byte range of d_dst covered by the slots
+  uint64_t* out_len = nullptr;
+  int32_t* status = nullptr;
+  const uint64_t* src_len_dev = nullptr;
+  // profiling
+  bool profiling = false;
+  std::vector<const char*> k_names;
+  std::vector<hipEvent_t> k_events;
+  std::vector<float> k_ms;
+};
+
+static void prof_mark(zh_plan* p, const char* name) {
+  if (!p->profiling) return;
+  size_t i = p->k_names.size();
+  if (p->k_events.size() <= i) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    p->k_events.push_back(e);
+  }
+  hipEventRecord(p->k_events[i], p->ctx->stream);
+  p->k_names.push_back(name);
+}
+
+extern "C" void zh_plan_set_profiling(zh_plan* plan, int on) {
+  if (plan) plan->profiling = on != 0;
+}
+
+extern "C" int zh_plan_kernel_times(zh_plan* p, const char** names, float* ms, int max_entries) {
+  if (!p || !p->profiling || p->k_names.size() < 2) return 0;
+  hipStreamSynchronize(p->ctx->stream);
+  int cnt = 0;
+  for (size_t i = 0; i + 1 < p->k_names.size() && cnt < max_entries; i++) {
+    float t = 0;
+    hipEventElapsedTime(&t, p->k_events[i], p->k_events[i + 1]);
+    names[cnt] = p->k_names[i];  // the marker recorded BEFORE a launch carries its name
+    ms[cnt] = t;
+    cnt++;
+  }
+  return cnt;
+}
+
+extern "C" void zh_plan_destroy(zh_plan* p) {
+  if (!p) return;
+  hipStreamSynchronize(p->ctx->stream);
+  if (p->arena) hipFree(p->arena);
+  for (auto e : p->k_events) hipEventDestroy(e);
+  delete p;
+}
+
+template <class T>
+static T* carve(uint8_t* base, size_t off) {
+  return reinterpret_cast<T*>(base + off);
+}
+
+extern "C" int zh_plan_compress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
+                                const uint64_t* src_len, const uint64_t* dst_off,
+                                const uint64_t* dst_cap, int level, int data_format, zh_plan** out) {
+  if (!ctx || !out || (n && (!src_off || !src_len || !dst_off || !dst_cap))) return ZH_ERR_ARGUMENT;
+  *out = nullptr;
+  if (level < -2 || level > 9) return ZH_ERR_INVALID_LEVEL;  // deflate.nim:208-209
+  if (data_format != ZH_DF_GZIP && data_format != ZH_DF_ZLIB && data_format != ZH_DF_DEFLATE)
+    return ZH_ERR_INVALID_FORMAT;  // zippy.nim:83-84
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+
+  std::vector<ZhBufDesc> bufs(n);
+  std::vector<ZhBlockDesc> blocks;
+  std::vector<ZhFragDesc> frags;
+  std::vector<ZhPieceDesc> pieces;
+  uint64_t lo = ~0ull, hi = 0;
+  for (size_t i = 0; i < n; i++) {
+    ZhBufDesc& b = bufs[i];
+    b.src_off = src_off[i];
+    b.src_len = src_len[i];
+    b.dst_off = dst_off[i];
+    b.dst_cap = dst_cap[i];
+    b.first_block = (uint32_t)blocks.size();
+    b.first_piece = (uint32_t)frags.size();
+    int k = ctx->fname_len;
+    if (k < 0) k = (int)(ctx->rng() % 26);  // zippy.nim:28-38
+    b.fname_len = (uint32_t)k;
+    b.pad = 0;
+    // deflate.nim:228: blocks of <= 4 MiB; level 0 uses one run of stored chunks over the
+    // whole buffer (deflate.nim:214-226)
+    const uint64_t bsize = level == 0 ? (b.src_len ? b.src_len : 1) : ZH_BLOCK_SIZE;
+    uint64_t nb = (b.src_len + bsize - 1) / bsize;
+    if (nb < 1) nb = 1;
+    for (uint64_t j = 0; j < nb; j++) {
+      ZhBlockDesc blk;
+      const uint64_t bstart = j * bsize;
+      blk.src_off = b.src_off + bstart;
+      blk.len = std::min<uint64_t>(b.src_len - bstart, bsize);
+      blk.buf = (uint32_t)i;
+      blk.first_frag = (uint32_t)frags.size();
+      blk.is_final = j == nb - 1;
+      for (uint64_t o = 0; o < blk.len; o += ZH_FRAG_SIZE) {
+        ZhFragDesc f;
+        f.src_off = blk.src_off + o;
+        f.len = (uint32_t)std::min<uint64_t>(blk.len - o, ZH_FRAG_SIZE);
+        f.block = (uint32_t)blocks.size();
+        frags.push_back(f);
+        pieces.push_back(ZhPieceDesc{f.src_off, f.len, (uint32_t)i, bstart + o});
+      }
+      blk.nfrag = (uint32_t)frags.size() - blk.first_frag;
+      blocks.push_back(blk);
+    }
+    b.nblocks = (uint32_t)blocks.size() - b.first_block;
+    b.npieces = (uint32_t)frags.size() - b.first_piece;
+    lo = std::min(lo, b.dst_off);
+    hi = std::max(hi, b.dst_off + b.dst_cap);
+  }
+  if (blocks.size() >= 0xffffffffull || frags.size() >= 0xffffffffull) return ZH_ERR_ARGUMENT;
+
+  zh_plan* p = new zh_plan;
+  p->ctx = ctx;
+  p->is_compress = true;
+  p->n = n;
+  p->level = level;
+  p->fmt = data_format;
+  p->dst_lo = n ? lo : 0;
+  p->dst_hi = n ? hi : 0;
+  const size_t nf = frags.size(), nb = blocks.size();
+  const bool chain = level == -1 || level >= 2;
+  const bool need_matches = level != 0;
+
+  Arena ar;
+  const size_t o_bufs = ar.reserve(n * sizeof(ZhBufDesc));
+  const size_t o_blocks = ar.reserve(nb * sizeof(ZhBlockDesc));
+  const size_t o_frags = ar.reserve(nf * sizeof(ZhFragDesc));
+  const size_t o_pieces = ar.reserve(nf * sizeof(ZhPieceDesc));
+  const size_t mslots = need_matches ? nf * ZH_MAX_MATCHES_PER_FRAG : 0;
+  const size_t o_mpos = ar.reserve(mslots * 2), o_mlen = ar.reserve(mslots * 2), o_moff = ar.reserve(mslots * 2);
+  const size_t o_fnm = ar.reserve(nf * 4), o_fsp = ar.reserve(nf * 4), o_fnl = ar.reserve(nf * 4),
+               o_fex = ar.reserve(nf * 4), o_fhist = ar.reserve(nf * ZH_HIST_STRIDE * 2),
+               o_fbits = ar.reserve(nf * 4), o_fstart = ar.reserve(nf * 8);
+  const size_t o_pcrc = ar.reserve(nf * 4), o_pad = ar.reserve(nf * 4), o_plen = ar.reserve(nf * 4);
+  const size_t o_bmode = ar.reserve(nb * 4), o_blit = ar.reserve(nb * 288 * 4),
+               o_bdist = ar.reserve(nb * 32 * 4), o_bhdr = ar.reserve(nb * ZH_HDR_WORDS * 4),
+               o_bhb = ar.reserve(nb * 4), o_bbits = ar.reserve(nb * 8), o_bd0 = ar.reserve(nb * 8);
+  const size_t o_bcrc = ar.reserve(n * 4), o_bad = ar.reserve(n * 4), o_olen = ar.reserve(n * 8),
+               o_st = ar.reserve(n * 4);
+  p->head_bytes = chain ? nb * ((size_t)2 << 17) : 0;
+  const size_t o_head = ar.reserve(p->head_bytes);
+  ar.reserve(256);
+
+  if (hipMalloc(&p->arena, ar.size) != hipSuccess) {
+    ctx->last_error = "hipMalloc(plan arena, " + std::to_string(ar.size) + " bytes)";
+    delete p;
+    return ZH_ERR_NOMEM;
+  }
+  uint8_t* base = p->arena;
+  hipStream_t s = ctx->stream;
+  hipMemcpyAsync(base + o_bufs, bufs.data(), n * sizeof(ZhBufDesc), hipMemcpyHostToDevice, s);
+  hipMemcpyAsync(base + o_blocks, blocks.data(), nb * sizeof(ZhBlockDesc), hipMemcpyHostToDevice, s);
+  hipMemcpyAsync(base + o_frags, frags.data(), nf * sizeof(ZhFragDesc), hipMemcpyHostToDevice, s);
+  hipMemcpyAsync(base + o_pieces, pieces.data(), nf * sizeof(ZhPieceDesc), hipMemcpyHostToDevice, s);
+  hipMemsetAsync(base + o_fnm, 0, nf * 4, s);
+  hipMemsetAsync(base + o_fsp, 0, nf * 4, s);
+  hipMemsetAsync(base + o_fhist, 0, nf * ZH_HIST_STRIDE * 2, s);
+  hipMemsetAsync(base + o_fnl, 0, nf * 4, s);
+  hipMemsetAsync(base + o_fex, 0, nf * 4, s);
+  ZH_HIP(ctx, hipStreamSynchronize(s));  // host vectors go out of scope
+
+  ZhCompressArgs& a = p->ca;
+  a.bufs = p->d_bufs = carve<ZhBufDesc>(base, o_bufs);
+  a.blocks = carve<ZhBlockDesc>(base, o_blocks);
+  a.frags = carve<ZhFragDesc>(base, o_frags);
+  p->d_pieces = carve<ZhPieceDesc>(base, o_pieces);
+  p->npieces = (uint32_t)nf;
+  a.nfrags = (uint32_t)nf;
+  a.nblocks = (uint32_t)nb;
+  a.nbufs = (uint32_t)n;
+  a.level = level;
+  a.data_format = data_format;
+  a.m_pos = carve<uint16_t>(base, o_mpos);
+  a.m_len = carve<uint16_t>(base, o_mlen);
+  a.m_off = carve<uint16_t>(base, o_moff);
+  a.f_nmatch = carve<uint32_t>(base, o_fnm);
+  a.f_spill = carve<uint32_t>(base, o_fsp);
+  a.f_nlit = carve<uint32_t>(base, o_fnl);
+  a.f_extra_bits = carve<uint32_t>(base, o_fex);
+  a.f_hist = carve<uint16_t>(base, o_fhist);
+  a.f_crc = p->piece_crc = carve<uint32_t>(base, o_pcrc);
+  a.f_adler = p->piece_adler = carve<uint32_t>(base, o_pad);
+  p->piece_len = carve<uint32_t>(base, o_plen);
+  a.f_bits = carve<uint32_t>(base, o_fbits);
+  a.f_bit_start = carve<uint64_t>(base, o_fstart);
+  a.b_mode = carve<uint32_t>(base, o_bmode);
+  a.b_litcode = carve<uint32_t>(base, o_blit);
+  a.b_distcode = carve<uint32_t>(base, o_bdist);
+  a.b_hdr = carve<uint32_t>(base, o_bhdr);
+  a.b_hdr_bits = carve<uint32_t>(base, o_bhb);
+  a.b_bits = carve<uint64_t>(base, o_bbits);
+  a.b_stored_d0 = carve<uint64_t>(base, o_bd0);
+  p->buf_crc = carve<uint32_t>(base, o_bcrc);
+  p->buf_adler = carve<uint32_t>(base, o_bad);
+  a.out_len = p->out_len = carve<uint64_t>(base, o_olen);
+  a.status = p->status = carve<int32_t>(base, o_st);
+  p->head_scratch = carve<uint16_t>(base, o_head);
+  *out = p;
+  return ZH_OK;
+}
+
+extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
+                                  const uint64_t* src_len, const uint64_t* dst_off,
+                                  const uint64_t* dst_cap, int data_format, zh_plan** out) {
+  if (!ctx || !out || (n && (!src_off || !src_len || !dst_off || !dst_cap))) return ZH_ERR_ARGUMENT;
+  *out = nullptr;
+  if (data_format < ZH_DF_DETECT || data_format > ZH_DF_DEFLATE) return ZH_ERR_INVALID_FORMAT;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<ZhBufDesc> bufs(n);
+  std::vector<ZhPieceDesc> pieces;
+  for (size_t i = 0; i < n; i++) {
+    ZhBufDesc& b = bufs[i];
+    memset(&b, 0, sizeof(b));
+    b.src_off = src_off[i];
+    b.src_len = src_len[i];
+    b.dst_off = dst_off[i];
+    b.dst_cap = dst_cap[i];
+    b.first_piece = (uint32_t)pieces.size();
+    for (uint64_t o = 0; o < b.dst_cap; o += ZH_FRAG_SIZE)
+      pieces.push_back(ZhPieceDesc{b.dst_off + o, 0, (uint32_t)i, o});
+    b.npieces = (uint32_t)pieces.size() - b.first_piece;
+  }
+  zh_plan* p = new zh_plan;
+  p->ctx = ctx;
+  p->is_compress = false;
+  p->n = n;
+  p->fmt = data_format;
+  const size_t np = pieces.size();
+  Arena ar;
+  const size_t o_bufs = ar.reserve(n * sizeof(ZhBufDesc)), o_pieces = ar.reserve(np * sizeof(ZhPieceDesc));
+  const size_t o_pcrc = ar.reserve(np * 4), o_pad = ar.reserve(np * 4), o_plen = ar.reserve(np * 4);
+  const size_t o_bp = ar.reserve(n * 4), o_fmt = ar.reserve(n * 4), o_es = ar.reserve(n * 4),
+               o_ei = ar.reserve(n * 4), o_bcrc = ar.reserve(n * 4), o_bad = ar.reserve(n * 4),
+               o_olen = ar.reserve(n * 8), o_st = ar.reserve(n * 4);
+  ar.reserve(256);
+  if (hipMalloc(&p->arena, ar.size) != hipSuccess) {
+    ctx->last_error = "hipMalloc(plan arena)";
+    delete p;
+    return ZH_ERR_NOMEM;
+  }
+  uint8_t* base = p->arena;
+  hipMemcpyAsync(base + o_bufs, bufs.data(), n * sizeof(ZhBufDesc), hipMemcpyHostToDevice, ctx->stream);
+  hipMemcpyAsync(base + o_pieces, pieces.data(), np * sizeof(ZhPieceDesc), hipMemcpyHostToDevice, ctx->stream);
+  ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  p->d_bufs = carve<ZhBufDesc>(base, o_bufs);
+  p->d_pieces = carve<ZhPieceDesc>(base, o_pieces);
+  p->npieces = (uint32_t)np;
+  p->piece_crc = carve<uint32_t>(base, o_pcrc);
+  p->piece_adler = carve<uint32_t>(base, o_pad);
+  p->piece_len = carve<uint32_t>(base, o_plen);
+  p->buf_crc = carve<uint32_t>(base, o_bcrc);
+  p->buf_adler = carve<uint32_t>(base, o_bad);
+  ZhInflateArgs& a = p->ia;
+  a.bufs = p->d_bufs;
+  a.src_len_dev = nullptr;
+  a.nbufs = (uint32_t)n;
+  a.data_format = data_format;
+  a.count_only = 0;
+  a.body_pos = carve<uint32_t>(base, o_bp);
+  a.fmt = carve<uint32_t>(base, o_fmt);
+  a.expect_sum = carve<uint32_t>(base, o_es);
+  a.expect_isize = carve<uint32_t>(base, o_ei);
+  a.out_len = p->out_len = carve<uint64_t>(base, o_olen);
+  a.status = p->status = carve<int32_t>(base, o_st);
+  *out = p;
+  return ZH_OK;
+}
+
+extern "C" int zh_plan_set_src_lens_device(zh_plan* plan, const uint64_t* d_lens) {
+  if (!plan || plan->is_compress) return ZH_ERR_ARGUMENT;
+  plan->ia.src_len_dev = d_lens;
+  return ZH_OK;
+}
+
+static void plan_set_count_only(zh_plan* plan, int on) { plan->ia.count_only = on; }
+
+extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
+  if (!p) return ZH_ERR_ARGUMENT;
+  zh_ctx* ctx = p->ctx;
+  hipStream_t s = ctx->stream;
+  const uint8_t* d_src = (const uint8_t*)d_src_v;
+  uint8_t* d_dst = (uint8_t*)d_dst_v;
+  p->k_names.clear();
+  if (!p->n) return ZH_OK;
+  if (p->is_compress) {
+    const ZhCompressArgs& a = p->ca;
+    const int want_crc = p->fmt == ZH_DF_GZIP, want_adler = p->fmt == ZH_DF_ZLIB;
+    // every shared output word is OR-ed into place, so the slots start out zeroed
+    prof_mark(p, "memset_dst");
+    ZH_HIP(ctx, hipMemsetAsync(d_dst + p->dst_lo, 0, p->dst_hi - p->dst_lo, s));
+    if (p->level == 1 || p->level == -2) {
+      prof_mark(p, "zh_l1_match_kernel");
+      zh_launch_l1_match(s, d_src, a, p->level == -2);
+    } else if (p->level != 0) {
+      const int* cfg = kChainConfig[p->level == -1 ? 6 : p->level];
+      prof_mark(p, "memset_head");
+      ZH_HIP(ctx, hipMemsetAsync(p->head_scratch, 0, p->head_bytes, s));
+      prof_mark(p, "zh_chain_match_kernel");
+      zh_launch_chain_match(s, d_src, a, cfg[0], cfg[1], cfg[2], p->head_scratch);
+      prof_mark(p, "zh_frag_stats_kernel");
+      zh_launch_frag_stats(s, d_src, a);
+    }
+    if (want_crc || want_adler) {
+      prof_mark(p, "zh_checksum_pieces_kernel");
+      zh_launch_checksum_pieces(s, ctx->cktabs, d_src, p->d_pieces, p->npieces, nullptr, want_crc,
+                                want_adler, p->piece_crc, p->piece_adler, p->piece_len);
+      prof_mark(p, "zh_checksum_combine_kernel");
+      zh_launch_checksum_combine(s, p->d_bufs, (uint32_t)p->n, p->piece_crc, p->piece_adler,
+                                 p->piece_len, want_crc, want_adler, p->buf_crc, p->buf_adler);
+    }
+    prof_mark(p, "zh_huffman_kernel");
+    zh_launch_huffman(s, a);
+    prof_mark(p, "zh_layout_kernel");
+    zh_launch_layout(s, d_dst, a, p->buf_crc, p->buf_adler);
+    prof_mark(p, "zh_emit_kernel");
+    zh_launch_emit(s, d_src, d_dst, a);
+    prof_mark(p, "end");
+  } else {
+    const ZhInflateArgs& a = p->ia;
+    prof_mark(p, "zh_unwrap_kernel");
+    zh_launch_unwrap(s, d_src, a);
+    prof_mark(p, "zh_inflate_kernel");
+    zh_launch_inflate(s, d_src, d_dst, a);
+    if (!a.count_only) {
+      // both checksums: with dfDetect the format is only known per stream on the device
+      const int want_crc = p->fmt == ZH_DF_GZIP || p->fmt == ZH_DF_DETECT;
+      const int want_adler = p->fmt == ZH_DF_ZLIB || p->fmt == ZH_DF_DETECT;
+      if (want_crc || want_adler) {
+        prof_mark(p, "zh_checksum_pieces_kernel");
+        zh_launch_checksum_pieces(s, ctx->cktabs, d_dst, p->d_pieces, p->npieces, p->out_len,
+                                  want_crc, want_adler, p->piece_crc, p->piece_adler, p->piece_len);
+        prof_mark(p, "zh_checksum_combine_kernel");
+        zh_launch_checksum_combine(s, p->d_bufs, (uint32_t)p->n, p->piece_crc, p->piece_adler,
+                                   p->piece_len, want_crc, want_adler, p->buf_crc, p->buf_adler);
+        prof_mark(p, "zh_verify_kernel");
+        zh_launch_verify(s, a, p->buf_crc, p->buf_adler);
+      }
+    }
+    prof_mark(p, "end");
+  }
+  ZH_HIP(ctx, hipGetLastError());
+  return ZH_OK;
+}
+
+extern "C" int zh_plan_results(zh_plan* p, uint64_t* out_lens, int32_t* statuses) {
+  if (!p) return ZH_ERR_ARGUMENT;
+  zh_ctx* ctx = p->ctx;
+  if (out_lens) ZH_HIP(ctx, hipMemcpyAsync(out_lens, p->out_len, p->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (statuses) ZH_HIP(ctx, hipMemcpyAsync(statuses, p->status, p->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZH_OK;
+}
+extern "C" const uint64_t* zh_plan_device_lens(zh_plan* p) { return p ? p->out_len : nullptr; }
+extern "C" const int32_t* zh_plan_device_statuses(zh_plan* p) { return p ? p->status : nullptr; }
+
+// ---------------------------------------------------------------------------
+// host-buffer API
+// ---------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+  uint8_t* p = nullptr;
+  ~DevBuf() {
+    if (p) hipFree(p);
+  }
+};
+struct PlanGuard {
+  zh_plan* p = nullptr;
+  ~PlanGuard() { zh_plan_destroy(p); }
+};
+
+// Pack host buffers into one device allocation (256-byte aligned slices).
+int upload(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n, DevBuf& dev,
+           std::vector<uint64_t>& off, std::vector<uint64_t>& len64) {
+  off.resize(n);
+  len64.resize(n);
+  uint64_t total = 0;
+  for (size_t i = 0; i < n; i++) {
+    off[i] = total;
+    len64[i] = lens[i];
+    total += (lens[i] + 255) & ~(uint64_t)255;
+  }
+  total += 256;
+  if (hipMalloc(&dev.p, total) != hipSuccess) return ZH_ERR_NOMEM;
+  for (size_t i = 0; i < n; i++)
+    if (lens[i]) ZH_HIP(ctx, hipMemcpyAsync(dev.p + off[i], srcs[i], lens[i], hipMemcpyHostToDevice, ctx->stream));
+  return ZH_OK;
+}
+}  // namespace
+
+extern "C" int zh_compress_batch(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
+                                 int level, int data_format, void** dsts, size_t* dst_lens,
+                                 int32_t* statuses) {
+  if (!ctx || (n && (!srcs || !lens || !dsts || !dst_lens || !statuses))) return ZH_ERR_ARGUMENT;
+  for (size_t i = 0; i < n; i++) {
+    dsts[i] = nullptr;
+    dst_lens[i] = 0;
+    statuses[i] = ZH_OK;
+  }
+  if (level < -2 || level > 9) {
+    for (size_t i = 0; i < n; i++) statuses[i] = ZH_ERR_INVALID_LEVEL;
+    return ZH_ERR_INVALID_LEVEL;
+  }
+  if (data_format != ZH_DF_GZIP && data_format != ZH_DF_ZLIB && data_format != ZH_DF_DEFLATE) {
+    for (size_t i = 0; i < n; i++) statuses[i] = ZH_ERR_INVALID_FORMAT;
+    return ZH_ERR_INVALID_FORMAT;
+  }
+  if (!n) return ZH_OK;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf d_src;
+  std::vector<uint64_t> soff, slen;
+  int st = upload(ctx, srcs, lens, n, d_src, soff, slen);
+  if (st) return st;
+
+  for (int attempt = 0; attempt < 2; attempt++) {
+    std::vector<uint64_t> doff(n), dcap(n);
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+      doff[i] = total;
+      dcap[i] = attempt == 0 ? typical_cap(lens[i], data_format) : zh_compress_bound(lens[i], data_format);
+      total += (dcap[i] + 255) & ~(uint64_t)255;
+    }
+    DevBuf d_dst;
+    if (hipMalloc(&d_dst.p, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
+    PlanGuard pg;
+    st = zh_plan_compress(ctx, n, soff.data(), slen.data(), doff.data(), dcap.data(), level,
+                          data_format, &pg.p);
+    if (st) return st;
+    st = zh_plan_run(pg.p, d_src.p, d_dst.p);
+    if (st) return st;
+    std::vector<uint64_t> olen(n);
+    std::vector<int32_t> ost(n);
+    st = zh_plan_results(pg.p, olen.data(), ost.data());
+    if (st) return st;
+    bool retry = false;
+    for (size_t i = 0; i < n; i++)
+      if (ost[i] == ZH_ERR_DST_TOO_SMALL) retry = true;
+    if (retry && attempt == 0) continue;
+    for (size_t i = 0; i < n; i++) {
+      statuses[i] = ost[i];
+      if (ost[i] != ZH_OK) continue;
+      dsts[i] = malloc(olen[i] ? olen[i] : 1);
+      if (!dsts[i]) {
+        statuses[i] = ZH_ERR_NOMEM;
+        continue;
+      }
+      dst_lens[i] = olen[i];
+      ZH_HIP(ctx, hipMemcpyAsync(dsts[i], d_dst.p + doff[i], olen[i], hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    break;
+  }
+  return ZH_OK;
+}
+
+// Which container will the device see?  (zippy.nim:108-125, sizing only)
+static int host_detect(const uint8_t* s, size_t len, int fmt) {
+  if (fmt != ZH_DF_DETECT) return fmt;
+  if (len > 18 && s[0] == 31 && s[1] == 139 && s[2] == 8 && (s[3] & 0xe0) == 0) return ZH_DF_GZIP;
+  if (len > 6 && (s[0] & 0x0f) == 8 && (s[0] >> 4) <= 7 && (((unsigned)s[0] * 256u) + s[1]) % 31u == 0)
+    return ZH_DF_ZLIB;
+  return ZH_DF_DETECT;
+}
+
+extern "C" int zh_uncompress_batch(zh_ctx* ctx, const void* const* srcs, const size_t* lens,
+                                   size_t n, int data_format, void** dsts, size_t* dst_lens,
+                                   int32_t* statuses) {
+  if (!ctx || (n && (!srcs || !lens || !dsts || !dst_lens || !statuses))) return ZH_ERR_ARGUMENT;
+  for (size_t i = 0; i < n; i++) {
+    dsts[i] = nullptr;
+    dst_lens[i] = 0;
+    statuses[i] = ZH_OK;
+  }
+  if (data_format < ZH_DF_DETECT || data_format > ZH_DF_DEFLATE) {
+    for (size_t i = 0; i < n; i++) statuses[i] = ZH_ERR_INVALID_FORMAT;
+    return ZH_ERR_INVALID_FORMAT;
+  }
+  if (!n) return ZH_OK;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf d_src;
+  std::vector<uint64_t> soff, slen;
+  int st = upload(ctx, srcs, lens, n, d_src, soff, slen);
+  if (st) return st;
+
+  // Output sizes: gzip members carry ISIZE (gzip.nim:64-66, trusted only as a
+  // capacity hint and verified afterwards); zlib / raw streams get a sizing pass.
+  std::vector<uint64_t> cap(n, 0);
+  std::vector<char> need_count(n, 0);
+  bool any_count = false;
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t* s8 = (const uint8_t*)srcs[i];
+    const int f = host_detect(s8, lens[i], data_format);
+    if (f == ZH_DF_GZIP && lens[i] >= 18) {
+      const uint8_t* t = s8 + lens[i] - 4;
+      const uint64_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint64_t)t[3] << 24);
+      const uint64_t max_out = (uint64_t)lens[i] * 1032 + 64;  // deflate cannot expand further
+      cap[i] = std::min(isize, max_out);
+    } else if (f == ZH_DF_ZLIB || f == ZH_DF_DEFLATE) {
+      need_count[i] = 1;
+      any_count = true;
+    }
+  }
+  std::vector<uint64_t> zero_off(n, 0);
+  for (int pass = any_count ? 0 : 1; pass < 3; pass++) {
+    // pass 0: sizing (count only) of the streams without a size field
+    // pass 1: decode; pass 2: re-decode gzip members whose ISIZE wrapped (>= 4 GiB)
+    std::vector<uint64_t> doff(n), dcap(n);
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+      doff[i] = total;
+      dcap[i] = pass == 0 ? 0 : cap[i];
+      if (pass != 0) total += (dcap[i] + 255) & ~(uint64_t)255;
+    }
+    DevBuf d_dst;
+    if (hipMalloc(&d_dst.p, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
+    PlanGuard pg;
+    st = zh_plan_uncompress(ctx, n, soff.data(), slen.data(), doff.data(), dcap.data(), data_format, &pg.p);
+    if (st) return st;
+    plan_set_count_only(pg.p, pass == 0);
+    st = zh_plan_run(pg.p, d_src.p, d_dst.p);
+    if (st) return st;
+    std::vector<uint64_t> olen(n);
+    std::vector<int32_t> ost(n);
+    st = zh_plan_results(pg.p, olen.data(), ost.data());
+    if (st) return st;
+    if (pass == 0) {
+      for (size_t i = 0; i < n; i++)
+        if (need_count[i]) cap[i] = olen[i];
+      continue;
+    }
+    bool again = false;
+    for (size_t i = 0; i < n; i++) {
+      if (dsts[i] || (pass == 2 && statuses[i] != ZH_ERR_DST_TOO_SMALL)) continue;
+      statuses[i] = ost[i];
+      if (ost[i] == ZH_ERR_DST_TOO_SMALL && pass == 1) {
+        // more data than ISIZE promised: a >= 4 GiB member (ISIZE is mod 2^32) or a
+        // corrupt stream.  Give it the deflate expansion bound once.
+        cap[i] = (uint64_t)lens[i] * 1032 + 64;
+        again = true;
+        continue;
+      }
+      if (ost[i] != ZH_OK) continue;
+      dsts[i] = malloc(olen[i] ? olen[i] : 1);
+      if (!dsts[i]) {
+        statuses[i] = ZH_ERR_NOMEM;
+        continue;
+      }
+      dst_lens[i] = olen[i];
+      if (olen[i]) ZH_HIP(ctx, hipMemcpyAsync(dsts[i], d_dst.p + doff[i], olen[i], hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!again) break;
+    for (size_t i = 0; i < n; i++)
+      if (statuses[i] != ZH_ERR_DST_TOO_SMALL) cap[i] = 0;  // only the wrapped members run again
+  }
+  for (size_t i = 0; i < n; i++)
+    if (statuses[i] == ZH_ERR_DST_TOO_SMALL) statuses[i] = ZH_ERR_CHECKSUM;
+  return ZH_OK;
+}
+
+extern "C" int zh_compress(zh_ctx* ctx, const void* src, size_t len, int level, int data_format,
+                           void** dst, size_t* dst_len) {
+  int32_t st = ZH_OK;
+  const void* srcs[1] = {src};
+  size_t lens[1] = {len};
+  int rc = zh_compress_batch(ctx, srcs, lens, 1, level, data_format, dst, dst_len, &st);
+  return rc ? rc : st;
+}
+extern "C" int zh_uncompress(zh_ctx* ctx, const void* src, size_t len, int data_format, void** dst,
+                             size_t* dst_len) {
+  int32_t st = ZH_OK;
+  const void* srcs[1] = {src};
+  size_t lens[1] = {len};
+  int rc = zh_uncompress_batch(ctx, srcs, lens, 1, data_format, dst, dst_len, &st);
+  return rc ? rc : st;
+}
+
+static int checksum_host(zh_ctx* ctx, const void* src, size_t len, int want_crc, uint32_t* out) {
+  if (!ctx || !out || (len && !src)) return ZH_ERR_ARGUMENT;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+  const void* srcs[1] = {src};
+  size_t lens[1] = {len};
+  DevBuf d;
+  std::vector<uint64_t> off, l64;
+  int st = upload(ctx, srcs, lens, 1, d, off, l64);
+  if (st) return st;
+  std::vector<ZhPieceDesc> pieces;
+  for (uint64_t o = 0; o < len; o += ZH_FRAG_SIZE)
+    pieces.push_back(ZhPieceDesc{o, (uint32_t)std::min<uint64_t>(len - o, ZH_FRAG_SIZE), 0, o});
+  ZhBufDesc b;
+  memset(&b, 0, sizeof(b));
+  b.src_len = len;
+  b.npieces = (uint32_t)pieces.size();
+  const size_t np = pieces.size();
+  DevBuf scratch;
+  const size_t bytes = sizeof(ZhBufDesc) + 256 + np * sizeof(ZhPieceDesc) + 256 + np * 12 + 256 + 64;
+  if (hipMalloc(&scratch.p, bytes) != hipSuccess) return ZH_ERR_NOMEM;
+  ZhBufDesc* d_b = (ZhBufDesc*)scratch.p;
+  ZhPieceDesc* d_p = (ZhPieceDesc*)(scratch.p + 256);
+  uint32_t* d_pc = (uint32_t*)(scratch.p + 512 + ((np * sizeof(ZhPieceDesc) + 255) & ~(size_t)255));
+  uint32_t* d_pl = d_pc + np;
+  uint32_t* d_pa = d_pl + np;
+  uint32_t* d_out = d_pa + np;
+  hipStream_t s = ctx->stream;
+  ZH_HIP(ctx, hipMemcpyAsync(d_b, &b, sizeof(b), hipMemcpyHostToDevice, s));
+  if (np) ZH_HIP(ctx, hipMemcpyAsync(d_p, pieces.data(), np * sizeof(ZhPieceDesc), hipMemcpyHostToDevice, s));
+  zh_launch_checksum_pieces(s, ctx->cktabs, d.p, d_p, (uint32_t)np, nullptr, want_crc, !want_crc,
+                            d_pc, d_pa, d_pl);
+  zh_launch_checksum_combine(s, d_b, 1, d_pc, d_pa, d_pl, want_crc, !want_crc, d_out, d_out + 1);
+  uint32_t res[2] = {0, 0};
+  ZH_HIP(ctx, hipMemcpyAsync(res, d_out, 8, hipMemcpyDeviceToHost, s));
+  ZH_HIP(ctx, hipStreamSynchronize(s));
+  *out = want_crc ? res[0] : res[1];
+  return ZH_OK;
+}
+extern "C" int zh_crc32(zh_ctx* ctx, const void* src, size_t len, uint32_t* out) {
+  return checksum_host(ctx, src, len, 1, out);
+}
+extern "C" int zh_adler32(zh_ctx* ctx, const void* src, size_t len, uint32_t* out) {
+  return checksum_host(ctx, src, len, 0, out);
+}
+
+// ---------------------------------------------------------------------------
+// parity introspection: device parse -> reference token stream
+// ---------------------------------------------------------------------------
+extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int level,
+                               uint16_t** tokens, size_t* num_tokens) {
+  if (!ctx || !tokens || !num_tokens || (len && !src)) return ZH_ERR_ARGUMENT;
+  if (level < -2 || level > 9 || level == 0) return ZH_ERR_INVALID_LEVEL;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+  const void* srcs[1] = {src};
+  size_t lens[1] = {len};
+  DevBuf d_src;
+  std::vector<uint64_t> soff, slen;
+  int st = upload(ctx, srcs, lens, 1, d_src, soff, slen);
+  if (st) return st;
+  uint64_t doff = 0, dcap = 0;
+  PlanGuard pg;
+  st = zh_plan_compress(ctx, 1, soff.data(), slen.data(), &doff, &dcap, level, ZH_DF_DEFLATE, &pg.p);
+  if (st) return st;
+  zh_plan* p = pg.p;
+  hipStream_t s = ctx->stream;
+  const ZhCompressArgs& a = p->ca;
+  if (level == 1 || level == -2) {
+    zh_launch_l1_match(s, d_src.p, a, level == -2);
+  } else {
+    const int* cfg = kChainConfig[level == -1 ? 6 : level];
+    ZH_HIP(ctx, hipMemsetAsync(p->head_scratch, 0, p->head_bytes, s));
+    zh_launch_chain_match(s, d_src.p, a, cfg[0], cfg[1], cfg[2], p->head_scratch);
+  }
+  const size_t nf = a.nfrags;
+  std::vector<uint32_t> nmatch(nf);
+  std::vector<uint16_t> mpos(nf * ZH_MAX_MATCHES_PER_FRAG), mlen(mpos.size()), moff(mpos.size());
+  if (nf) {
+    ZH_HIP(ctx, hipMemcpyAsync(nmatch.data(), a.f_nmatch, nf * 4, hipMemcpyDeviceToHost, s));
+    ZH_HIP(ctx, hipMemcpyAsync(mpos.data(), a.m_pos, mpos.size() * 2, hipMemcpyDeviceToHost, s));
+    ZH_HIP(ctx, hipMemcpyAsync(mlen.data(), a.m_len, mpos.size() * 2, hipMemcpyDeviceToHost, s));
+    ZH_HIP(ctx, hipMemcpyAsync(moff.data(), a.m_off, mpos.size() * 2, hipMemcpyDeviceToHost, s));
+  }
+  ZH_HIP(ctx, hipStreamSynchronize(s));
+
+  std::vector<uint16_t> out;
+  auto add_literals = [&](uint64_t count) {  // snappy.nim:39-47
+    while (count > 0) {
+      const uint64_t added = std::min<uint64_t>(count, 32767);
+      out.push_back((uint16_t)added);
+      count -= added;
+    }
+  };
+  // Level 1 closes its literal run at every fragment end (emitRemainder,
+  // snappy.nim:66-68); the chain levels and -2 run literals across the block.
+  const bool per_fragment = level == 1;
+  size_t f = 0;
+  for (uint64_t bstart = 0; bstart < len || (len == 0 && bstart == 0); bstart += ZH_BLOCK_SIZE) {
+    const uint64_t blen = std::min<uint64_t>(len - bstart, ZH_BLOCK_SIZE);
+    uint64_t run = 0;  // pending literals
+    uint64_t covered_until = 0;  // block-relative end of the last match
+    for (uint64_t o = 0; o < blen; o += ZH_FRAG_SIZE, f++) {
+      const uint64_t flen = std::min<uint64_t>(blen - o, ZH_FRAG_SIZE);
+      uint64_t cursor = std::max<uint64_t>(o, covered_until);
+      for (uint32_t m = 0; m < nmatch[f]; m++) {
+        const size_t k = f * ZH_MAX_MATCHES_PER_FRAG + m;
+        const uint64_t mp = o + mpos[k];
+        run += mp - cursor;
+        add_literals(run);
+        run = 0;
+        const uint32_t l = mlen[k], off = moff[k];
+        uint32_t li = 0;
+        {
+          static const uint16_t base[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
+                                            31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+          for (int i = 0; i < 29; i++)
+            if (base[i] <= l) li = i;
+          if (l == 258) li = 28;
+        }
+        const uint32_t di = zh_dist_code(off);
+        out.push_back((uint16_t)(0x8000u | (li << 8) | di));
+        out.push_back((uint16_t)off);
+        out.push_back((uint16_t)l);
+        cursor = mp + l;
+        covered_until = cursor;
+      }
+      const uint64_t fend = o + flen;
+      if (cursor < fend) run += fend - cursor;
+      if (per_fragment) {
+        add_literals(run);
+        run = 0;
+      }
+    }
+    add_literals(run);
+    if (len == 0) break;
+  }
+  *num_tokens = out.size();
+  *tokens = (uint16_t*)malloc(out.size() * 2 + 2);
+  if (!*tokens) return ZH_ERR_NOMEM;
+  memcpy(*tokens, out.data(), out.size() * 2);
+  return ZH_OK;
+}

@@ -1,0 +1,246 @@
+// CRC-32 / Adler-32 of byte ranges in HBM ("pieces" of <= 32 KiB) plus the
+// GF(2) / modular combination into whole-buffer checksums.
+//
+// Replaces crc.nim:29-72 (slice-by-8 / PCLMUL folding; gfx950 has no carry-less
+// multiply) and adler32.nim:19-63.  One 64-lane wave per piece:
+//   * lane k owns the 16-byte column k of every 1 KiB row, so a row is one fully
+//     coalesced 1 KiB global load (global_load_dwordx4 per lane);
+//   * per row a lane does slice-by-4 over its 16 bytes (4 LDS table lookups per
+//     dword) and then "skips" the other lanes' 1008 bytes with one 4-lookup
+//     multiplication by x^(8*1008) mod P (tables Z0..Z3);
+//   * lanes are aligned to the end of the piece by one multiplication with
+//     x^(8*d) (d from a small table) and XOR-reduced across the wave.
+// Algorithmic traffic: each input byte is read once.
+#include "zh_common.h"
+#include "zh_tables.h"
+
+namespace {
+
+constexpr uint32_t kPoly = 0xedb88320u;
+
+// a(x) * b(x) mod P in the reflected representation (x^0 == bit 31), the role of
+// zlib's multmodp; 32 shift/xor steps.
+__host__ __device__ inline uint32_t gf2_mul(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+  for (int i = 0; i < 32; i++) {
+    p ^= (a & 0x80000000u) ? b : 0u;
+    a <<= 1;
+    b = (b & 1u) ? (b >> 1) ^ kPoly : (b >> 1);
+  }
+  return p;
+}
+
+// x^(8*n) mod P
+__host__ __device__ inline uint32_t gf2_xpow8(uint64_t n) {
+  uint32_t result = 0x80000000u;   // x^0
+  uint32_t sq = 0x00800000u;       // x^8
+  while (n) {
+    if (n & 1) result = gf2_mul(sq, result);
+    sq = gf2_mul(sq, sq);
+    n >>= 1;
+  }
+  return result;
+}
+
+struct ChecksumTables {
+  uint32_t t[4][256];   // slice-by-4 byte tables
+  uint32_t z[4][256];   // multiply a state by x^(8*1008): Zj[b] = (b << 8j) * x^(8*1008)
+  uint32_t xz[2048];    // x^(8*j) mod P for j < 2048
+};
+
+}  // namespace
+
+
+__global__ __launch_bounds__(64) void zh_checksum_pieces_kernel(
+    const uint8_t* __restrict__ d_data, const ZhPieceDesc* __restrict__ pieces, uint32_t npieces,
+    const uint64_t* __restrict__ dyn_len, const ChecksumTables* __restrict__ tabs, int want_crc,
+    int want_adler, uint32_t* __restrict__ out_crc, uint32_t* __restrict__ out_adler,
+    uint32_t* __restrict__ out_len) {
+  __shared__ uint32_t s_t[4][256];
+  __shared__ uint32_t s_z[4][256];
+  const unsigned lane = zh_lane();
+  if (want_crc) {
+    for (unsigned i = lane; i < 1024; i += 64) {
+      (&s_t[0][0])[i] = (&tabs->t[0][0])[i];
+      (&s_z[0][0])[i] = (&tabs->z[0][0])[i];
+    }
+  }
+  zh_wave_sync();
+
+  for (uint32_t p = blockIdx.x; p < npieces; p += gridDim.x) {
+    const ZhPieceDesc pd = pieces[p];
+    uint32_t len = pd.len;
+    if (dyn_len) {
+      uint64_t total = dyn_len[pd.buf];
+      len = total > pd.rel_off ? (uint32_t)(total - pd.rel_off < 32768u ? total - pd.rel_off : 32768u) : 0u;
+    }
+    const uint8_t* base = d_data + pd.off;
+    // head: bytes before the first 16-byte boundary (handled by lane 0)
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)base & 15u)) & 15u);
+    if (head > len) head = len;
+    const uint32_t body = len - head;
+    const uint32_t rows = body >> 10;
+    const uint32_t tail = body & 1023u;
+    const uint8_t* bp = base + head;
+
+    uint32_t crc_rows = 0, crc_tail = 0, crc_head = 0;
+    uint64_t sum_b = 0, sum_ib = 0;  // adler: sum of bytes, sum of index*byte
+
+    if (lane == 0) {
+      for (uint32_t i = 0; i < head; i++) {
+        uint32_t b = base[i];
+        if (want_crc) crc_head = s_t[0][(crc_head ^ b) & 255u] ^ (crc_head >> 8);
+        sum_b += b;
+        sum_ib += (uint64_t)i * b;
+      }
+    }
+    for (uint32_t r = 0; r < rows; r++) {
+      const uint4 v = *reinterpret_cast<const uint4*>(bp + ((size_t)r << 10) + lane * 16u);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      if (want_crc) {
+        if (r) {  // skip the other 63 lanes' bytes of the previous row boundary
+          crc_rows = s_z[0][crc_rows & 255u] ^ s_z[1][(crc_rows >> 8) & 255u] ^
+                     s_z[2][(crc_rows >> 16) & 255u] ^ s_z[3][crc_rows >> 24];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          uint32_t c = crc_rows ^ w[k];
+          crc_rows = s_t[3][c & 255u] ^ s_t[2][(c >> 8) & 255u] ^ s_t[1][(c >> 16) & 255u] ^
+                     s_t[0][c >> 24];
+        }
+      }
+      if (want_adler) {
+        const uint32_t i0 = head + (r << 10) + lane * 16u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            uint32_t b = (w[k] >> (8 * j)) & 255u;
+            sum_b += b;
+            sum_ib += (uint64_t)(i0 + 4 * k + j) * b;
+          }
+        }
+      }
+    }
+    // tail: lane k takes bytes [16k, 16k+16) of the last partial row
+    uint32_t t_begin = lane * 16u, t_end = t_begin + 16u;
+    if (t_begin > tail) t_begin = tail;
+    if (t_end > tail) t_end = tail;
+    for (uint32_t i = t_begin; i < t_end; i++) {
+      uint32_t b = bp[((size_t)rows << 10) + i];
+      if (want_crc) crc_tail = s_t[0][(crc_tail ^ b) & 255u] ^ (crc_tail >> 8);
+      sum_b += b;
+      sum_ib += (uint64_t)(head + (rows << 10) + i) * b;
+    }
+
+    if (want_crc) {
+      // align every partial state to the end of the piece and fold
+      uint32_t acc = 0;
+      if (rows) acc ^= gf2_mul(tabs->xz[16u * (63u - lane) + tail], crc_rows);
+      if (t_end > t_begin) acc ^= gf2_mul(tabs->xz[tail - t_end], crc_tail);
+      acc = zh_wave_xor(acc);
+      if (lane == 0) {
+        if (head) acc ^= gf2_mul(gf2_xpow8(len - head), crc_head);
+        // standard conditioning: init 0xffffffff travels through len bytes, final NOT
+        uint32_t crc = ~(acc ^ gf2_mul(gf2_xpow8(len), 0xffffffffu));
+        out_crc[p] = crc;
+      }
+    }
+    if (want_adler) {
+      sum_b = zh_wave_sum64(sum_b);
+      sum_ib = zh_wave_sum64(sum_ib);
+      if (lane == 0) {
+        // s1 = 1 + sum b ; s2 = len + sum (len - i) * b   (adler32.nim:28-31 unrolled)
+        uint64_t s1 = (1 + sum_b) % 65521u;
+        uint64_t s2 = ((uint64_t)len + (uint64_t)len * sum_b - sum_ib) % 65521u;
+        out_adler[p] = (uint32_t)((s2 << 16) | s1);
+      }
+    }
+    if (lane == 0) out_len[p] = len;
+  }
+}
+
+// Combine per-piece checksums of each buffer in order:
+//   crc(A||B)   = crc(A) * x^(8 len B) xor crc(B)                (zlib crc32_combine)
+//   adler(A||B) : s1 = s1A + s1B - 1 ; s2 = s2A + s2B + lenB * (s1A - 1)   (mod 65521)
+__global__ void zh_checksum_combine_kernel(const ZhBufDesc* __restrict__ bufs, uint32_t nbufs,
+                                           const uint32_t* __restrict__ piece_crc,
+                                           const uint32_t* __restrict__ piece_adler,
+                                           const uint32_t* __restrict__ piece_len, int want_crc,
+                                           int want_adler, uint32_t* __restrict__ buf_crc,
+                                           uint32_t* __restrict__ buf_adler) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nbufs) return;
+  const ZhBufDesc b = bufs[i];
+  uint32_t crc = 0;
+  uint64_t s1 = 1, s2 = 0;
+  const uint32_t x_full = gf2_xpow8(32768);
+  for (uint32_t k = 0; k < b.npieces; k++) {
+    uint32_t p = b.first_piece + k;
+    uint32_t len = piece_len[p];
+    if (len == 0) continue;
+    if (want_crc) {
+      uint32_t x = len == 32768u ? x_full : gf2_xpow8(len);
+      crc = gf2_mul(x, crc) ^ piece_crc[p];
+    }
+    if (want_adler) {
+      uint32_t a = piece_adler[p];
+      uint64_t s1b = a & 0xffffu, s2b = a >> 16;
+      s2 = (s2 + s2b + (uint64_t)(len % 65521u) * ((s1 + 65520u) % 65521u)) % 65521u;
+      s1 = (s1 + s1b + 65520u) % 65521u;
+    }
+  }
+  if (want_crc) buf_crc[i] = crc;
+  if (want_adler) buf_adler[i] = (uint32_t)((s2 << 16) | s1);
+}
+
+// ---- host side ------------------------------------------------------------
+static ChecksumTables* g_tabs_dev[64] = {nullptr};
+
+extern "C" const void* zh_checksum_tables(int device) {
+  if (device < 0 || device >= 64) device = 0;
+  if (g_tabs_dev[device]) return g_tabs_dev[device];
+  ChecksumTables* h = new ChecksumTables;
+  constexpr zh::CrcTables ct = zh::make_crc_tables();
+  for (int k = 0; k < 4; k++)
+    for (int i = 0; i < 256; i++) h->t[k][i] = ct.t[k][i];
+  const uint32_t x1008 = gf2_xpow8(1008);
+  for (int j = 0; j < 4; j++)
+    for (uint32_t b = 0; b < 256; b++) h->z[j][b] = gf2_mul(x1008, b << (8 * j));
+  uint32_t x = 0x80000000u;
+  const uint32_t x8 = 0x00800000u;
+  for (int j = 0; j < 2048; j++) {
+    h->xz[j] = x;
+    x = gf2_mul(x8, x);
+  }
+  ChecksumTables* d = nullptr;
+  if (hipMalloc(&d, sizeof(ChecksumTables)) != hipSuccess) {
+    delete h;
+    return nullptr;
+  }
+  hipMemcpy(d, h, sizeof(ChecksumTables), hipMemcpyHostToDevice);
+  delete h;
+  g_tabs_dev[device] = d;
+  return d;
+}
+
+extern "C" void zh_launch_checksum_pieces(hipStream_t stream, const void* tabs, const uint8_t* d_data,
+                                          const ZhPieceDesc* pieces, uint32_t npieces,
+                                          const uint64_t* dyn_len, int want_crc, int want_adler,
+                                          uint32_t* out_crc, uint32_t* out_adler, uint32_t* out_len) {
+  if (!npieces) return;
+  uint32_t grid = npieces < 8192u ? npieces : 8192u;
+  hipLaunchKernelGGL(zh_checksum_pieces_kernel, dim3(grid), dim3(64), 0, stream, d_data, pieces,
+                     npieces, dyn_len, (const ChecksumTables*)tabs, want_crc, want_adler, out_crc,
+                     out_adler, out_len);
+}
+
+extern "C" void zh_launch_checksum_combine(hipStream_t stream, const ZhBufDesc* bufs, uint32_t nbufs,
+                                           const uint32_t* piece_crc, const uint32_t* piece_adler,
+                                           const uint32_t* piece_len, int want_crc, int want_adler,
+                                           uint32_t* buf_crc, uint32_t* buf_adler) {
+  if (!nbufs) return;
+  hipLaunchKernelGGL(zh_checksum_combine_kernel, dim3((nbufs + 63) / 64), dim3(64), 0, stream, bufs,
+                     nbufs, piece_crc, piece_adler, piece_len, want_crc, want_adler, buf_crc,
+                     buf_adler);
+}

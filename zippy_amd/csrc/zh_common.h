@@ -1,0 +1,169 @@
+// Shared definitions of the MI355X DEFLATE engine (device + host side).
+//
+// Vocabulary (follows the reference):
+//   buffer    one independent input of the batch (one compress()/uncompress() call)
+//   block     <= 4 MiB of a buffer = one deflate block with one Huffman table
+//             (deflate.nim:228-237, internal.nim:16)
+//   fragment  <= 32 KiB of a block.  At BestSpeed fragments are LZ-independent
+//             (snappy.nim:150-163), so a fragment is the unit of device
+//             parallelism: one 64-lane wave parses / emits one fragment.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/zippy_hip.h"
+
+#define ZH_WAVE 64
+#define ZH_FRAG_SIZE 32768u          // internal.nim:14 maxWindowSize
+#define ZH_BLOCK_SIZE 4194304u       // internal.nim:16 maxBlockSize
+#define ZH_STORED_MAX 65535u         // internal.nim:15 maxUncompressedBlockSize
+#define ZH_MAX_MATCHES_PER_FRAG 8192 // a >=4-byte match every 4 bytes
+#define ZH_HIST_STRIDE 320           // 286 litlen + 30 distance counters, padded
+#define ZH_HDR_WORDS 256             // dynamic block header bit string, <= 1 KiB
+#define ZH_NUM_LITLEN 286
+#define ZH_NUM_DIST 30
+
+enum { ZH_MODE_STORED = 0, ZH_MODE_FIXED = 1, ZH_MODE_DYNAMIC = 2 };
+
+struct ZhFragDesc {
+  uint64_t src_off;  // absolute byte offset of the fragment in d_src
+  uint32_t len;      // 1..32768
+  uint32_t block;    // owning block
+};
+
+struct ZhBlockDesc {
+  uint64_t src_off;  // absolute byte offset of the block in d_src
+  uint64_t len;      // <= 4 MiB (whole buffer at level 0)
+  uint32_t buf;
+  uint32_t first_frag;
+  uint32_t nfrag;
+  uint32_t is_final;
+};
+
+struct ZhBufDesc {
+  uint64_t src_off, src_len;
+  uint64_t dst_off, dst_cap;
+  uint32_t first_block, nblocks;
+  uint32_t first_piece, npieces;  // checksum pieces (== fragments on the compress side)
+  uint32_t fname_len;             // gzip FNAME letters (zippy.nim:26-42)
+  uint32_t pad;
+};
+
+// Device pointers of one compress plan (SoA scratch in HBM).
+struct ZhCompressArgs {
+  const ZhFragDesc* frags;
+  const ZhBlockDesc* blocks;
+  const ZhBufDesc* bufs;
+  uint32_t nfrags, nblocks, nbufs;
+  int32_t level, data_format;
+  // per fragment, written by the matcher
+  uint16_t* m_pos;   // [nfrags][8192] match start, relative to the fragment
+  uint16_t* m_len;   // [nfrags][8192] 4..258 (5..258 for the chain levels)
+  uint16_t* m_off;   // [nfrags][8192] 1..32767
+  uint32_t* f_nmatch;
+  uint32_t* f_spill;  // leading bytes covered by a match begun in the previous fragment
+  uint32_t* f_nlit;
+  uint32_t* f_extra_bits;  // sum of length+distance extra bits of the fragment's matches
+  uint16_t* f_hist;        // [nfrags][320]
+  uint32_t* f_crc;         // CRC-32 (gzip) or adler s1 | s2<<16 pieces, see zh_checksum
+  uint32_t* f_adler;
+  // per fragment, written by the Huffman / layout kernels
+  uint32_t* f_bits;        // encoded bit length under the block's codes
+  uint64_t* f_bit_start;   // absolute bit position in d_dst
+  // per block
+  uint32_t* b_mode;
+  uint32_t* b_litcode;     // [nblocks][288]  code | len << 16
+  uint32_t* b_distcode;    // [nblocks][32]
+  uint32_t* b_hdr;         // [nblocks][ZH_HDR_WORDS] header bit string (LSB first)
+  uint32_t* b_hdr_bits;
+  uint64_t* b_bits;        // total bits of the block (header + payload + EOB), compressed modes
+  uint64_t* b_stored_d0;   // stored mode: absolute byte of block byte 0 in d_dst
+  // per buffer
+  uint64_t* out_len;
+  int32_t* status;
+};
+
+// Checksum piece: d_data[off .. off+len), len <= 32768.  With a device-side length
+// array (inflate output) len = clamp(dyn_len[buf] - rel_off, 0, 32768).
+struct ZhPieceDesc {
+  uint64_t off;      // absolute byte offset in d_data
+  uint32_t len;      // static length (ignored when dyn_len is used)
+  uint32_t buf;
+  uint64_t rel_off;  // offset of the piece inside its buffer
+};
+
+struct ZhInflateArgs {
+  const ZhBufDesc* bufs;         // src_off/src_len = compressed stream, dst_off/dst_cap = slot
+  const uint64_t* src_len_dev;   // optional device override of src_len (compress -> uncompress)
+  uint32_t nbufs;
+  int32_t data_format;
+  int32_t count_only;            // sizing pass for zlib/raw streams: decode without writing
+  // unwrap results (per stream)
+  uint32_t* body_pos;
+  uint32_t* fmt;                 // resolved format
+  uint32_t* expect_sum;          // CRC-32 (gzip) / Adler-32 (zlib) from the trailer
+  uint32_t* expect_isize;
+  uint64_t* out_len;
+  int32_t* status;
+};
+
+// ---- wave helpers (single-wave workgroups; lockstep execution on gfx950) ----
+__device__ __forceinline__ unsigned zh_lane() { return threadIdx.x & 63u; }
+
+// Orders LDS/global traffic between lanes of one wave: nothing is emitted on the
+// GPU (a wave executes in lockstep and LDS is in-order per wave); it only pins
+// the compiler.  The CPU emulator used by the tests turns it into a rendezvous.
+__device__ __forceinline__ void zh_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t zh_bcast(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t zh_bcast64(uint64_t v) {
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint32_t zh_wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ uint64_t zh_wave_sum64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t zh_wave_xor(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
+  return v;
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t zh_wave_scan(uint32_t v) {
+  const unsigned lane = zh_lane();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(v, o, 64);
+    if (lane >= (unsigned)o) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t zh_lanemask_lt() { return (1ull << zh_lane()) - 1ull; }
+
+// unaligned little-endian loads from a dword-typed LDS/global array
+__device__ __forceinline__ uint32_t zh_ld32(const uint32_t* w, uint32_t byte_pos) {
+  uint32_t i = byte_pos >> 2;
+  return __builtin_amdgcn_alignbyte(w[i + 1], w[i], byte_pos & 3u);
+}
+__device__ __forceinline__ uint64_t zh_ld64(const uint32_t* w, uint32_t byte_pos) {
+  uint32_t i = byte_pos >> 2, s = byte_pos & 3u;
+  uint32_t a = w[i], b = w[i + 1], c = w[i + 2];
+  return (uint64_t)__builtin_amdgcn_alignbyte(b, a, s) |
+         ((uint64_t)__builtin_amdgcn_alignbyte(c, b, s) << 32);
+}
+__device__ __forceinline__ uint32_t zh_ld8(const uint32_t* w, uint32_t byte_pos) {
+  return (w[byte_pos >> 2] >> ((byte_pos & 3u) * 8u)) & 0xffu;
+}

@@ -1,0 +1,541 @@
+// Per-block Huffman construction and per-buffer output layout.
+//
+// zh_huffman_kernel (one wave per deflate block) replaces deflate.nim:274-394:
+//   * sums the fragment histograms into the block's BlockMetadata
+//     (internal.nim:128-131), applies the "almost all literals -> stored" test
+//     (deflate.nim:274-277, float32 multiply + truncation) and the fixed-code rule
+//     (deflate.nim:279-294);
+//   * builds the three length-limited Huffman codes exactly like
+//     deflate.nim:13-151 `huffmanCodes`: binary-heap Huffman with the reference's
+//     tie-breaking (Nim std/heapqueue == CPython heapq sift rules, compared on
+//     frequency only), the histogram rebalancing loop, the unstable quicksort and
+//     shortest-first reassignment when a code exceeds the limit, canonical
+//     bit-reversed codes.  This part is inherently serial (<= 286 symbols) and
+//     runs on lane 0 out of LDS; thousands of blocks run concurrently instead;
+//   * run-length encodes the code lengths and assembles the dynamic block
+//     header bit string (deflate.nim:296-394);
+//   * computes every fragment's encoded bit length as a dot product of its
+//     histogram with the code lengths (all 64 lanes).
+//
+// zh_layout_kernel (one wave per buffer) turns bit lengths into absolute bit
+// positions (the job of BitStreamWriter.pos/bitPos, bitstreams.nim:84-123),
+// and writes everything that is not fragment payload: container header
+// (zippy.nim:22-42,61-69), block headers, end-of-block codes, stored-block
+// headers (deflate.nim:179-205), final padding and the trailer
+// (zippy.nim:47-58,71-78).  All of it is OR-ed into a zeroed output.
+#include "zh_common.h"
+#include "zh_tables.h"
+
+namespace {
+
+__constant__ uint8_t c_clcl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+constexpr int kMaxSyms = 288;
+
+struct HuffWork {
+  uint32_t nfreq[2 * kMaxSyms];   // node frequency (leaves then internal nodes)
+  uint16_t left[2 * kMaxSyms];
+  uint16_t right[2 * kMaxSyms];
+  uint16_t depth[2 * kMaxSyms];
+  int16_t symbol[kMaxSyms];        // leaf -> symbol
+  uint16_t heap[kMaxSyms];
+  uint16_t order[kMaxSyms];        // leaves, sorted by depth when limiting
+  uint16_t stack[2 * kMaxSyms + 4];
+  int32_t histogram[2 * kMaxSyms];
+};
+
+__device__ inline uint32_t rev16(uint32_t v) { return __brev(v) >> 16; }
+
+// ---- Nim std/heapqueue (CPython heapq) on node indices, `<` on frequency ----
+__device__ inline void heap_sift_to_root(HuffWork& w, int startpos, int pos) {
+  const uint16_t newitem = w.heap[pos];
+  const uint32_t f = w.nfreq[newitem];
+  while (pos > startpos) {
+    const int parentpos = (pos - 1) >> 1;
+    const uint16_t parent = w.heap[parentpos];
+    if (f < w.nfreq[parent]) {
+      w.heap[pos] = parent;
+      pos = parentpos;
+    } else {
+      break;
+    }
+  }
+  w.heap[pos] = newitem;
+}
+__device__ inline void heap_sink_to_bottom(HuffWork& w, int len, int pos) {
+  const int startpos = pos;
+  const uint16_t newitem = w.heap[pos];
+  int childpos = 2 * pos + 1;
+  while (childpos < len) {
+    const int rightpos = childpos + 1;
+    if (rightpos < len && !(w.nfreq[w.heap[childpos]] < w.nfreq[w.heap[rightpos]])) childpos = rightpos;
+    w.heap[pos] = w.heap[childpos];
+    pos = childpos;
+    childpos = 2 * pos + 1;
+  }
+  w.heap[pos] = newitem;
+  heap_sift_to_root(w, startpos, pos);
+}
+__device__ inline int heap_pop(HuffWork& w, int& len) {
+  const uint16_t last = w.heap[--len];
+  if (len > 0) {
+    const uint16_t result = w.heap[0];
+    w.heap[0] = last;
+    heap_sink_to_bottom(w, len, 0);
+    return result;
+  }
+  return last;
+}
+
+// deflate.nim:13-151.  Serial; call from one lane.  Returns the number of codes.
+__device__ int huffman_codes(const uint32_t* freq, int num_freq, int min_codes, int limit,
+                             uint16_t* codes, uint8_t* lens, HuffWork& w) {
+  int highest = 0, used = 0;
+  for (int s = 0; s < num_freq; s++)
+    if (freq[s] > 0) {
+      highest = s;
+      used++;
+    }
+  const int num_codes = (highest > min_codes ? highest : min_codes) + 1;
+  for (int i = 0; i < num_codes; i++) {
+    codes[i] = 0;
+    lens[i] = 0;
+  }
+  if (used == 0) {  // :34-36
+    lens[0] = 1;
+    lens[1] = 1;
+  } else if (used == 1) {  // :37-45
+    for (int i = 0; i < num_freq; i++)
+      if (freq[i] != 0) {
+        lens[i] = 1;
+        lens[i == 0 ? 1 : 0] = 1;
+        break;
+      }
+  } else {
+    int n = 0;
+    for (int s = 0; s < num_freq; s++)
+      if (freq[s] > 0) {
+        w.nfreq[n] = freq[s];
+        w.symbol[n] = (int16_t)s;
+        w.order[n] = (uint16_t)n;
+        n++;
+      }
+    int hlen = 0;
+    for (int i = 0; i < n; i++) {  // :54-55 push all leaves
+      w.heap[hlen++] = (uint16_t)i;
+      heap_sift_to_root(w, 0, hlen - 1);
+    }
+    int total = n;
+    while (hlen >= 2) {  // :57-63
+      const int l = heap_pop(w, hlen);
+      const int r = heap_pop(w, hlen);
+      w.left[total] = (uint16_t)l;
+      w.right[total] = (uint16_t)r;
+      w.nfreq[total] = w.nfreq[l] + w.nfreq[r];
+      w.heap[hlen++] = (uint16_t)total;
+      heap_sift_to_root(w, 0, hlen - 1);
+      total++;
+    }
+    // :65-75 leaf depths.  Children always have smaller indices than their parent,
+    // so one descending sweep over the internal nodes replaces the recursion.
+    w.depth[total - 1] = 0;
+    for (int i = total - 1; i >= n; i--) {
+      const uint16_t d = (uint16_t)(w.depth[i] + 1);
+      w.depth[w.left[i]] = d;
+      w.depth[w.right[i]] = d;
+    }
+    int longest = 0;
+    for (int i = 0; i < n; i++)
+      if (w.depth[i] > longest) longest = w.depth[i];
+    if (longest > limit) {  // :78-131
+      for (int i = 0; i <= longest; i++) w.histogram[i] = 0;
+      for (int i = 0; i < n; i++) w.histogram[w.depth[i]]++;
+      int i = longest;
+      while (i > limit) {
+        if (w.histogram[i] == 0) {
+          i--;
+          continue;
+        }
+        int j = i - 2;
+        while (j > 0 && w.histogram[j] == 0) j--;
+        w.histogram[i] -= 2;
+        w.histogram[i - 1]++;
+        w.histogram[j + 1] += 2;
+        w.histogram[j]--;
+      }
+      // :103-123 quickSort(nodes by depth), explicit stack instead of recursion
+      int sp = 0;
+      w.stack[sp++] = 0;
+      w.stack[sp++] = (uint16_t)(n - 1);
+      while (sp > 0) {
+        const int inr = (int16_t)w.stack[--sp];
+        const int inl = (int16_t)w.stack[--sp];
+        int r = inr, l = inl;
+        const int cnt = r - l + 1;
+        if (cnt < 2) continue;
+        const uint16_t p = w.depth[w.order[l + 3 * cnt / 4]];
+        while (l <= r) {
+          if (w.depth[w.order[l]] < p) {
+            l++;
+          } else if (w.depth[w.order[r]] > p) {
+            r--;
+          } else {
+            const uint16_t t = w.order[l];
+            w.order[l] = w.order[r];
+            w.order[r] = t;
+            l++;
+            r--;
+          }
+        }
+        w.stack[sp++] = (uint16_t)inl;
+        w.stack[sp++] = (uint16_t)(int16_t)r;
+        w.stack[sp++] = (uint16_t)l;
+        w.stack[sp++] = (uint16_t)inr;
+      }
+      int code_len = 1;
+      for (int k = 0; k < n; k++) {  // :125-131
+        while (w.histogram[code_len] == 0) code_len++;
+        w.depth[w.order[k]] = (uint16_t)code_len;
+        w.histogram[code_len]--;
+      }
+    }
+    for (int i = 0; i < n; i++) lens[w.symbol[i]] = (uint8_t)w.depth[i];
+  }
+  // :136-149 canonical codes, bit-reversed (wide counters)
+  uint32_t hist[16], next_code[16];
+  for (int i = 0; i < 16; i++) hist[i] = 0;
+  for (int i = 0; i < num_codes; i++) hist[lens[i]]++;
+  hist[0] = 0;
+  next_code[0] = 0;
+  for (int i = 1; i < 16; i++) next_code[i] = (next_code[i - 1] + hist[i - 1]) << 1;
+  for (int i = 0; i < num_codes; i++)
+    if (lens[i]) {
+      codes[i] = (uint16_t)(rev16(next_code[lens[i]] & 0xffffu) >> (16 - lens[i]));
+      next_code[lens[i]]++;
+    }
+  return num_codes;
+}
+
+struct HdrWriter {
+  uint32_t* words;
+  uint32_t bits;
+};
+__device__ inline void hdr_add(HdrWriter& h, uint32_t value, uint32_t n) {
+  if (!n) return;
+  const uint32_t w = h.bits >> 5, s = h.bits & 31u;
+  h.words[w] |= value << s;
+  if (s + n > 32) h.words[w + 1] |= value >> (32 - s);
+  h.bits += n;
+}
+
+// OR `nbits` (<= 32) of value at absolute bit position `bit` of the byte stream at base.
+__device__ inline void or_bits(uint8_t* base, uint64_t bit, uint32_t value, uint32_t nbits) {
+  if (!nbits) return;
+  if (nbits < 32) value &= (1u << nbits) - 1u;
+  const uintptr_t addr = (uintptr_t)base + (bit >> 3);
+  uint32_t* wp = reinterpret_cast<uint32_t*>(addr & ~(uintptr_t)3);
+  const uint32_t s = (uint32_t)((addr & 3u) * 8u + (bit & 7u));  // 0..31
+  atomicOr(wp, value << s);
+  if (s + nbits > 32) atomicOr(wp + 1, value >> (32 - s));
+}
+__device__ inline void or_byte(uint8_t* base, uint64_t byte_pos, uint32_t v) {
+  or_bits(base, byte_pos * 8, v & 0xffu, 8);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
+  __shared__ uint32_t s_freq[ZH_HIST_STRIDE];
+  __shared__ HuffWork s_work;
+  __shared__ uint16_t s_codes[ZH_HIST_STRIDE];  // litlen at 0, distance at 288
+  __shared__ uint8_t s_lens[ZH_HIST_STRIDE];
+  __shared__ uint8_t s_cl_all[ZH_HIST_STRIDE];
+  __shared__ uint8_t s_rle[704];
+  __shared__ uint32_t s_hdr[ZH_HDR_WORDS];
+  __shared__ uint32_t s_mode, s_nlitlen, s_ndist, s_hdr_bits;
+
+  const unsigned lane = zh_lane();
+  const uint32_t b = blockIdx.x;
+  const ZhBlockDesc bd = a.blocks[b];
+  const int level = a.level;
+
+  // ---- block histogram = sum of the fragment histograms (BlockMetadata) ----
+  uint32_t nlit = 0;
+  for (uint32_t i = lane; i < ZH_HIST_STRIDE; i += 64) {
+    uint32_t acc = 0;
+    for (uint32_t k = 0; k < bd.nfrag; k++) acc += a.f_hist[(size_t)(bd.first_frag + k) * ZH_HIST_STRIDE + i];
+    if (i == 256) acc = 1;  // always one end-of-block symbol (snappy.nim:145, lz77.nim:52)
+    s_freq[i] = acc;
+  }
+  for (uint32_t k = lane; k < bd.nfrag; k += 64) nlit += a.f_nlit[bd.first_frag + k];
+  nlit = zh_wave_sum(nlit);
+  for (uint32_t i = lane; i < ZH_HDR_WORDS; i += 64) s_hdr[i] = 0;
+  for (uint32_t i = lane; i < ZH_HIST_STRIDE; i += 64) {
+    s_codes[i] = 0;
+    s_lens[i] = 0;
+  }
+  zh_wave_sync();
+
+  if (lane == 0) {
+    uint32_t mode;
+    if (level == 0 ||
+        (level != -2 && (int64_t)nlit >= (int64_t)((float)bd.len * 0.98f))) {  // deflate.nim:274-277
+      mode = ZH_MODE_STORED;
+    } else if (level <= 6 && bd.len <= 2048) {  // deflate.nim:280
+      mode = ZH_MODE_FIXED;
+    } else {
+      mode = ZH_MODE_DYNAMIC;
+    }
+    s_mode = mode;
+    HdrWriter h{s_hdr, 0};
+    if (mode == ZH_MODE_FIXED) {  // internal.nim:151-175
+      for (int i = 0; i < 288; i++) s_lens[i] = (uint8_t)(i <= 143 ? 8 : i <= 255 ? 9 : i <= 279 ? 7 : 8);
+      for (int i = 0; i < 30; i++) s_lens[288 + i] = 5;
+      uint32_t next8 = 0x30, next9 = 0x190, next7 = 0;  // canonical first codes of lengths 8, 9, 7
+      for (int i = 0; i < 288; i++) {
+        const uint32_t l = s_lens[i];
+        uint32_t c = l == 8 ? next8++ : l == 9 ? next9++ : next7++;
+        s_codes[i] = (uint16_t)(rev16(c) >> (16 - l));
+      }
+      for (int i = 0; i < 30; i++) s_codes[288 + i] = (uint16_t)(rev16((uint32_t)i) >> 11);
+      s_nlitlen = 288;
+      s_ndist = 30;
+      hdr_add(h, bd.is_final ? 1 : 0, 1);  // deflate.nim:296-298
+      hdr_add(h, 1, 2);
+    } else if (mode == ZH_MODE_DYNAMIC) {
+      const int n_litlen = huffman_codes(s_freq, ZH_NUM_LITLEN, 257, 15, s_codes, s_lens, s_work);
+      const int n_dist = huffman_codes(s_freq + ZH_NUM_LITLEN, ZH_NUM_DIST, 2, 15, s_codes + 288,
+                                       s_lens + 288, s_work);
+      s_nlitlen = (uint32_t)n_litlen;
+      s_ndist = (uint32_t)n_dist;
+      const int num_codes = n_litlen + n_dist;
+      for (int i = 0; i < n_litlen; i++) s_cl_all[i] = s_lens[i];
+      for (int i = 0; i < n_dist; i++) s_cl_all[n_litlen + i] = s_lens[288 + i];
+      // deflate.nim:313-350 run-length encoding of the code lengths
+      int rle_len = 0;
+      {
+        int i = 0;
+        while (i < num_codes) {
+          int repeat = 0;
+          while (i + repeat + 1 < num_codes && s_cl_all[i + repeat + 1] == s_cl_all[i]) repeat++;
+          if (s_cl_all[i] == 0 && repeat >= 2) {
+            repeat++;
+            if (repeat <= 10) {
+              s_rle[rle_len++] = 17;
+              s_rle[rle_len++] = (uint8_t)(repeat - 3);
+            } else {
+              if (repeat > 138) repeat = 138;
+              s_rle[rle_len++] = 18;
+              s_rle[rle_len++] = (uint8_t)(repeat - 11);
+            }
+            i += repeat - 1;
+          } else if (repeat >= 3) {
+            const int q = repeat / 6, r = repeat % 6;
+            s_rle[rle_len++] = s_cl_all[i];
+            for (int j = 0; j < q; j++) {
+              s_rle[rle_len++] = 16;
+              s_rle[rle_len++] = 3;
+            }
+            if (r >= 3) {
+              s_rle[rle_len++] = 16;
+              s_rle[rle_len++] = (uint8_t)(r - 3);
+            } else {
+              repeat -= r;
+            }
+            i += repeat;
+          } else {
+            s_rle[rle_len++] = s_cl_all[i];
+          }
+          i++;
+        }
+      }
+      uint32_t cl_freq[19];
+      for (int i = 0; i < 19; i++) cl_freq[i] = 0;
+      for (int i = 0; i < rle_len; i++) {  // deflate.nim:352-360
+        cl_freq[s_rle[i]]++;
+        if (s_rle[i] >= 16) i++;
+      }
+      uint16_t cl_codes[20];
+      uint8_t cl_lens[20];
+      huffman_codes(cl_freq, 19, 19, 7, cl_codes, cl_lens, s_work);  // deflate.nim:362
+      uint32_t clcl_ordered[19];
+      for (int i = 0; i < 19; i++) clcl_ordered[i] = cl_lens[c_clcl_order[i]];
+      int hclen = 19;
+      while (clcl_ordered[hclen - 1] == 0) hclen--;
+      hclen -= 4;
+      hdr_add(h, bd.is_final ? 1 : 0, 1);  // deflate.nim:376-383
+      hdr_add(h, 2, 2);
+      hdr_add(h, (uint32_t)(n_litlen - 257), 5);
+      hdr_add(h, (uint32_t)(n_dist - 1), 5);
+      hdr_add(h, (uint32_t)hclen, 4);
+      for (int i = 0; i < hclen + 4; i++) hdr_add(h, clcl_ordered[i], 3);
+      for (int i = 0; i < rle_len;) {  // deflate.nim:388-401
+        const uint32_t sym = s_rle[i++];
+        hdr_add(h, cl_codes[sym], cl_lens[sym]);
+        if (sym == 16) hdr_add(h, s_rle[i++], 2);
+        else if (sym == 17) hdr_add(h, s_rle[i++], 3);
+        else if (sym == 18) hdr_add(h, s_rle[i++], 7);
+      }
+    }
+    s_hdr_bits = h.bits;
+  }
+  zh_wave_sync();
+
+  const uint32_t mode = s_mode;
+  if (lane == 0) {
+    a.b_mode[b] = mode;
+    a.b_hdr_bits[b] = s_hdr_bits;
+  }
+  if (mode == ZH_MODE_STORED) return;
+
+  for (uint32_t i = lane; i < 288; i += 64) a.b_litcode[(size_t)b * 288 + i] = s_codes[i] | ((uint32_t)s_lens[i] << 16);
+  if (lane < 32) a.b_distcode[(size_t)b * 32 + lane] = lane < 30 ? (s_codes[288 + lane] | ((uint32_t)s_lens[288 + lane] << 16)) : 0u;
+  for (uint32_t i = lane; i < ZH_HDR_WORDS; i += 64) a.b_hdr[(size_t)b * ZH_HDR_WORDS + i] = s_hdr[i];
+
+  // ---- encoded size of every fragment under these codes ----
+  uint64_t total = s_hdr_bits + s_lens[256];
+  for (uint32_t k = 0; k < bd.nfrag; k++) {
+    const uint32_t f = bd.first_frag + k;
+    const uint16_t* hist = a.f_hist + (size_t)f * ZH_HIST_STRIDE;
+    uint32_t acc = 0;
+    for (uint32_t i = lane; i < ZH_NUM_LITLEN + ZH_NUM_DIST; i += 64) {
+      const uint32_t l = i < ZH_NUM_LITLEN ? s_lens[i] : s_lens[288 + (i - ZH_NUM_LITLEN)];
+      acc += (uint32_t)hist[i] * l;
+    }
+    acc = zh_wave_sum(acc) + a.f_extra_bits[f];
+    if (lane == 0) a.f_bits[f] = acc;
+    total += acc;
+  }
+  if (lane == 0) a.b_bits[b] = total;
+}
+
+__global__ __launch_bounds__(64) void zh_layout_kernel(uint8_t* __restrict__ d_dst, ZhCompressArgs a,
+                                                       const uint32_t* __restrict__ buf_crc,
+                                                       const uint32_t* __restrict__ buf_adler) {
+  const unsigned lane = zh_lane();
+  const uint32_t bi = blockIdx.x;
+  const ZhBufDesc bd = a.bufs[bi];
+  const int fmt = a.data_format;
+  uint8_t* out = d_dst + bd.dst_off;
+
+  const uint32_t hdr_len = fmt == ZH_DF_GZIP ? 10 + bd.fname_len + 1 : fmt == ZH_DF_ZLIB ? 2 : 0;
+  const uint32_t trailer_len = fmt == ZH_DF_GZIP ? 8 : fmt == ZH_DF_ZLIB ? 4 : 0;
+
+  // ---- pass 1: size of the deflate body (uniform arithmetic) ----
+  uint64_t cursor = 0;  // bits, relative to the start of the deflate body
+  for (uint32_t k = 0; k < bd.nblocks; k++) {
+    const uint32_t b = bd.first_block + k;
+    const ZhBlockDesc blk = a.blocks[b];
+    if (a.b_mode[b] == ZH_MODE_STORED) {  // deflate.nim:179-205
+      uint64_t chunks = (blk.len + ZH_STORED_MAX - 1) / ZH_STORED_MAX;
+      if (chunks < 1) chunks = 1;
+      const uint64_t first_len_byte = (cursor + 3 + 7) >> 3;
+      cursor = (first_len_byte + 4 + blk.len + 5 * (chunks - 1)) * 8;
+    } else {
+      cursor += a.b_bits[b];
+    }
+  }
+  const uint64_t body_bytes = (cursor + 7) >> 3;
+  const uint64_t total_len = hdr_len + body_bytes + trailer_len;
+  if (total_len > bd.dst_cap) {
+    if (lane == 0) {
+      a.out_len[bi] = total_len;
+      a.status[bi] = ZH_ERR_DST_TOO_SMALL;
+    }
+    // poison the fragments so that the emission kernel skips this buffer
+    for (uint32_t k = 0; k < bd.nblocks; k++) {
+      const ZhBlockDesc blk = a.blocks[bd.first_block + k];
+      for (uint32_t j = lane; j < blk.nfrag; j += 64) a.f_bit_start[blk.first_frag + j] = ~0ull;
+    }
+    return;
+  }
+
+  // ---- container header ----
+  if (fmt == ZH_DF_GZIP) {  // zippy.nim:22-42
+    if (lane == 0) {
+      or_byte(out, 0, 31);
+      or_byte(out, 1, 139);
+      or_byte(out, 2, 8);
+      or_byte(out, 3, 1u << 3);  // FNAME
+    }
+    if (lane < bd.fname_len) or_byte(out, 10 + lane, 97 + lane);
+  } else if (fmt == ZH_DF_ZLIB) {  // zippy.nim:61-69
+    if (lane == 0) {
+      const uint32_t cmf = (7u << 4) | 8u;
+      or_byte(out, 0, cmf);
+      or_byte(out, 1, 31u - (cmf * 256u) % 31u);
+    }
+  }
+
+  // ---- pass 2: positions, block headers, EOB codes, stored headers ----
+  const uint64_t body_bit0 = (uint64_t)hdr_len * 8;  // relative to `out`
+  cursor = 0;
+  for (uint32_t k = 0; k < bd.nblocks; k++) {
+    const uint32_t b = bd.first_block + k;
+    const ZhBlockDesc blk = a.blocks[b];
+    const uint32_t mode = a.b_mode[b];
+    if (mode == ZH_MODE_STORED) {
+      uint64_t chunks = (blk.len + ZH_STORED_MAX - 1) / ZH_STORED_MAX;
+      if (chunks < 1) chunks = 1;
+      const uint64_t first_len_byte = (body_bit0 + cursor + 3 + 7) >> 3;  // relative to out
+      const uint64_t d0 = first_len_byte + 4;  // block byte o lands at d0 + o + 5 * (o / 65535)
+      for (uint64_t c = lane; c < chunks; c += 64) {
+        const uint32_t fin = (blk.is_final && c == chunks - 1) ? 1u : 0u;
+        const uint64_t clen = (c == chunks - 1) ? blk.len - c * ZH_STORED_MAX : ZH_STORED_MAX;
+        const uint64_t len_byte = d0 - 4 + c * (ZH_STORED_MAX + 5ull);
+        if (c == 0) or_bits(out, body_bit0 + cursor, fin, 3);  // BFINAL + BTYPE=00, then pad
+        else or_bits(out, (len_byte - 1) * 8, fin, 3);
+        or_bits(out, len_byte * 8, (uint32_t)clen | ((uint32_t)(ZH_STORED_MAX - clen) << 16), 32);
+      }
+      if (lane == 0) a.b_stored_d0[b] = bd.dst_off + d0;
+      cursor = (d0 + blk.len + 5 * (chunks - 1)) * 8 - body_bit0;
+    } else {
+      const uint32_t hbits = a.b_hdr_bits[b];
+      const uint32_t* hdr = a.b_hdr + (size_t)b * ZH_HDR_WORDS;
+      for (uint32_t w = lane; w * 32 < hbits; w += 64) {
+        const uint32_t nb = hbits - w * 32 < 32 ? hbits - w * 32 : 32;
+        or_bits(out, body_bit0 + cursor + (uint64_t)w * 32, hdr[w], nb);
+      }
+      cursor += hbits;
+      for (uint32_t base = 0; base < blk.nfrag; base += 64) {
+        const uint32_t j = base + lane;
+        const uint32_t fb = j < blk.nfrag ? a.f_bits[blk.first_frag + j] : 0u;
+        // 64-bit inclusive scan built from the 32-bit one (fragment sums fit in 32 bits:
+        // 64 fragments * 32 KiB * 15 bits < 2^32)
+        const uint32_t incl = zh_wave_scan(fb);
+        if (j < blk.nfrag)
+          a.f_bit_start[blk.first_frag + j] = (bd.dst_off + hdr_len) * 8 + cursor + (incl - fb);
+        cursor += __shfl(incl, 63, 64);
+      }
+      const uint32_t eob = a.b_litcode[(size_t)b * 288 + 256];
+      if (lane == 0) or_bits(out, body_bit0 + cursor, eob & 0xffffu, eob >> 16);  // deflate.nim:471
+      cursor += eob >> 16;
+    }
+  }
+
+  // ---- trailer (after padding to a byte, deflate.nim:473) ----
+  const uint64_t tpos = hdr_len + ((cursor + 7) >> 3);
+  if (fmt == ZH_DF_GZIP) {  // zippy.nim:47-58
+    const uint32_t crc = buf_crc[bi], isize = (uint32_t)(bd.src_len & 0xffffffffu);
+    if (lane < 4) or_byte(out, tpos + lane, crc >> (8 * lane));
+    else if (lane < 8) or_byte(out, tpos + lane, isize >> (8 * (lane - 4)));
+  } else if (fmt == ZH_DF_ZLIB) {  // zippy.nim:71-78 (big-endian)
+    const uint32_t ad = buf_adler[bi];
+    if (lane < 4) or_byte(out, tpos + lane, ad >> (8 * (3 - lane)));
+  }
+  if (lane == 0) {
+    a.out_len[bi] = total_len;
+    a.status[bi] = ZH_OK;
+  }
+}
+
+extern "C" void zh_launch_huffman(hipStream_t stream, ZhCompressArgs a) {
+  if (!a.nblocks) return;
+  hipLaunchKernelGGL(zh_huffman_kernel, dim3(a.nblocks), dim3(64), 0, stream, a);
+}
+extern "C" void zh_launch_layout(hipStream_t stream, uint8_t* d_dst, ZhCompressArgs a,
+                                 const uint32_t* buf_crc, const uint32_t* buf_adler) {
+  if (!a.nbufs) return;
+  hipLaunchKernelGGL(zh_layout_kernel, dim3(a.nbufs), dim3(64), 0, stream, d_dst, a, buf_crc,
+                     buf_adler);
+}
