@@ -1,0 +1,162 @@
+"""Parity cases shared by tests/test_gpu_parity.py (real MI355X through
+zippy_amd/libzippy_hip.so) and tests/test_emu_parity.py (the same kernel sources
+under the CPU emulator).  `eng` is a zippy_amd._binding.Engine; the oracle
+(oracle/) is the checker.  Mirrors the reference's own tests."""
+import hashlib
+import random
+import zlib
+
+import numpy as np
+
+import oracle
+from zippy_amd import synth
+
+WBITS = {oracle.dfDeflate: -15, oracle.dfZlib: 15, oracle.dfGzip: 31}
+FORMATS = (oracle.dfDeflate, oracle.dfZlib, oracle.dfGzip)
+
+
+def check_fixtures(eng, max_len=None):
+    """tests/test.nim:41-60, tests/test_known_bad.nim:3 -- bit-exact decode."""
+    names, blobs = [], []
+    for name, meta in synth.manifest()["fixtures"].items():
+        if max_len is None or meta["len"] <= max_len:
+            names.append(name)
+            blobs.append(synth.fixture(name))
+    outs, sts = eng.uncompress_batch(blobs)
+    for name, out, st in zip(names, outs, sts):
+        meta = synth.manifest()["fixtures"][name]
+        assert st == 0, (name, st)
+        assert len(out) == meta["len"], name
+        assert hashlib.sha256(out).hexdigest() == meta["sha256"], name
+
+
+def check_compress_identical(eng, inputs, levels, formats=FORMATS):
+    """Device output == oracle output, byte for byte; an independent decoder
+    (zlib) and the oracle's zippy-equivalent decoder both round-trip it."""
+    eng.set_gzip_fname_len(0)
+    for level in levels:
+        for fmt in formats:
+            outs, sts = eng.compress_batch(inputs, level, fmt)
+            for src, out, st in zip(inputs, outs, sts):
+                assert st == 0, (level, fmt, len(src), st)
+                ref = oracle.compress(src, level, fmt, fname_len=0)
+                assert out == ref, "level %d fmt %d len %d: device %d B vs oracle %d B" % (
+                    level, fmt, len(src), len(out), len(ref))
+                assert zlib.decompress(out, WBITS[fmt]) == src
+                assert oracle.uncompress(out, fmt) == src
+
+
+def check_roundtrip(eng, inputs, level, fmt=oracle.dfGzip):
+    outs, sts = eng.compress_batch(inputs, level, fmt)
+    assert all(s == 0 for s in sts)
+    back, sts2 = eng.uncompress_batch(outs, oracle.dfDeflate if fmt == oracle.dfDeflate
+                                      else oracle.dfDetect)
+    assert all(s == 0 for s in sts2), sts2
+    for src, b in zip(inputs, back):
+        assert b == src
+
+
+def check_tokens(eng, src, level):
+    """Device match list re-expressed as the reference's u16 token stream
+     == oracle token stream, block by block."""
+    dev = eng.debug_tokens(src, level)
+    parts = [oracle.block_tokens(src, level, o, min(len(src) - o, 4194304))[0]
+             for o in range(0, max(len(src), 1), 4194304)]
+    want = np.concatenate(parts) if parts else np.zeros(0, np.uint16)
+    assert np.array_equal(dev, want), (level, len(dev), len(want))
+
+
+def check_gzip_random_fname(eng, src):
+    """zippy.nim:26-42: FNAME of 0..25 letters chosen per call."""
+    eng.set_gzip_fname_len(-1)
+    seen = set()
+    for _ in range(12):
+        out = eng.compress(src, 1, oracle.dfGzip)
+        assert out[:4] == b"\x1f\x8b\x08\x08"
+        k = out.index(b"\x00", 10) - 10
+        assert 0 <= k <= 25 and out[10:10 + k] == bytes(range(97, 97 + k))
+        seen.add(k)
+        assert zlib.decompress(out, 31) == src
+        assert oracle.uncompress(out) == src
+    eng.set_gzip_fname_len(0)
+    assert len(seen) > 1
+
+
+def check_checksums(eng, blobs):
+    for d in blobs:
+        assert eng.crc32(d) == zlib.crc32(d)
+        assert eng.adler32(d) == zlib.adler32(d)
+
+
+def check_errors_match_oracle(eng, blobs, data_format=oracle.dfDetect):
+    """tests/fuzz.nim / tests/stress.nim contract: a damaged stream either fails
+    (any ZippyError) or decodes; device and oracle must agree on which, and on
+    the bytes when it decodes."""
+    outs, sts = eng.uncompress_batch(blobs, data_format)
+    for blob, out, st in zip(blobs, outs, sts):
+        try:
+            want = oracle.uncompress(blob, data_format)
+            ok = True
+        except oracle.ZippyError:
+            ok = False
+        assert (st == 0) == ok, (len(blob), st, ok)
+        if ok:
+            assert out == want
+
+
+def mutated_fixtures(count, seed, max_len=70000):
+    """tests/fuzz.nim:16-33: flip one byte, then truncate at that position."""
+    files = ["randtest1.gz", "randtest2.gz", "randtest3.gz", "rfctest1.gz", "rfctest2.gz",
+             "rfctest3.gz", "zerotest1.gz", "zerotest2.gz"]
+    files = [f for f in files if synth.manifest()["fixtures"][f]["len"] <= max_len]
+    rng = random.Random(seed)
+    blobs = []
+    for _ in range(count):
+        comp = bytearray(synth.fixture(rng.choice(files)))
+        pos = rng.randrange(len(comp))
+        comp[pos] = rng.randrange(256)
+        blobs.append(bytes(comp))
+        blobs.append(bytes(comp[:pos]))
+    return blobs
+
+
+def edge_inputs():
+    rnd = random.Random(5)
+    text = synth.corpus_file("alice29.txt")
+    sizes = [0, 1, 2, 4, 5, 14, 15, 16, 17, 255, 256, 2047, 2048, 2049, 32767, 32768, 32769,
+             65535, 65536, 65537]
+    out = [text[:n] for n in sizes]
+    out += [bytes(range(256)), b"\x00" * 70000, rnd.randbytes(70000), b"ab" * 20000]
+    return out
+
+
+def check_error_statuses(eng):
+    gz = bytearray(oracle.compress(b"hello world" * 10, 1, fname_len=0))
+
+    def status_of(blob, fmt=oracle.dfDetect):
+        _, sts = eng.uncompress_batch([bytes(blob)], fmt)
+        return sts[0]
+
+    bad = bytearray(gz)
+    bad[3] |= 4
+    assert status_of(bad) == 12  # FEXTRA, gzip.nim:40-41
+    bad = bytearray(gz)
+    bad[-5] ^= 1
+    assert status_of(bad) == 8  # CRC, gzip.nim:80-81
+    bad = bytearray(gz)
+    bad[-1] ^= 1
+    assert status_of(bad) != 0  # ISIZE, gzip.nim:83-88
+    assert status_of(b"\x00" * 30) == 3  # detect, zippy.nim:125
+    assert status_of(b"\x07" + b"\x00" * 16, oracle.dfDeflate) == 17  # BTYPE 3, inflate.nim:288
+    # a bad stream must not poison its neighbours
+    good = oracle.compress(b"neighbour" * 100, 1, fname_len=0)
+    outs, sts = eng.uncompress_batch([good, bytes(bad), good])
+    assert sts[0] == 0 and sts[2] == 0 and sts[1] != 0
+    assert outs[0] == b"neighbour" * 100 and outs[2] == outs[0]
+    import pytest
+    from zippy_amd.common import ZippyError
+    for level in (10, -3):
+        with pytest.raises(ZippyError):
+            eng.compress(b"x", level)
+    with pytest.raises(ZippyError):
+        eng.compress(b"x", 1, oracle.dfDetect)

@@ -1,0 +1,199 @@
+"""Parity proper (-m gpu): hand-written gfx950 kernels through the C ABI
+(zippy_amd/libzippy_hip.so) against the oracle, on a real MI355X."""
+import hashlib
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+import parity_cases as pc
+from zippy_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from zippy_amd import api
+    e = api.engine()
+    e.set_gzip_fname_len(0)
+    return e
+
+
+def test_gpu_fixtures_decode(eng):
+    pc.check_fixtures(eng)
+
+
+def test_gpu_compress_identical_all_levels_corpus(eng, golds):
+    """tests/test_levels.nim:18-25 and tests/test.nim:62-85, tightened from
+    'round-trips' to 'byte-identical to the oracle'."""
+    names = ["randtest1.gold", "rfctest1.gold", "zerotest1.gold", "empty.gold", "alice29.txt",
+             "asyoulik.txt", "fireworks.jpg", "geo.protodata", "html", "kppkn.gtb",
+             "paper-100k.pdf"]
+    inputs = [golds[n] for n in names]
+    pc.check_compress_identical(eng, inputs, levels=range(-2, 10), formats=(oracle.dfGzip,))
+    pc.check_compress_identical(eng, inputs, levels=(1, -1), formats=(oracle.dfDeflate, oracle.dfZlib))
+
+
+def test_gpu_oracle_kat_hashes(eng, manifest, golds):
+    """Committed hashes of the oracle's output (tests/golden/manifest.json)."""
+    for name, per_level in manifest["oracle_kat"].items():
+        for level in ("1", "-1", "-2", "0", "9"):
+            out = eng.compress(golds[name], int(level), oracle.dfDeflate)
+            assert len(out) == per_level[level]["len"], (name, level)
+            assert hashlib.sha256(out).hexdigest() == per_level[level]["sha256"], (name, level)
+
+
+def test_gpu_edge_inputs(eng):
+    pc.check_compress_identical(eng, pc.edge_inputs(), levels=(1, -1, -2, 0))
+
+
+def test_gpu_tokens(eng, golds):
+    for name in ("urls.10K", "alice29.txt", "geo.protodata", "fireworks.jpg", "zerotest3.gold"):
+        pc.check_tokens(eng, golds[name], 1)
+    pc.check_tokens(eng, golds["kppkn.gtb"], -1)
+    pc.check_tokens(eng, golds["html"], 9)
+    pc.check_tokens(eng, golds["html"], -2)
+
+
+def test_gpu_config2_batch_1024x64k_bestspeed(eng):
+    """BASELINE.json configs[1]: 1024 x 64 KiB G-mix, BestSpeed, every buffer
+    byte-identical to the oracle and decodable by zlib."""
+    bufs = [b.tobytes() for b in synth.gen_batch("mix", 1024, 65536)]
+    outs, sts = eng.compress_batch(bufs, 1, oracle.dfGzip)
+    assert all(s == 0 for s in sts)
+    for src, out in zip(bufs, outs):
+        assert out == oracle.compress(src, 1, oracle.dfGzip, fname_len=0)
+    for src, out in zip(bufs[::37], outs[::37]):
+        assert zlib.decompress(out, 31) == src
+    back, sts = eng.uncompress_batch(outs)
+    assert all(s == 0 for s in sts) and back == bufs
+
+
+def test_gpu_config3_uncompress_1mib_streams(eng):
+    """BASELINE.json configs[2] at test size: 1 MiB streams pre-gzipped on the host by
+    the oracle (level 1) and by system zlib (level 6, multi-block foreign streams)."""
+    bufs = [b.tobytes() for b in synth.gen_batch("mix", 48, 1 << 20)]
+    blobs = [oracle.compress(b, 1, oracle.dfGzip, fname_len=i % 26) for i, b in enumerate(bufs)]
+    blobs += [zlib.compress(b, 6) for b in bufs[:16]]
+    co = [zlib.compressobj(6, zlib.DEFLATED, 31) for _ in range(16)]
+    blobs += [c.compress(b) + c.flush() for c, b in zip(co, bufs[:16])]
+    outs, sts = eng.uncompress_batch(blobs)
+    assert all(s == 0 for s in sts), sts
+    assert outs == bufs + bufs[:16] + bufs[:16]
+
+
+def test_gpu_config4_default_compression_ratio(eng):
+    """BASELINE.json configs[3] at test size: DefaultCompression, identical to the oracle."""
+    bufs = [b.tobytes() for b in synth.gen_batch("mix", 12, 1 << 20)]
+    outs, sts = eng.compress_batch(bufs, -1, oracle.dfGzip)
+    assert all(s == 0 for s in sts)
+    for src, out in zip(bufs, outs):
+        assert out == oracle.compress(src, -1, oracle.dfGzip, fname_len=0)
+
+
+def test_gpu_config5_single_large_buffer(eng):
+    """BASELINE.json configs[4] substitute (tor-list.gold is absent): one 40 MiB buffer =
+    10 deflate blocks x 128 LZ-independent fragments, compress + uncompress."""
+    parts = synth.gen_batch("mix", 40, 1 << 20)
+    src = parts.tobytes()
+    out = eng.compress(src, 1, oracle.dfGzip)
+    assert out == oracle.compress(src, 1, oracle.dfGzip, fname_len=0)
+    assert eng.uncompress(out) == src
+
+
+def test_gpu_property_roundtrip_kinds(eng):
+    for kind in ("runs", "rand", "zero", "mix"):
+        bufs = [b.tobytes() for b in synth.gen_batch(kind, 32, 200000 + 7)]
+        for level in (1, -2, 0):
+            pc.check_roundtrip(eng, bufs, level)
+        outs, _ = eng.compress_batch(bufs[:4], 1, oracle.dfDeflate)
+        for s, o in zip(bufs[:4], outs):
+            assert o == oracle.deflate(s, 1)
+
+
+def test_gpu_stress_runs(eng):
+    """tests/stress.nim:10-58 restated with fixed seeds, BestSpeed and default really passed."""
+    bufs = []
+    for seed in range(64):
+        rng = np.random.default_rng(seed)
+        data = synth.gen_runs(rng, int(rng.integers(0, 100001)))
+        bufs.append(data.tobytes())
+        bufs.append(rng.permutation(data).tobytes())
+    pc.check_compress_identical(eng, bufs, levels=(1,), formats=(oracle.dfGzip,))
+    pc.check_compress_identical(eng, bufs[:24], levels=(-1,), formats=(oracle.dfGzip,))
+
+
+def test_gpu_cross_encoder_streams(eng, golds):
+    """tests/stress2.nim:8-20: zlib-made streams of growing size."""
+    base = golds["rfctest3.gold"]
+    blobs, want = [], []
+    for mult in (1, 2, 5, 17, 40):
+        for level in (1, 6, 9):
+            blobs.append(zlib.compress(base * mult, level))
+            want.append(base * mult)
+    outs, sts = eng.uncompress_batch(blobs)
+    assert all(s == 0 for s in sts) and outs == want
+
+
+def test_gpu_damaged_streams_agree_with_oracle(eng):
+    pc.check_errors_match_oracle(eng, pc.mutated_fixtures(400, seed=2024))
+    pc.check_error_statuses(eng)
+
+
+def test_gpu_random_fname_and_checksums(eng, golds):
+    pc.check_gzip_random_fname(eng, golds["alice29.txt"])
+    pc.check_checksums(eng, [golds["alice29.txt"], golds["urls.10K"], b"", b"a",
+                             random.Random(3).randbytes(1 << 20), golds["zerotest3.gold"]])
+
+
+def test_gpu_device_api_unaligned_offsets(eng, golds):
+    """Device-resident API with byte-granular (unaligned) source offsets and slots."""
+    import torch
+    srcs = [golds["alice29.txt"][:70001], golds["html"][:33333], b"", golds["geo.protodata"][:5]]
+    pad = [3, 1, 7, 2]
+    blob = bytearray()
+    soff = []
+    for s, p in zip(srcs, pad):
+        blob += b"\xaa" * p
+        soff.append(len(blob))
+        blob += s
+    d_src = torch.frombuffer(bytes(blob) + b"\x00" * 64, dtype=torch.uint8).cuda()
+    caps = [eng.compress_bound(len(s)) for s in srcs]
+    doff, total = [], 5
+    for c in caps:
+        doff.append(total)
+        total += c + 3
+    d_dst = torch.empty(total + 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    plan = eng.plan_compress(soff, [len(s) for s in srcs], doff, caps, 1, oracle.dfGzip)
+    plan.run(d_src.data_ptr(), d_dst.data_ptr())
+    lens, sts = plan.results()
+    assert sts == [0] * 4
+    host = d_dst.cpu().numpy().tobytes()
+    for s, o, n in zip(srcs, doff, lens):
+        assert host[o:o + n] == oracle.compress(s, 1, oracle.dfGzip, fname_len=0)
+    # and back, straight from the compressed slots with device-side lengths
+    ocap = [len(s) for s in srcs]
+    ooff, t2 = [], 1
+    for c in ocap:
+        ooff.append(t2)
+        t2 += c + 5
+    d_out = torch.zeros(t2 + 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    up = eng.plan_uncompress(doff, caps, ooff, ocap, oracle.dfGzip)
+    up.set_src_lens_device(plan.device_lens())
+    up.run(d_dst.data_ptr(), d_out.data_ptr())
+    lens2, sts2 = up.results()
+    assert sts2 == [0] * 4 and lens2 == ocap
+    host2 = d_out.cpu().numpy().tobytes()
+    for s, o in zip(srcs, ooff):
+        assert host2[o:o + len(s)] == s
+    # slot too small -> per-buffer status, neighbours unaffected, nothing written
+    small = eng.plan_compress(soff, [len(s) for s in srcs], doff, [caps[0], 100, caps[2], caps[3]],
+                              1, oracle.dfGzip)
+    small.run(d_src.data_ptr(), d_dst.data_ptr())
+    _, sts3 = small.results()
+    assert sts3 == [0, 21, 0, 0]
