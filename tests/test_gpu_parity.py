@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def eng():
+    import torch  # torch's bundled HIP runtime has to initialise before libzippy_hip.so's
+    torch.cuda.init()
     from zippy_amd import api
     e = api.engine()
     e.set_gzip_fname_len(0)

@@ -6,12 +6,14 @@
 // (gzip header + trailer), inflate.nim:24-291 (Huffman tables, decode loop,
 // stored blocks) and the BitStreamReader of bitstreams.nim:22-82.
 //
-// Per wave, in LDS: the 32 KiB output window as a ring (LZ copies never touch
-// HBM), a 4 KiB sliding window of the input stream, a 10-bit literal/length
-// LUT and a 9-bit distance LUT (inflate.nim's 9-bit `fast` table widened), and
-// the canonical slow-path arrays (firstCode / firstSymbol / maxCodes / values,
-// inflate.nim:14-19).  The decode state (bit buffer, positions) is wave-uniform
-// and lives in scalar registers; the 64 lanes cooperate on LZ copies, stored
+// Per wave, in LDS (39 KiB, 4 waves per CU): the 32 KiB output window as a ring
+// (LZ copies never touch HBM), a 10-bit literal/length LUT and an 8-bit distance
+// LUT of self-describing 32-bit entries (inflate.nim's 9-bit `fast` table,
+// re-shaped), and the canonical slow-path arrays (firstCode / firstSymbol /
+// maxCodes / values, inflate.nim:14-19).  The compressed stream is held 512
+// bytes at a time in two VGPRs per lane and fed to a wave-uniform 64-bit bit
+// buffer with v_readlane, so the per-symbol chain is one LDS lookup.  The decode
+// state lives in scalar registers; the 64 lanes cooperate on LZ copies, stored
 // block copies, table construction and the coalesced write-back of the window.
 // Algorithmic traffic: compressed bytes read once, output written once.
 #include "zh_common.h"
@@ -24,8 +26,7 @@ __constant__ zh::LenTables c_len = zh::make_len_tables();
 __constant__ zh::DistTables c_dist = zh::make_dist_tables();
 __constant__ uint8_t c_clcl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-constexpr uint32_t kLitBits = 10, kDistBits = 9;
-constexpr uint32_t kInWin = 4096;  // bytes of input staged in LDS
+constexpr uint32_t kLitBits = 10, kDistBits = 8;
 
 }  // namespace
 
@@ -104,10 +105,20 @@ __global__ void zh_unwrap_kernel(const uint8_t* __restrict__ d_src, ZhInflateArg
   a.out_len[i] = 0;
 }
 
+
 // ---------------------------------------------------------------------------
 // Decode tables (inflate.nim:24-65 initHuffman), built by the whole wave.
+//
+// LUT entries are self-describing 32-bit words so that the decode loop needs
+// one LDS lookup per code and no second table for base/extra values:
+//   bits 0-3   code length in bits (0 = not in this table: take the slow path)
+//   bits 4-7   number of extra bits that follow the code
+//   bits 8-9   kind: 0 literal, 1 length (or any distance), 2 end of block, 3 invalid symbol
+//   bits 16-31 literal byte / base length / base distance
 // ---------------------------------------------------------------------------
 namespace {
+
+enum { kKindLit = 0, kKindBase = 1, kKindEob = 2, kKindBad = 3 };
 
 struct HuffTab {
   uint16_t first_code[16];
@@ -115,11 +126,27 @@ struct HuffTab {
   uint32_t max_codes[17];
 };
 
-// lens[0..n): code lengths in LDS.  lut: 1 << lut_bits entries of len << 12 | symbol.
-// Returns ZH_OK or ZH_ERR_INVALID_BUFFER (over-subscribed; incomplete codes are
-// accepted like the reference).
-__device__ int build_table(const uint8_t* lens, uint32_t n, uint16_t* lut, uint32_t lut_bits,
-                           HuffTab* tab, uint16_t* values, uint32_t* s_cnt) {
+__device__ __forceinline__ uint32_t litlen_entry(uint32_t sym, uint32_t len) {
+  if (sym < 256) return len | (kKindLit << 8) | (sym << 16);
+  if (sym == 256) return len | (kKindEob << 8);
+  if (sym < 286) {  // inflate.nim:199-209
+    const uint32_t li = sym - 257;
+    return len | ((uint32_t)c_len.extra[li] << 4) | (kKindBase << 8) | ((uint32_t)c_len.base[li] << 16);
+  }
+  return len | (kKindBad << 8);  // 286, 287 and the 0xffff "unassigned code" marker
+}
+__device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t len) {
+  if (sym < 30)  // inflate.nim:210-222
+    return len | ((uint32_t)c_dist.extra[sym] << 4) | (kKindBase << 8) | ((uint32_t)c_dist.base[sym] << 16);
+  return len | (kKindBad << 8);
+}
+__device__ __forceinline__ uint32_t cl_entry(uint32_t sym, uint32_t len) { return len | (sym << 16); }
+
+// lens[0..n): code lengths in LDS.  kind selects the entry encoder (0 litlen, 1 distance,
+// 2 code-length alphabet).  Returns ZH_OK or ZH_ERR_INVALID_BUFFER (over-subscribed;
+// incomplete codes are accepted like the reference).
+__device__ int build_table(const uint8_t* lens, uint32_t n, uint32_t* lut, uint32_t lut_bits,
+                           int kind, HuffTab* tab, uint16_t* values, uint32_t* s_cnt) {
   const unsigned lane = zh_lane();
   zh_wave_sync();
   if (lane < 16) s_cnt[lane] = 0;
@@ -170,7 +197,7 @@ __device__ int build_table(const uint8_t* lens, uint32_t n, uint16_t* lut, uint3
     if (l) {
       values[my_code - tab->first_code[l] + tab->first_symbol[l]] = (uint16_t)s;
       if (l <= lut_bits) {
-        const uint16_t entry = (uint16_t)((l << 12) | s);
+        const uint32_t entry = kind == 0 ? litlen_entry(s, l) : kind == 1 ? dist_entry(s, l) : cl_entry(s, l);
         for (uint32_t kk = __brev(my_code) >> (32 - l); kk < (1u << lut_bits); kk += 1u << l)
           lut[kk] = entry;
       }
@@ -180,29 +207,18 @@ __device__ int build_table(const uint8_t* lens, uint32_t n, uint16_t* lut, uint3
   return ZH_OK;
 }
 
-// Wave-uniform bit reader over the LDS input window (bitstreams.nim:22-62).
-struct BitReader {
-  uint64_t buf;
-  int32_t cnt;        // valid bits in buf
-  uint64_t in_pos;    // stream byte offset of the next byte to load
-  uint64_t win_base;  // stream byte offset of s_in[0]
-};
-
 }  // namespace
 
 __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restrict__ d_src,
                                                         uint8_t* __restrict__ d_dst,
                                                         ZhInflateArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[32768];
-  __shared__ __attribute__((aligned(16))) uint32_t s_in[kInWin / 4 + 4];
-  __shared__ uint16_t s_lit[1u << kLitBits];
-  __shared__ uint16_t s_dst[1u << kDistBits];
-  __shared__ uint16_t s_clt[128];
+  __shared__ uint32_t s_lit[1u << kLitBits];
+  __shared__ uint32_t s_dst[1u << kDistBits];  // also hosts the 7-bit code-length table
   __shared__ HuffTab s_tab_lit, s_tab_dist, s_tab_cl;
   __shared__ uint16_t s_val_lit[288], s_val_dist[32], s_val_cl[20];
   __shared__ uint8_t s_lens[320 + 16];
   __shared__ uint32_t s_cnt[16];
-  __shared__ uint32_t s_lenbase[32], s_distbase[32];
 
   const unsigned lane = zh_lane();
   const uint32_t sid = blockIdx.x;
@@ -216,70 +232,59 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
   const int count_only = a.count_only;
   const bool dst_al16 = (((uintptr_t)dst) & 15u) == 0;
 
-  if (lane < 29) s_lenbase[lane] = c_len.base[lane] | ((uint32_t)c_len.extra[lane] << 16);
-  if (lane < 30) s_distbase[lane] = c_dist.base[lane] | ((uint32_t)c_dist.extra[lane] << 16);
-
-  BitReader br;
-  br.buf = 0;
-  br.cnt = 0;
-  br.in_pos = a.body_pos[sid];
-  br.win_base = br.in_pos & ~(uint64_t)3;
-
-  // (re)load the whole LDS input window starting at br.win_base (zero past the end)
-  auto load_window = [&](uint32_t from_word) {
-    zh_wave_sync();
-    for (uint32_t w = from_word + lane; w < kInWin / 4 + 4; w += 64) {
-      const uint64_t p = br.win_base + (uint64_t)w * 4;
-      uint32_t v = 0;
-      if (p + 4 <= src_len) {
-        v = src[p] | (src[p + 1] << 8) | (src[p + 2] << 16) | ((uint32_t)src[p + 3] << 24);
-      } else {
-        for (int j = 0; j < 4; j++)
-          if (p + j < src_len) v |= (uint32_t)src[p + j] << (8 * j);
-      }
-      s_in[w] = v;
-    }
-    zh_wave_sync();
-  };
-  load_window(0);
-
-  auto refill = [&]() {  // guarantees cnt > 32
-    if (br.cnt <= 32) {
-      uint32_t off = (uint32_t)(br.in_pos - br.win_base);
-      if (off + 4 > kInWin) {  // slide: keep the upper half, fetch 2 KiB more
-        zh_wave_sync();
-        uint32_t keep[8];
-        for (int j = 0; j < 8; j++) keep[j] = s_in[kInWin / 8 + j * 64 + lane];
-        zh_wave_sync();
-        for (int j = 0; j < 8; j++) s_in[j * 64 + lane] = keep[j];
-        br.win_base += kInWin / 2;
-        load_window(kInWin / 8);
-        off -= kInWin / 2;
-      }
-      const uint32_t w = zh_bcast(zh_ld32(s_in, off));
-      br.buf |= (uint64_t)w << br.cnt;
-      br.cnt += 32;
-      br.in_pos += 4;
-    }
-  };
-  auto consumed_past_end = [&]() -> bool {  // the role of `bitsBuffered < 0`
-    return br.in_pos * 8 - (uint64_t)br.cnt > src_len * 8;
-  };
-  auto take = [&](uint32_t nbits) -> uint32_t {
-    uint32_t v = (uint32_t)br.buf & ((1u << nbits) - 1u);
-    br.buf >>= nbits;
-    br.cnt -= (int32_t)nbits;
+  // ---- input: two 256-byte windows of the stream held in registers (one dword per
+  // lane), addressed relative to the 4-byte aligned base below `src`; the bit buffer
+  // is topped up 32 aligned bits at a time with v_readlane (bitstreams.nim:22-49) ----
+  const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
+  const uint32_t* asrc = reinterpret_cast<const uint32_t*>(src - mis);
+  const uint64_t end = mis + src_len;  // first byte offset (from asrc) past the stream
+  auto load_dword = [&](uint64_t off) -> uint32_t {  // bytes past the end read as zero
+    if (off >= end) return 0u;
+    uint32_t v = asrc[off >> 2];
+    if (off + 4 > end) v &= (1u << (8 * (uint32_t)(end - off))) - 1u;
     return v;
   };
-  // inflate.nim:67-102 decodeSymbol / decodeSymbolSlow; 0xffff = unassigned code
-  auto decode = [&](const uint16_t* lut, uint32_t lut_bits, const HuffTab* tab,
-                    const uint16_t* values) -> uint32_t {
-    const uint32_t e = zh_bcast(lut[(uint32_t)br.buf & ((1u << lut_bits) - 1u)]);
-    if (e) {
-      take(e >> 12);
-      return e & 0xfffu;
+  uint64_t buf = 0;   // bit buffer (LSB first)
+  int32_t cnt = 0;    // valid bits in buf
+  uint64_t wbase = 0; // byte offset (from asrc) of lane 0 of wcur
+  uint32_t widx = 0;  // next dword of wcur to consume
+  uint32_t wcur = 0, wnxt = 0;
+  auto seek = [&](uint64_t sb) {  // restart the bit reader at byte offset sb (from asrc)
+    wbase = sb & ~(uint64_t)255;
+    wcur = load_dword(wbase + 4 * lane);
+    wnxt = load_dword(wbase + 256 + 4 * lane);
+    widx = (uint32_t)(sb - wbase) >> 2;
+    const uint32_t w = __builtin_amdgcn_readlane(wcur, widx);
+    widx++;
+    buf = (uint64_t)(w >> (8 * ((uint32_t)sb & 3u)));
+    cnt = 32 - 8 * (int32_t)((uint32_t)sb & 3u);
+  };
+  auto refill = [&]() {  // guarantees cnt > 32
+    if (cnt <= 32) {
+      if (widx == 64) {
+        wcur = wnxt;
+        wbase += 256;
+        wnxt = load_dword(wbase + 256 + 4 * lane);
+        widx = 0;
+      }
+      const uint32_t w = __builtin_amdgcn_readlane(wcur, widx);
+      widx++;
+      buf |= (uint64_t)w << cnt;
+      cnt += 32;
     }
-    const uint32_t k = __brev((uint32_t)br.buf) >> 16;
+  };
+  // bits consumed so far (from asrc); the role of `bitsBuffered < 0`
+  auto past_end = [&]() -> bool { return (wbase + 4ull * widx) * 8 - (uint64_t)cnt > end * 8; };
+  auto take = [&](uint32_t nbits) -> uint32_t {
+    const uint32_t v = (uint32_t)buf & ((1u << nbits) - 1u);
+    buf >>= nbits;
+    cnt -= (int32_t)nbits;
+    return v;
+  };
+  // inflate.nim:67-91 decodeSymbolSlow for codes longer than the LUT; returns the
+  // symbol (0xffff = unassigned code) and consumes its bits
+  auto decode_slow = [&](uint32_t lut_bits, const HuffTab* tab, const uint16_t* values) -> uint32_t {
+    const uint32_t k = __brev((uint32_t)buf) >> 16;
     uint32_t cl = lut_bits + 1;
     while (cl < 16 && k >= zh_bcast(tab->max_codes[cl])) cl++;
     if (cl >= 16) return 0xffffu;
@@ -289,8 +294,12 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
     return zh_bcast(values[id]);
   };
 
+  seek((uint64_t)mis + a.body_pos[sid]);
+
   uint64_t op = 0, flushed = 0;
   int st = ZH_OK;
+  uint64_t pend = 0;     // up to 8 decoded literals not yet stored in the window
+  uint32_t npend = 0;
 
   // write ring bytes [flushed, upto) back to HBM; upto - flushed <= 32768
   auto flush = [&](uint64_t upto) {
@@ -308,6 +317,19 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
     flushed = upto;
     zh_wave_sync();
   };
+  // store the pending literals; every write-back to HBM is preceded by the capacity check
+  auto flush_pend = [&]() {
+    if (npend) {
+      if (!count_only && lane < npend) s_win[(op + lane) & 32767u] = (uint8_t)(pend >> (8 * lane));
+      op += npend;
+      npend = 0;
+      pend = 0;
+    }
+    if (op - flushed >= 16384 + 1024) {
+      if (op > cap && !count_only) st = ZH_ERR_DST_TOO_SMALL;
+      else flush(flushed + 16384);
+    }
+  };
 
   bool final_block = false;
   while (!final_block && st == ZH_OK) {  // inflate.nim:273-289
@@ -316,27 +338,24 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
     if (bfinal) final_block = true;
 
     if (btype == 0) {  // inflate.nim:252-266 inflateNoCompression
-      take((uint32_t)br.cnt & 7u);
+      take((uint32_t)cnt & 7u);
       refill();
       const uint32_t len = take(16), nlen = take(16);
       if (len + nlen != 65535u) { st = ZH_ERR_INVALID_BUFFER; break; }
-      const uint64_t byte_pos = br.in_pos - (uint64_t)(br.cnt >> 3);
-      if (byte_pos + len > src_len) { st = ZH_ERR_END_OF_BUFFER; break; }
+      const uint64_t byte_pos = wbase + 4ull * widx - (uint64_t)(cnt >> 3);  // from asrc
+      if (byte_pos + len > end) { st = ZH_ERR_END_OF_BUFFER; break; }
       if (op + len > cap && !count_only) { st = ZH_ERR_DST_TOO_SMALL; break; }
+      const uint8_t* raw = reinterpret_cast<const uint8_t*>(asrc) + byte_pos;
       for (uint32_t done = 0; done < len;) {
-        uint32_t n = len - done < 8192u ? len - done : 8192u;
+        const uint32_t n = len - done < 8192u ? len - done : 8192u;
         zh_wave_sync();
         if (!count_only)
-          for (uint32_t i = lane; i < n; i += 64) s_win[(op + i) & 32767u] = src[byte_pos + done + i];
+          for (uint32_t i = lane; i < n; i += 64) s_win[(op + i) & 32767u] = raw[done + i];
         op += n;
         done += n;
         if (op - flushed >= 16384) flush(flushed + 16384);
       }
-      br.buf = 0;
-      br.cnt = 0;
-      br.in_pos = byte_pos + len;
-      br.win_base = br.in_pos & ~(uint64_t)3;
-      load_window(0);
+      seek(byte_pos + len);
       continue;
     }
     if (btype == 3) { st = ZH_ERR_BLOCK_HEADER; break; }
@@ -359,30 +378,35 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
         const uint32_t v = take(3);
         if (lane == 0) s_lens[c_clcl_order[i]] = (uint8_t)v;
       }
-      st = build_table(s_lens, 19, s_clt, 7, &s_tab_cl, s_val_cl, s_cnt);
+      st = build_table(s_lens, 19, s_dst, 7, 2, &s_tab_cl, s_val_cl, s_cnt);
       if (st != ZH_OK) break;
-      // the cl lengths sit in s_lens[0..19); unpack litlen+dist lengths after them
-      uint8_t* unpacked = s_lens;  // overwritten below only after the cl table is built
       uint32_t i = 0;
       const uint32_t total = hlit + hdist;
       uint32_t prev = 0;
       while (i != total) {
         refill();
-        const uint32_t sym = decode(s_clt, 7, &s_tab_cl, s_val_cl);
-        if (consumed_past_end()) { st = ZH_ERR_END_OF_BUFFER; break; }
+        uint32_t sym;
+        const uint32_t e = zh_bcast(s_dst[(uint32_t)buf & 127u]);
+        if (e) {
+          take(e & 15u);
+          sym = e >> 16;
+        } else {
+          sym = decode_slow(7, &s_tab_cl, s_val_cl);
+        }
+        if (past_end()) { st = ZH_ERR_END_OF_BUFFER; break; }
         if (sym <= 15) {
-          if (lane == 0) unpacked[i] = (uint8_t)sym;
+          if (lane == 0) s_lens[i] = (uint8_t)sym;
           prev = sym;
           i++;
         } else if (sym == 16) {
           if (i == 0) { st = ZH_ERR_INVALID_BUFFER; break; }
           const uint32_t rep = take(2) + 3;
           if (i + rep > 320) { st = ZH_ERR_INVALID_BUFFER; break; }
-          if (lane < rep) unpacked[i + lane] = (uint8_t)prev;
+          if (lane < rep) s_lens[i + lane] = (uint8_t)prev;
           i += rep;
         } else if (sym == 17 || sym == 18) {
           const uint32_t rep = sym == 17 ? take(3) + 3 : take(7) + 11;
-          for (uint32_t j = lane; j < rep && i + j < 320 + 16; j += 64) unpacked[i + j] = 0;
+          for (uint32_t j = lane; j < rep && i + j < 320 + 16; j += 64) s_lens[i + j] = 0;
           prev = 0;
           i += rep;
         } else {
@@ -395,53 +419,73 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
     }
     {
       const uint32_t dist_at = btype == 1 ? 288u : hlit;
-      st = build_table(s_lens, hlit, s_lit, kLitBits, &s_tab_lit, s_val_lit, s_cnt);
+      st = build_table(s_lens, hlit, s_lit, kLitBits, 0, &s_tab_lit, s_val_lit, s_cnt);
       if (st != ZH_OK) break;
-      st = build_table(s_lens + dist_at, hdist, s_dst, kDistBits, &s_tab_dist, s_val_dist, s_cnt);
+      st = build_table(s_lens + dist_at, hdist, s_dst, kDistBits, 1, &s_tab_dist, s_val_dist, s_cnt);
       if (st != ZH_OK) break;
     }
 
     for (;;) {  // inflate.nim:173-250
       refill();
-      const uint32_t sym = decode(s_lit, kLitBits, &s_tab_lit, s_val_lit);
-      if (consumed_past_end()) { st = ZH_ERR_END_OF_BUFFER; break; }
-      if (sym <= 255) {
-        if (op >= cap && !count_only) { st = ZH_ERR_DST_TOO_SMALL; break; }
-        if (!count_only && lane == 0) s_win[op & 32767u] = (uint8_t)sym;
-        op++;
-      } else if (sym == 256) {
-        break;
+      uint32_t e = zh_bcast(s_lit[(uint32_t)buf & ((1u << kLitBits) - 1u)]);
+      if (e == 0) {  // longer than the LUT, or unassigned
+        const uint32_t sym = decode_slow(kLitBits, &s_tab_lit, s_val_lit);
+        e = litlen_entry(sym, 0);
       } else {
-        const uint32_t li = sym - 257;
-        if (li >= 29) { st = ZH_ERR_INVALID_BUFFER; break; }  // inflate.nim:202-204 (and 0xffff)
-        refill();
-        const uint32_t lb = zh_bcast(s_lenbase[li]);
-        const uint32_t length = (lb & 0xffffu) + take(lb >> 16);
-        const uint32_t dsym = decode(s_dst, kDistBits, &s_tab_dist, s_val_dist);
-        if (dsym >= 30) { st = ZH_ERR_INVALID_BUFFER; break; }  // inflate.nim:211-213
-        const uint32_t db = zh_bcast(s_distbase[dsym]);
-        const uint32_t dist = (db & 0xffffu) + take(db >> 16);
-        if (dist > op) { st = ZH_ERR_INVALID_BUFFER; break; }  // inflate.nim:224-225
-        if (op + length > cap && !count_only) { st = ZH_ERR_DST_TOO_SMALL; break; }
-        if (!count_only) {
-          // inflate.nim:227-250: byte-sequential LZ77 copy semantics; an overlapping
-          // copy (dist < length) repeats the dist-byte pattern, so every lane can
-          // read its source from the already written region.
-          zh_wave_sync();
-          const bool overlap = dist < length;
-          for (uint32_t i = lane; i < length; i += 64) {
-            const uint32_t si = overlap ? i % dist : i;
-            const uint8_t v = s_win[(op - dist + si) & 32767u];
-            s_win[(op + i) & 32767u] = v;
-          }
-        }
-        op += length;
+        take(e & 15u);
       }
-      if (op - flushed >= 16384 + 512) flush(flushed + 16384);
+      const uint32_t kind = (e >> 8) & 3u;
+      if (kind == kKindLit) {
+        pend |= (uint64_t)(e >> 16) << (8 * npend);
+        if (++npend == 8) {
+          // literals decoded from beyond the end are caught at the next match / block end
+          if (past_end()) { st = ZH_ERR_END_OF_BUFFER; break; }
+          flush_pend();
+          if (st != ZH_OK) break;
+        }
+        continue;
+      }
+      if (past_end()) { st = ZH_ERR_END_OF_BUFFER; break; }
+      flush_pend();
+      if (st != ZH_OK) break;
+      if (kind == kKindEob) break;
+      if (kind == kKindBad) { st = ZH_ERR_INVALID_BUFFER; break; }  // inflate.nim:202-204
+      const uint32_t length = (e >> 16) + take((e >> 4) & 15u);
+      refill();
+      uint32_t de = zh_bcast(s_dst[(uint32_t)buf & ((1u << kDistBits) - 1u)]);
+      if (de == 0) {
+        const uint32_t dsym = decode_slow(kDistBits, &s_tab_dist, s_val_dist);
+        de = dist_entry(dsym, 0);
+      } else {
+        take(de & 15u);
+      }
+      if (((de >> 8) & 3u) == kKindBad) { st = ZH_ERR_INVALID_BUFFER; break; }  // inflate.nim:211-213
+      const uint32_t dist = (de >> 16) + take((de >> 4) & 15u);
+      if (dist > op) { st = ZH_ERR_INVALID_BUFFER; break; }  // inflate.nim:224-225
+      if (!count_only) {
+        // inflate.nim:227-250: byte-sequential LZ77 copy semantics; an overlapping copy
+        // (dist < length) repeats the dist-byte pattern, so every lane reads its source
+        // from the region that is already written.
+        zh_wave_sync();
+        if (dist >= length) {
+          for (uint32_t i = lane; i < length; i += 64)
+            s_win[(op + i) & 32767u] = s_win[(op - dist + i) & 32767u];
+        } else if (dist == 1) {
+          const uint8_t v = s_win[(op - 1) & 32767u];
+          for (uint32_t i = lane; i < length; i += 64) s_win[(op + i) & 32767u] = v;
+        } else {
+          for (uint32_t i = lane; i < length; i += 64)
+            s_win[(op + i) & 32767u] = s_win[(op - dist + i % dist) & 32767u];
+        }
+      }
+      op += length;
     }
   }
 
-  if (st == ZH_OK) flush(op);
+  if (st == ZH_OK) {
+    if (op > cap && !count_only) st = ZH_ERR_DST_TOO_SMALL;
+    else flush(op);
+  }
   if (lane == 0) {
     a.out_len[sid] = op;
     a.status[sid] = st;
