@@ -127,6 +127,8 @@ template <class T> inline T __shfl_xor(T v, int mask, int width = 64) {
   unsigned l = emu::lane_id();
   return emu_shfl_from(v, l ^ (unsigned)mask);
 }
+inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
@@ -162,6 +164,8 @@ inline void emu_amdgcn_wave_barrier() { uint64_t live; (void)emu::wave_exchange(
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(ptr, order, scope) (*(ptr))
 // atomics: fibers are cooperative, so plain read-modify-write is atomic
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = (T)(o + v); return o; }
 template <class T> inline T atomicSub(T* p, T v) { T o = *p; *p = (T)(o - v); return o; }

@@ -69,3 +69,12 @@ def test_emu_zlib_and_raw_need_sizing_pass(eng):
         co = zlib.compressobj(6, zlib.DEFLATED, wb)
         blob = co.compress(src) + co.flush()
         assert eng.uncompress(blob, fmt) == src
+
+
+def test_emu_level1_many_fragments(eng):
+    """Wider net for rare parse situations (hash collisions inside one probe step)."""
+    bufs = [b.tobytes() for b in synth.gen_batch("mix", 160, 65536, first_index=5000)]
+    outs, sts = eng.compress_batch(bufs, 1, oracle.dfDeflate)
+    assert all(s == 0 for s in sts)
+    for src, out in zip(bufs, outs):
+        assert out == oracle.deflate(src, 1)

@@ -6,8 +6,10 @@
 // (gzip header + trailer), inflate.nim:24-291 (Huffman tables, decode loop,
 // stored blocks) and the BitStreamReader of bitstreams.nim:22-82.
 //
-// Per wave, in LDS (39 KiB, 4 waves per CU): the 32 KiB output window as a ring
-// (LZ copies never touch HBM), a 10-bit literal/length LUT and an 8-bit distance
+// Per wave, in LDS (22 KiB, 7 waves per CU -- a wave alone on its SIMD issues one
+// instruction per ~4.4 cycles, so resident waves are what buys throughput): the last
+// 16 KiB of output as a ring (LZ copies that reach further back, a few percent, re-read
+// the already written-back output through L2), a 10-bit literal/length LUT and an 8-bit distance
 // LUT of self-describing 32-bit entries (inflate.nim's 9-bit `fast` table,
 // re-shaped), and the canonical slow-path arrays (firstCode / firstSymbol /
 // maxCodes / values, inflate.nim:14-19).  The compressed stream is held 512
@@ -27,6 +29,8 @@ __constant__ zh::DistTables c_dist = zh::make_dist_tables();
 __constant__ uint8_t c_clcl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 constexpr uint32_t kLitBits = 10, kDistBits = 8;
+constexpr uint32_t kRing = 16384;       // bytes of recent output kept in LDS
+constexpr uint32_t kFlushChunk = 4096;  // write-back granularity
 
 }  // namespace
 
@@ -114,6 +118,7 @@ __global__ void zh_unwrap_kernel(const uint8_t* __restrict__ d_src, ZhInflateArg
 //   bits 0-3   code length in bits (0 = not in this table: take the slow path)
 //   bits 4-7   number of extra bits that follow the code
 //   bits 8-9   kind: 0 literal, 1 length (or any distance), 2 end of block, 3 invalid symbol
+//   bit  15    set for literals (single-bit test on the hot path)
 //   bits 16-31 literal byte / base length / base distance
 // ---------------------------------------------------------------------------
 namespace {
@@ -127,7 +132,7 @@ struct HuffTab {
 };
 
 __device__ __forceinline__ uint32_t litlen_entry(uint32_t sym, uint32_t len) {
-  if (sym < 256) return len | (kKindLit << 8) | (sym << 16);
+  if (sym < 256) return len | (kKindLit << 8) | 0x8000u | (sym << 16);
   if (sym == 256) return len | (kKindEob << 8);
   if (sym < 286) {  // inflate.nim:199-209
     const uint32_t li = sym - 257;
@@ -212,7 +217,7 @@ __device__ int build_table(const uint8_t* lens, uint32_t n, uint32_t* lut, uint3
 __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restrict__ d_src,
                                                         uint8_t* __restrict__ d_dst,
                                                         ZhInflateArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[32768];
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kRing];
   __shared__ uint32_t s_lit[1u << kLitBits];
   __shared__ uint32_t s_dst[1u << kDistBits];  // also hosts the 7-bit code-length table
   __shared__ HuffTab s_tab_lit, s_tab_dist, s_tab_cl;
@@ -296,38 +301,45 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
 
   seek((uint64_t)mis + a.body_pos[sid]);
 
-  uint64_t op = 0, flushed = 0;
+  uint64_t op = 0;          // bytes produced (including the pending literals' predecessors)
+  uint32_t unflushed = 0;   // op - (bytes already written back to HBM)
   int st = ZH_OK;
-  uint64_t pend = 0;     // up to 8 decoded literals not yet stored in the window
-  uint32_t npend = 0;
+  uint64_t pend = 0;        // up to 8 decoded literals not yet stored in the ring
+  uint32_t psh = 0;         // 8 * number of pending literals
 
-  // write ring bytes [flushed, upto) back to HBM; upto - flushed <= 32768
-  auto flush = [&](uint64_t upto) {
+  // write the oldest `nbytes` unflushed ring bytes back to HBM (nbytes <= unflushed <= kRing)
+  auto flush = [&](uint32_t nbytes) {
     zh_wave_sync();
     if (!count_only) {
-      uint64_t p = flushed;
-      if (dst_al16) {
+      const uint64_t from = op - unflushed;
+      const uint64_t upto = from + nbytes;
+      uint64_t p = from;
+      if (dst_al16) {  // `from` is a multiple of kFlushChunk here (chunks go out whole)
         for (; p + 1024 <= upto; p += 1024) {
-          const uint64_t q = p + lane * 16u;  // flushed is always a multiple of 16 here
-          *reinterpret_cast<uint4*>(dst + q) = *reinterpret_cast<const uint4*>(&s_win[q & 32767u]);
+          const uint64_t q = p + lane * 16u;
+          *reinterpret_cast<uint4*>(dst + q) = *reinterpret_cast<const uint4*>(&s_win[q & (kRing - 1u)]);
         }
       }
-      for (uint64_t q = p + lane; q < upto; q += 64) dst[q] = s_win[q & 32767u];
+      for (uint64_t q = p + lane; q < upto; q += 64) dst[q] = s_win[q & (kRing - 1u)];
     }
-    flushed = upto;
+    unflushed -= nbytes;
     zh_wave_sync();
   };
-  // store the pending literals; every write-back to HBM is preceded by the capacity check
+  // store the pending literals in the ring; checks that are only needed now and then
+  // (end of input, slot capacity, write-back) ride along here
   auto flush_pend = [&]() {
+    const uint32_t npend = psh >> 3;
     if (npend) {
-      if (!count_only && lane < npend) s_win[(op + lane) & 32767u] = (uint8_t)(pend >> (8 * lane));
+      if (!count_only && lane < npend) s_win[(op + lane) & (kRing - 1u)] = (uint8_t)(pend >> (8 * lane));
       op += npend;
-      npend = 0;
+      unflushed += npend;
+      psh = 0;
       pend = 0;
     }
-    if (op - flushed >= 16384 + 1024) {
-      if (op > cap && !count_only) st = ZH_ERR_DST_TOO_SMALL;
-      else flush(flushed + 16384);
+    if (unflushed >= kFlushChunk + 2048) {
+      if (past_end()) st = ZH_ERR_END_OF_BUFFER;
+      else if (op > cap && !count_only) st = ZH_ERR_DST_TOO_SMALL;
+      else flush(kFlushChunk);
     }
   };
 
@@ -347,13 +359,14 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
       if (op + len > cap && !count_only) { st = ZH_ERR_DST_TOO_SMALL; break; }
       const uint8_t* raw = reinterpret_cast<const uint8_t*>(asrc) + byte_pos;
       for (uint32_t done = 0; done < len;) {
-        const uint32_t n = len - done < 8192u ? len - done : 8192u;
+        const uint32_t n = len - done < kFlushChunk ? len - done : kFlushChunk;
         zh_wave_sync();
         if (!count_only)
-          for (uint32_t i = lane; i < n; i += 64) s_win[(op + i) & 32767u] = raw[done + i];
+          for (uint32_t i = lane; i < n; i += 64) s_win[(op + i) & (kRing - 1u)] = raw[done + i];
         op += n;
+        unflushed += n;
         done += n;
-        if (op - flushed >= 16384) flush(flushed + 16384);
+        if (unflushed >= kFlushChunk + 2048) flush(kFlushChunk);
       }
       seek(byte_pos + len);
       continue;
@@ -428,26 +441,38 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
     for (;;) {  // inflate.nim:173-250
       refill();
       uint32_t e = zh_bcast(s_lit[(uint32_t)buf & ((1u << kLitBits) - 1u)]);
-      if (e == 0) {  // longer than the LUT, or unassigned
-        const uint32_t sym = decode_slow(kLitBits, &s_tab_lit, s_val_lit);
-        e = litlen_entry(sym, 0);
-      } else {
-        take(e & 15u);
-      }
-      const uint32_t kind = (e >> 8) & 3u;
-      if (kind == kKindLit) {
-        pend |= (uint64_t)(e >> 16) << (8 * npend);
-        if (++npend == 8) {
-          // literals decoded from beyond the end are caught at the next match / block end
-          if (past_end()) { st = ZH_ERR_END_OF_BUFFER; break; }
+      if (e & 0x8000u) {  // literal straight out of the LUT: the hot path
+        const uint32_t nb = e & 15u;
+        buf >>= nb;
+        cnt -= (int32_t)nb;
+        pend |= (uint64_t)(e >> 16) << psh;
+        psh += 8;
+        if (psh == 64) {
           flush_pend();
           if (st != ZH_OK) break;
         }
         continue;
       }
+      if (e == 0) {  // longer than the LUT, or unassigned
+        const uint32_t sym = decode_slow(kLitBits, &s_tab_lit, s_val_lit);
+        e = litlen_entry(sym, 0);
+        if (e & 0x8000u) {
+          pend |= (uint64_t)(e >> 16) << psh;
+          psh += 8;
+          if (psh == 64) {
+            flush_pend();
+            if (st != ZH_OK) break;
+          }
+          continue;
+        }
+      } else {
+        take(e & 15u);
+      }
+      // literals decoded from beyond the end of the input are caught here at the latest
       if (past_end()) { st = ZH_ERR_END_OF_BUFFER; break; }
       flush_pend();
       if (st != ZH_OK) break;
+      const uint32_t kind = (e >> 8) & 3u;
       if (kind == kKindEob) break;
       if (kind == kKindBad) { st = ZH_ERR_INVALID_BUFFER; break; }  // inflate.nim:202-204
       const uint32_t length = (e >> 16) + take((e >> 4) & 15u);
@@ -467,24 +492,45 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
         // (dist < length) repeats the dist-byte pattern, so every lane reads its source
         // from the region that is already written.
         zh_wave_sync();
-        if (dist >= length) {
+        if (dist > kRing) {
+          // source older than the ring: it was written back at least kRing - kFlushChunk -
+          // 2048 - 258 bytes ago.  Wait for those stores, then read through L2 (this CU's
+          // L1 may hold a stale copy of a partially written line).
+          if (op + length > cap) { st = ZH_ERR_DST_TOO_SMALL; break; }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           for (uint32_t i = lane; i < length; i += 64)
-            s_win[(op + i) & 32767u] = s_win[(op - dist + i) & 32767u];
+            s_win[(op + i) & (kRing - 1u)] =
+                __hip_atomic_load(dst + (op - dist + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (dist + length > kRing) {
+          // the destination wraps onto the source's ring slots: each 64-byte group must be
+          // read before the next group is written (program order on the GPU; the explicit
+          // syncs keep the CPU emulator, whose lanes are not in lockstep, honest)
+          for (uint32_t base = 0; base < length; base += 64) {
+            const uint32_t i = base + lane;
+            const uint8_t v = s_win[(op - dist + i) & (kRing - 1u)];
+            zh_wave_sync();
+            if (i < length) s_win[(op + i) & (kRing - 1u)] = v;
+            zh_wave_sync();
+          }
+        } else if (dist >= length) {
+          for (uint32_t i = lane; i < length; i += 64)
+            s_win[(op + i) & (kRing - 1u)] = s_win[(op - dist + i) & (kRing - 1u)];
         } else if (dist == 1) {
-          const uint8_t v = s_win[(op - 1) & 32767u];
-          for (uint32_t i = lane; i < length; i += 64) s_win[(op + i) & 32767u] = v;
+          const uint8_t v = s_win[(op - 1) & (kRing - 1u)];
+          for (uint32_t i = lane; i < length; i += 64) s_win[(op + i) & (kRing - 1u)] = v;
         } else {
           for (uint32_t i = lane; i < length; i += 64)
-            s_win[(op + i) & 32767u] = s_win[(op - dist + i % dist) & 32767u];
+            s_win[(op + i) & (kRing - 1u)] = s_win[(op - dist + i % dist) & (kRing - 1u)];
         }
       }
       op += length;
+      unflushed += length;
     }
   }
 
   if (st == ZH_OK) {
     if (op > cap && !count_only) st = ZH_ERR_DST_TOO_SMALL;
-    else flush(op);
+    else flush(unflushed);
   }
   if (lane == 0) {
     a.out_len[sid] = op;

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
   __shared__ uint32_t s_cover[ZH_FRAG_SIZE / 32];  // bit p set: byte p lies inside a match
   __shared__ uint32_t s_nmatch;
-  __shared__ uint32_t s_scr[128];  // per-step hash collision counters
+  __shared__ uint32_t s_scr[1024];  // per-step hash collision counters
 
   const unsigned lane = zh_lane();
   const uint32_t f = blockIdx.x;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
     }
     for (uint32_t i = lane; i < ZH_HIST_STRIDE; i += 64) s_hist[i] = 0;
     for (uint32_t i = lane; i < ZH_FRAG_SIZE / 32; i += 64) s_cover[i] = 0;
-    for (uint32_t i = lane; i < 128; i += 64) s_scr[i] = 0;
+    for (uint32_t i = lane; i < 1024; i += 64) s_scr[i] = 0;
   }
 
   uint32_t table_size = 256, shift = 24;  // snappy.nim:24-29
@@ -81,95 +81,156 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   // table[h] = p; hit iff load32(p) == load32(cand) (snappy.nim:86-101).  Here the 64
   // lanes take the next 64 probe positions of the skip-ahead schedule at once and the
   // first hit in probe order is found with ballots.  A lane's candidate must reflect
-  // the table inserts of the EARLIER probes of the same step; lanes whose hash
-  // collides with another lane of the step (detected with 128 LDS counters) are
-  // resolved one by one in probe order, everything else in parallel.  Only the probes
-  // up to the first hit insert into the table, so the table evolves exactly as in the
-  // serial walk and the parse is identical.
+  // the table inserts of the EARLIER probes of the same step: lanes whose hash equals
+  // an earlier lane's are resolved one by one in probe order, everything else in
+  // parallel.  Only the probes up to the first hit insert into the table, so the table
+  // evolves exactly as in the serial walk and the parse is identical.
+  //
+  // A wave alone on its SIMD issues ~1 instruction per 4-5 cycles and an LDS round trip
+  // costs ~125 cycles, so the step is built to need three dependent round trips (source
+  // bytes, table, candidate bytes): the insert of ip-1 that follows a match rides along
+  // as lane 0 of the next step, and every lane compares 16 bytes against its candidate so
+  // that matches shorter than 16 need no further read.
   if (!serial_parse) {
     uint32_t nm = 0;
+    uint32_t rp = 0, rl = 0, ro = 0;  // match list staging: lane (nm & 63) holds match nm
     if (!huffman_only && n >= 15) {
       const uint32_t ip_limit = n - 15;
+      // lane roles of a step that follows a match (snappy.nim:116-131): lane 0 inserts
+      // ip-1, lane 1 re-probes ip, lane j >= 2 is probe j-2 of the run that starts at ip+1
+      uint32_t post_off, post_step;
+      {
+        const uint32_t j = lane - 2;
+        post_off = lane == 0 ? 0xffffffffu : lane == 1 ? 0u : 1u + j + (j > 32u ? j - 32u : 0u);
+        post_step = lane < 2 ? 0u : (32u + j) >> 5;
+      }
       uint32_t ip = 1;     // position of the next probe (post: position right after a match)
       uint32_t K = 0;      // probes already done in this literal run (skip = 32 + K)
-      bool post = false;   // the step starts with the re-probe that follows a match
+      bool post = false;
       for (;;) {
-        // probe positions of this step (closed form of skip>>5 steps, snappy.nim:88-92)
-        uint32_t j = lane, s = 32 + K, base = ip;
-        bool valid = true;
-        if (post) {  // snappy.nim:116-131: insert ip-1, then probe ip, then the normal run from ip+1
-          if (lane == 0) s_table[(zh_ld32(s_src, ip - 1) * kHashMul) >> shift] = (uint16_t)(ip - 1);
-          s = 32;
-          base = ip + 1;
-          j = lane - 1;  // lane 0 is the re-probe at ip itself
-        }
         uint32_t pos, step;
-        if (post && lane == 0) {
-          pos = ip;
-          step = 1;
-        } else {
-          const uint32_t q = s >> 5, r = s & 31u;
+        if (post) {
+          pos = ip + post_off;
+          step = post_step;
+        } else {  // closed form of the skip>>5 schedule, snappy.nim:88-92
+          const uint32_t s = 32 + K, q = s >> 5, r = s & 31u, j = lane;
           uint32_t off = q * j;
           if (j > 32u - r) off += j - (32u - r);
           if (j > 64u - r) off += j - (64u - r);
-          pos = base + off;
+          pos = ip + off;
           step = (s + j) >> 5;
-          valid = pos + step <= ip_limit;
         }
+        const bool valid = pos + step <= ip_limit;  // lanes 0/1 of a post step: step 0, ip < ip_limit
         if (!valid) pos = 1;  // keep LDS reads in range; the lane is ignored
-        zh_wave_sync();
-        const uint32_t v = zh_ld32(s_src, pos);
-        const uint32_t h = (v * kHashMul) >> shift;
+        // round trip 1: 16 source bytes at pos (five aligned dwords)
+        const uint32_t pw = pos >> 2;
+        const uint32_t p0 = s_src[pw], p1 = s_src[pw + 1], p2 = s_src[pw + 2], p3 = s_src[pw + 3],
+                       p4 = s_src[pw + 4];
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(p1, p0, pos);
+        const uint32_t h = (a0 * kHashMul) >> shift;
+        // round trip 2: the table; the first 16 probes also tick a duplicate-hash counter
+        // (answer read back together with the candidate bytes, so no extra round trip)
+        const bool counted = valid && lane < 16;
         const uint32_t old = s_table[h];
-        const bool hit_old = valid && zh_ld32(s_src, old) == v;
-        if (valid) atomicAdd(&s_scr[h & 127u], 1u);
+        if (counted) atomicAdd(&s_scr[h & 1023u], 1u);
+        zh_wave_sync();  // (orders the counter traffic between lanes; emits nothing)
+        const uint32_t a1 = __builtin_amdgcn_alignbyte(p2, p1, pos);
+        const uint32_t a2 = __builtin_amdgcn_alignbyte(p3, p2, pos);
+        const uint32_t a3 = __builtin_amdgcn_alignbyte(p4, p3, pos);
+        // round trip 3: 16 bytes at the candidate the table held when the step began
+        const uint32_t ow = old >> 2;
+        const uint32_t q0 = s_src[ow], q1 = s_src[ow + 1], q2 = s_src[ow + 2], q3 = s_src[ow + 3],
+                       q4 = s_src[ow + 4];
+        const uint32_t cnt16 = counted ? s_scr[h & 1023u] : 0u;
         zh_wave_sync();
-        const bool collide = valid && s_scr[h & 127u] > 1u;
-        zh_wave_sync();
-        if (valid) s_scr[h & 127u] = 0;
+        if (counted) s_scr[h & 1023u] = 0;
+        const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(q1, q0, old);
+        const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(q2, q1, old);
+        const uint32_t x2 = a2 ^ __builtin_amdgcn_alignbyte(q3, q2, old);
+        const uint32_t x3 = a3 ^ __builtin_amdgcn_alignbyte(q4, q3, old);
+        // equal leading bytes 0..16, branch-free: ffs(0) - 1 = 0xffffffff -> min(.., 4) = 4
+        const uint32_t c0 = min(((uint32_t)__ffs((int)x0) - 1u) >> 3, 4u);
+        const uint32_t c1 = min(((uint32_t)__ffs((int)x1) - 1u) >> 3, 4u);
+        const uint32_t c2 = min(((uint32_t)__ffs((int)x2) - 1u) >> 3, 4u);
+        const uint32_t c3 = min(((uint32_t)__ffs((int)x3) - 1u) >> 3, 4u);
+        const uint32_t c23 = c2 + (c2 == 4u ? c3 : 0u);
+        const uint32_t c123 = c1 + (c1 == 4u ? c23 : 0u);
+        const uint32_t eqlen = c0 + (c0 == 4u ? c123 : 0u);
+        const bool hit_old = valid && x0 == 0 && !(post && lane == 0);
+
         const uint64_t V = __ballot(valid);
         const uint64_t H = __ballot(hit_old);
-        const uint64_t C = __ballot(collide);
         const uint32_t t = V == ~0ull ? 64u : (uint32_t)__ffsll((long long)~V) - 1u;  // first probe past ip_limit
-        const uint64_t clean_hits = H & ~C;
-        const uint32_t g = clean_hits ? (uint32_t)__ffsll((long long)clean_hits) - 1u : 64u;
-        const uint32_t bound = g < t ? g : t;
-        uint32_t f = 64, cand = 0;  // first hit in probe order and its candidate
-        {
+        const uint32_t g0 = H ? (uint32_t)__ffsll((long long)H) - 1u : 64u;
+        // lanes whose inserts can happen in this step: up to the first hit, or up to the limit
+        const uint32_t span = g0 < t ? g0 + 1 : t;
+        // C: superset of the lanes (below span) that share their hash with another lane
+        uint64_t C;
+        bool c_full = false;  // C covers every valid lane, not only those below span
+        if (span <= 16) {
+          C = __ballot(cnt16 > 1u) & ((1ull << span) - 1ull);
+        } else {
+          zh_wave_sync();
+          if (valid) atomicAdd(&s_scr[h & 1023u], 1u);
+          zh_wave_sync();
+          const bool coll = valid && s_scr[h & 1023u] > 1u;
+          zh_wave_sync();
+          if (valid) s_scr[h & 1023u] = 0;
+          C = __ballot(coll);
+          c_full = true;
+        }
+        uint32_t f = g0 < t ? g0 : 64u, cand_lane_old = f;  // first hit in probe order
+        uint32_t cand = 0, flen = 0;
+        bool cand_in_step = false;
+        if (C) {
+          if (!c_full && g0 < 64 && ((C >> g0) & 1ull)) {
+            // the first apparent hit may be void (an earlier probe of the step re-used its
+            // table slot): later lanes come into play, so classify all of them
+            zh_wave_sync();
+            if (valid) atomicAdd(&s_scr[h & 1023u], 1u);
+            zh_wave_sync();
+            const bool coll = valid && s_scr[h & 1023u] > 1u;
+            zh_wave_sync();
+            if (valid) s_scr[h & 1023u] = 0;
+            C = __ballot(coll);
+          }
+          // exact resolution of the colliding probes before the first clean event
+          const uint64_t clean_hits = H & ~C;
+          const uint32_t g = clean_hits ? (uint32_t)__ffsll((long long)clean_hits) - 1u : 64u;
+          const uint32_t bound = g < t ? g : t;
           uint64_t cb = bound >= 64 ? C : (C & ((1ull << bound) - 1ull));
-          while (cb) {  // colliding probes before the first clean event, in order
+          f = 64;
+          while (cb) {
             const uint32_t jx = (uint32_t)__ffsll((long long)cb) - 1u;
             cb &= cb - 1;
+            if (post && jx == 0) continue;  // the insert-only lane never hits
             const uint32_t hj = __builtin_amdgcn_readlane(h, jx);
             const uint64_t same = __ballot(valid && h == hj) & ((1ull << jx) - 1ull);
-            bool hitj;
-            uint32_t candj;
             if (same) {  // an earlier probe of this step inserted this hash last
               const uint32_t i = 63u - (uint32_t)__clzll((long long)same);
-              hitj = __builtin_amdgcn_readlane(v, i) == __builtin_amdgcn_readlane(v, jx);
-              candj = __builtin_amdgcn_readlane(pos, i);
-            } else {
-              hitj = (H >> jx) & 1ull;
-              candj = __builtin_amdgcn_readlane(old, jx);
-            }
-            if (hitj) {
+              if (__builtin_amdgcn_readlane(a0, i) == __builtin_amdgcn_readlane(a0, jx)) {
+                f = jx;
+                cand = __builtin_amdgcn_readlane(pos, i);
+                cand_in_step = true;
+                break;
+              }
+            } else if ((H >> jx) & 1ull) {
               f = jx;
-              cand = candj;
+              cand_lane_old = jx;
               break;
             }
           }
           if (f == 64 && g < t) {
             f = g;
-            cand = __builtin_amdgcn_readlane(old, g);
+            cand_lane_old = g;
           }
         }
-        // table inserts of the probes that really happened: up to the hit, or up to the limit
+        // table inserts of the probes that really happened
         const uint32_t last_plus1 = f < 64 ? f + 1 : t;
-        const bool commit = lane < last_plus1;
-        if (commit && !collide) s_table[h] = (uint16_t)pos;
-        {
+        if (lane < last_plus1 && !((C >> lane) & 1ull)) s_table[h] = (uint16_t)pos;
+        if (C) {
           uint64_t cc = last_plus1 >= 64 ? C : (C & ((1ull << last_plus1) - 1ull));
-          while (cc) {  // same-bucket probes write in probe order (the later one wins)
+          while (cc) {  // same-hash probes write in probe order (the later one wins)
             const uint32_t jx = (uint32_t)__ffsll((long long)cc) - 1u;
             cc &= cc - 1;
             if (lane == jx) s_table[h] = (uint16_t)pos;
@@ -177,24 +238,42 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         }
         if (f < 64) {
           const uint32_t mp = __builtin_amdgcn_readlane(pos, f);
-          // 4 + determineMatchLength(cand + 4, mp + 4, limit), internal.nim:251-270:
-          // lane l compares bytes 4+4l .. 7+4l (64 lanes cover the 258-byte maximum)
           const uint32_t limit = n < mp + 258u ? n : mp + 258u;
-          const uint32_t o = 4u + 4u * lane;
-          uint32_t avail = 0;
-          if (mp + o < limit) avail = limit - (mp + o) < 4u ? limit - (mp + o) : 4u;
-          const uint32_t x = zh_ld32(s_src, mp + o) ^ zh_ld32(s_src, cand + o);
-          uint32_t eq = x ? ((uint32_t)__ffs((int)x) - 1u) >> 3 : 4u;
-          if (eq > avail) eq = avail;
-          const uint64_t stop = __ballot(eq < 4u);  // lane 63 always stops (limit <= mp + 258)
-          const uint32_t fl = (uint32_t)__ffsll((long long)stop) - 1u;
-          const uint32_t matched = 4u + 4u * fl + __builtin_amdgcn_readlane(eq, fl);
-          if (lane == 0) {
-            m_pos[nm] = (uint16_t)mp;
-            m_len[nm] = (uint16_t)matched;
-            m_off[nm] = (uint16_t)(mp - cand);
+          uint32_t matched;
+          if (!cand_in_step) {
+            cand = __builtin_amdgcn_readlane(old, cand_lane_old);
+            flen = __builtin_amdgcn_readlane(eqlen, f);
+          } else {
+            flen = 4;  // only the first four bytes are known to match
+          }
+          if (flen < 16u && !cand_in_step) {
+            matched = flen;
+          } else {
+            // 4 + determineMatchLength(cand + 4, mp + 4, limit), internal.nim:251-270:
+            // lane l compares bytes flen+4l .. flen+3+4l against the candidate
+            zh_wave_sync();
+            const uint32_t o = flen + 4u * lane;
+            uint32_t avail = 0;
+            if (mp + o < limit) avail = limit - (mp + o) < 4u ? limit - (mp + o) : 4u;
+            const uint32_t x = zh_ld32(s_src, mp + o) ^ zh_ld32(s_src, cand + o);
+            uint32_t eq = min(((uint32_t)__ffs((int)x) - 1u) >> 3, 4u);
+            if (eq > avail) eq = avail;
+            const uint64_t stop = __ballot(eq < 4u);  // some lane always stops (limit <= mp + 258)
+            const uint32_t fl = (uint32_t)__ffsll((long long)stop) - 1u;
+            matched = flen + 4u * fl + __builtin_amdgcn_readlane(eq, fl);
+          }
+          if (matched > limit - mp) matched = limit - mp;
+          if (lane == (nm & 63u)) {
+            rp = mp;
+            rl = matched;
+            ro = mp - cand;
           }
           nm++;
+          if ((nm & 63u) == 0) {  // 64 staged matches -> one coalesced store per array
+            m_pos[nm - 64 + lane] = (uint16_t)rp;
+            m_len[nm - 64 + lane] = (uint16_t)rl;
+            m_off[nm - 64 + lane] = (uint16_t)ro;
+          }
           ip = mp + matched;
           if (ip >= ip_limit) break;  // snappy.nim:118-120
           post = true;
@@ -204,10 +283,16 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         if (t < 64) break;  // snappy.nim:93-95: the rest of the fragment is literals
         // 64 probes without a hit: continue the same literal run
         const uint32_t p63 = __builtin_amdgcn_readlane(pos, 63), s63 = __builtin_amdgcn_readlane(step, 63);
-        K = post ? 63 : K + 64;
+        K = post ? 62 : K + 64;
         post = false;
         ip = p63 + s63;
       }
+    }
+    if (lane < (nm & 63u)) {
+      const uint32_t b = nm & ~63u;
+      m_pos[b + lane] = (uint16_t)rp;
+      m_len[b + lane] = (uint16_t)rl;
+      m_off[b + lane] = (uint16_t)ro;
     }
     if (lane == 0) s_nmatch = nm;
   }
