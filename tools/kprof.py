@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Tuning aid (GPU box only): runs the BestSpeed compress + uncompress plans of bench.py on
+the -DZH_KPROF build (python -m zippy_amd.build --kprof) and prints the in-kernel phase
+timers (csrc/zh_kprof.h) as cycles per wave.
+
+    python tools/kprof.py [--buffers 1024] [--size 1048576] [--kind mix]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+L1 = ["stage-in", "step: vector part", "step: fast walk", "step: slow walk", "step: table inserts",
+      "stats phase", "#steps", "#fast steps", "#events fast", "#events slow", "#match extensions",
+      "#waves", "#refine iterations"]
+INF = ["setup+tables", "decode loop", "copies", "flush", "other", "#symbols", "#matches",
+       "#rounds", "#far copies", "#waves"]
+
+
+def show(title, names, vals):
+    waves = max(1, vals[names.index("#waves")])
+    print("== %s (%d waves)" % (title, waves))
+    cyc = sum(v for n, v in zip(names, vals) if not n.startswith("#"))
+    for n, v in zip(names, vals):
+        if n.startswith("#"):
+            print("  %-22s %12.1f per wave" % (n, v / waves))
+        else:
+            print("  %-22s %12.0f cycles per wave  (%5.1f %%)" % (n, v / waves, 100.0 * v / max(cyc, 1)))
+    print("  %-22s %12.0f cycles per wave" % ("total", cyc / waves))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--buffers", type=int, default=1024)
+    ap.add_argument("--size", type=int, default=1 << 20)
+    ap.add_argument("--kind", default="mix")
+    args = ap.parse_args()
+    import torch
+    from zippy_amd import api, synth
+    from zippy_amd._binding import Engine
+    lib_path = api.LIB_PATH.replace(".so", "_kprof.so")
+    n, size = args.buffers, args.size
+    host = synth.gen_batch(args.kind, n, size)
+    d_src = torch.from_numpy(host.reshape(-1)).cuda()
+    eng = Engine(lib_path, stream=torch.cuda.current_stream().cuda_stream)
+    eng.set_gzip_fname_len(0)
+    eng.lib.zh_kprof_read.restype = ctypes.c_int
+    eng.lib.zh_kprof_read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    cap = size + size // 8 + 2048
+    slot = (cap + 255) & ~255
+    d_comp = torch.empty(n * slot, dtype=torch.uint8, device="cuda")
+    d_back = torch.empty(n * size, dtype=torch.uint8, device="cuda")
+    src_off = [i * size for i in range(n)]
+    comp_off = [i * slot for i in range(n)]
+    cplan = eng.plan_compress(src_off, [size] * n, comp_off, [cap] * n, 1, api.dfGzip)
+    uplan = eng.plan_uncompress(comp_off, [cap] * n, src_off, [size] * n, api.dfGzip)
+    uplan.set_src_lens_device(cplan.device_lens())
+    cplan.set_profiling(True)
+    uplan.set_profiling(True)
+    for it in range(2):
+        eng.lib.zh_kprof_read(None, 1)
+        cplan.run(d_src.data_ptr(), d_comp.data_ptr())
+        uplan.run(d_comp.data_ptr(), d_back.data_ptr())
+        torch.cuda.synchronize()
+    assert torch.equal(d_back, d_src)
+    slots = (ctypes.c_ulonglong * 64)()
+    eng.lib.zh_kprof_read(slots, 0)
+    print("kernel ms:", {k: round(v, 3) for k, v in cplan.kernel_times() + uplan.kernel_times()})
+    show("zh_l1_match_kernel", L1, list(slots[0:13]))
+    show("zh_inflate_kernel", INF, list(slots[16:26]))
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,7 @@ OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libzippy_hip.so")
 SOURCES = ["zh_api.hip", "zh_checksum.hip", "zh_inflate.hip", "zh_l1_match.hip",
            "zh_chain_match.hip", "zh_huffman.hip", "zh_emit.hip"]
-HEADERS = ["zh_common.h", "zh_tables.h", os.path.join("..", "..", "include", "zippy_hip.h")]
+HEADERS = ["zh_common.h", "zh_tables.h", "zh_kprof.h", os.path.join("..", "..", "include", "zippy_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=default",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
@@ -29,17 +29,22 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJDIR, exist_ok=True)
+def build(force=False, verbose=False, kprof=False):
+    """kprof=True builds the tuning variant libzippy_hip_kprof.so (-DZH_KPROF: in-kernel
+    phase timers, csrc/zh_kprof.h); the product library never carries them."""
+    objdir = OBJDIR + ("_kprof" if kprof else "")
+    lib = LIB.replace(".so", "_kprof.so") if kprof else LIB
+    flags = FLAGS + (["-DZH_KPROF", "-fgpu-rdc"] if kprof else [])
+    os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + flags + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -52,10 +57,11 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _newer(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if jobs or force or _newer(lib, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + (["-fgpu-rdc"] if kprof else []) +
+            ["-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, kprof="--kprof" in sys.argv))

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "zh_common.h"
+#include "zh_kprof.h"
 #include "zh_tables.h"
 
 // ---- kernel launchers (defined next to their kernels) ----
@@ -895,3 +896,18 @@ extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int lev
   memcpy(*tokens, out.data(), out.size() * 2);
   return ZH_OK;
 }
+
+#ifdef ZH_KPROF
+// tuning builds only (zh_kprof.h): phase timers summed by the kernels
+__device__ unsigned long long zh_kprof_slots[ZH_KPROF_SLOTS];
+extern "C" int zh_kprof_read(unsigned long long* out, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return ZH_ERR_DEVICE;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(zh_kprof_slots), sizeof(zh_kprof_slots)) != hipSuccess)
+    return ZH_ERR_DEVICE;
+  if (reset) {
+    static const unsigned long long zeros[ZH_KPROF_SLOTS] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(zh_kprof_slots), zeros, sizeof(zeros)) != hipSuccess) return ZH_ERR_DEVICE;
+  }
+  return ZH_OK;
+}
+#endif

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "zh_common.h"
+#include "zh_kprof.h"
 #include "zh_tables.h"
 
 namespace {
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   __shared__ uint32_t s_scr[1024];  // per-step hash collision counters
 
   const unsigned lane = zh_lane();
+  KPROF_DECL(13);  // cycles: 0 stage-in, 1 vector part, 2 fast walk, 3 slow walk, 4 inserts, 5 stats; counts: 6..12
   const uint32_t f = blockIdx.x;
   const ZhFragDesc fd = a.frags[f];
   const uint32_t n = fd.len;
@@ -75,43 +77,47 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   if (!huffman_only)
     for (uint32_t i = lane; i < table_size / 2; i += 64) reinterpret_cast<uint32_t*>(s_table)[i] = 0;
   zh_wave_sync();
+  KPROF_MARK(0);
 
   // ---- greedy parse, wave-parallel (default) ----
   // The reference probes one position at a time: h = hash(load32(p)); cand = table[h];
-  // table[h] = p; hit iff load32(p) == load32(cand) (snappy.nim:86-101).  Here the 64
-  // lanes take the next 64 probe positions of the skip-ahead schedule at once and the
-  // first hit in probe order is found with ballots.  A lane's candidate must reflect
-  // the table inserts of the EARLIER probes of the same step: lanes whose hash equals
-  // an earlier lane's are resolved one by one in probe order, everything else in
-  // parallel.  Only the probes up to the first hit insert into the table, so the table
-  // evolves exactly as in the serial walk and the parse is identical.
+  // table[h] = p; hit iff load32(p) == load32(cand) (snappy.nim:86-101), and after a
+  // match it inserts ip-1, re-probes ip and restarts the skip schedule (snappy.nim:108-131).
   //
-  // A wave alone on its SIMD issues ~1 instruction per 4-5 cycles and an LDS round trip
-  // costs ~125 cycles, so the step is built to need three dependent round trips (source
-  // bytes, table, candidate bytes): the insert of ip-1 that follows a match rides along
-  // as lane 0 of the next step, and every lane compares 16 bytes against its candidate so
-  // that matches shorter than 16 need no further read.
+  // A step lays the 64 lanes over upcoming probe positions and does the parse-independent
+  // work for all of them at once in three dependent LDS round trips: 16 source bytes and
+  // the hash, the table slot (`old`, the candidate if no probe of this step re-uses the
+  // slot first), the 16 candidate bytes and their common prefix length.  A wave-uniform
+  // walk (scalar registers: ballots, s_ff1, v_readlane) then replays the reference's
+  // decisions over those lanes in probe order.
+  //   dense step  (fewer than 32 probes into the literal run, the usual case): the lanes
+  //     are 64 CONSECUTIVE positions, so the walk can carry on behind a match -- mark
+  //     ip-1 inserted, re-probe ip, restart the run -- and typically retires several
+  //     matches per step;
+  //   sparse step (>= 32 misses in a row: the reference probes every 2nd, 3rd ... byte,
+  //     snappy.nim:88-92): the lanes are the next 64 positions of that schedule in closed
+  //     form; the step ends at its first match.
+  // A lane's true candidate is the last position inserted before it with the same hash:
+  // a lane of this step if one shares its hash and was really inserted (tracked in the
+  // `ins` mask; lanes that share a table slot are flagged through an LDS counter and
+  // resolved exactly, one by one), else `old`.  Only the lanes the reference would have
+  // probed or inserted write the table, in probe order, so the table evolves exactly as
+  // in the serial walk and the match list equals the reference's token stream.
   if (!serial_parse) {
     uint32_t nm = 0;
-    uint32_t rp = 0, rl = 0, ro = 0;  // match list staging: lane (nm & 63) holds match nm
     if (!huffman_only && n >= 15) {
       const uint32_t ip_limit = n - 15;
-      // lane roles of a step that follows a match (snappy.nim:116-131): lane 0 inserts
-      // ip-1, lane 1 re-probes ip, lane j >= 2 is probe j-2 of the run that starts at ip+1
-      uint32_t post_off, post_step;
-      {
-        const uint32_t j = lane - 2;
-        post_off = lane == 0 ? 0xffffffffu : lane == 1 ? 0u : 1u + j + (j > 32u ? j - 32u : 0u);
-        post_step = lane < 2 ? 0u : (32u + j) >> 5;
-      }
       uint32_t ip = 1;     // position of the next probe (post: position right after a match)
       uint32_t K = 0;      // probes already done in this literal run (skip = 32 + K)
-      bool post = false;
-      for (;;) {
-        uint32_t pos, step;
-        if (post) {
-          pos = ip + post_off;
-          step = post_step;
+      bool post = false;   // a match has just ended at ip: insert ip-1, then re-probe ip
+      bool finished = false;
+      while (!finished) {
+        const bool dense = post || K < 32u;
+        uint32_t pos, step, W0 = 0;
+        if (dense) {
+          W0 = post ? ip - 1u : ip;
+          pos = W0 + lane;
+          step = 1;
         } else {  // closed form of the skip>>5 schedule, snappy.nim:88-92
           const uint32_t s = 32 + K, q = s >> 5, r = s & 31u, j = lane;
           uint32_t off = q * j;
@@ -120,19 +126,18 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
           pos = ip + off;
           step = (s + j) >> 5;
         }
-        const bool valid = pos + step <= ip_limit;  // lanes 0/1 of a post step: step 0, ip < ip_limit
-        if (!valid) pos = 1;  // keep LDS reads in range; the lane is ignored
+        const bool valid = pos + step <= ip_limit;  // the reference's `nextIp > ipLimit` test
+        if (!valid) pos = 1;  // keep LDS reads in range; the lane is never walked
         // round trip 1: 16 source bytes at pos (five aligned dwords)
         const uint32_t pw = pos >> 2;
         const uint32_t p0 = s_src[pw], p1 = s_src[pw + 1], p2 = s_src[pw + 2], p3 = s_src[pw + 3],
                        p4 = s_src[pw + 4];
         const uint32_t a0 = __builtin_amdgcn_alignbyte(p1, p0, pos);
         const uint32_t h = (a0 * kHashMul) >> shift;
-        // round trip 2: the table; the first 16 probes also tick a duplicate-hash counter
-        // (answer read back together with the candidate bytes, so no extra round trip)
-        const bool counted = valid && lane < 16;
+        // round trip 2: the table slot; every lane also ticks a counter of its (folded) hash,
+        // read back together with the candidate bytes
         const uint32_t old = s_table[h];
-        if (counted) atomicAdd(&s_scr[h & 1023u], 1u);
+        if (valid) atomicAdd(&s_scr[h & 1023u], 1u);
         zh_wave_sync();  // (orders the counter traffic between lanes; emits nothing)
         const uint32_t a1 = __builtin_amdgcn_alignbyte(p2, p1, pos);
         const uint32_t a2 = __builtin_amdgcn_alignbyte(p3, p2, pos);
@@ -141,9 +146,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         const uint32_t ow = old >> 2;
         const uint32_t q0 = s_src[ow], q1 = s_src[ow + 1], q2 = s_src[ow + 2], q3 = s_src[ow + 3],
                        q4 = s_src[ow + 4];
-        const uint32_t cnt16 = counted ? s_scr[h & 1023u] : 0u;
+        const uint32_t cnt = valid ? s_scr[h & 1023u] : 0u;
         zh_wave_sync();
-        if (counted) s_scr[h & 1023u] = 0;
+        if (valid) s_scr[h & 1023u] = 0;
         const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(q1, q0, old);
         const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(q2, q1, old);
         const uint32_t x2 = a2 ^ __builtin_amdgcn_alignbyte(q3, q2, old);
@@ -156,101 +161,171 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         const uint32_t c23 = c2 + (c2 == 4u ? c3 : 0u);
         const uint32_t c123 = c1 + (c1 == 4u ? c23 : 0u);
         const uint32_t eqlen = c0 + (c0 == 4u ? c123 : 0u);
-        const bool hit_old = valid && x0 == 0 && !(post && lane == 0);
 
-        const uint64_t V = __ballot(valid);
-        const uint64_t H = __ballot(hit_old);
-        const uint32_t t = V == ~0ull ? 64u : (uint32_t)__ffsll((long long)~V) - 1u;  // first probe past ip_limit
-        const uint32_t g0 = H ? (uint32_t)__ffsll((long long)H) - 1u : 64u;
-        // lanes whose inserts can happen in this step: up to the first hit, or up to the limit
-        const uint32_t span = g0 < t ? g0 + 1 : t;
-        // C: superset of the lanes (below span) that share their hash with another lane
-        uint64_t C;
-        bool c_full = false;  // C covers every valid lane, not only those below span
-        if (span <= 16) {
-          C = __ballot(cnt16 > 1u) & ((1ull << span) - 1ull);
-        } else {
-          zh_wave_sync();
-          if (valid) atomicAdd(&s_scr[h & 1023u], 1u);
-          zh_wave_sync();
-          const bool coll = valid && s_scr[h & 1023u] > 1u;
-          zh_wave_sync();
-          if (valid) s_scr[h & 1023u] = 0;
-          C = __ballot(coll);
-          c_full = true;
-        }
-        uint32_t f = g0 < t ? g0 : 64u, cand_lane_old = f;  // first hit in probe order
-        uint32_t cand = 0, flen = 0;
-        bool cand_in_step = false;
-        if (C) {
-          if (!c_full && g0 < 64 && ((C >> g0) & 1ull)) {
-            // the first apparent hit may be void (an earlier probe of the step re-used its
-            // table slot): later lanes come into play, so classify all of them
-            zh_wave_sync();
-            if (valid) atomicAdd(&s_scr[h & 1023u], 1u);
-            zh_wave_sync();
-            const bool coll = valid && s_scr[h & 1023u] > 1u;
-            zh_wave_sync();
-            if (valid) s_scr[h & 1023u] = 0;
-            C = __ballot(coll);
-          }
-          // exact resolution of the colliding probes before the first clean event
-          const uint64_t clean_hits = H & ~C;
-          const uint32_t g = clean_hits ? (uint32_t)__ffsll((long long)clean_hits) - 1u : 64u;
-          const uint32_t bound = g < t ? g : t;
-          uint64_t cb = bound >= 64 ? C : (C & ((1ull << bound) - 1ull));
-          f = 64;
-          while (cb) {
-            const uint32_t jx = (uint32_t)__ffsll((long long)cb) - 1u;
-            cb &= cb - 1;
-            if (post && jx == 0) continue;  // the insert-only lane never hits
+        const uint64_t V = __ballot(valid);  // a prefix of the lanes (pos + step is monotone)
+        const uint64_t H = __ballot(valid && x0 == 0);
+        uint64_t C = 0;  // lanes that share their table slot with another lane of this step
+        {
+          uint64_t cc = __ballot(cnt > 1u);  // candidates: the counters are keyed by a folded hash
+          while (cc) {
+            const uint32_t jx = (uint32_t)__ffsll((long long)cc) - 1u;
             const uint32_t hj = __builtin_amdgcn_readlane(h, jx);
-            const uint64_t same = __ballot(valid && h == hj) & ((1ull << jx) - 1ull);
-            if (same) {  // an earlier probe of this step inserted this hash last
-              const uint32_t i = 63u - (uint32_t)__clzll((long long)same);
-              if (__builtin_amdgcn_readlane(a0, i) == __builtin_amdgcn_readlane(a0, jx)) {
-                f = jx;
-                cand = __builtin_amdgcn_readlane(pos, i);
-                cand_in_step = true;
+            const uint64_t same = __ballot(valid && h == hj);
+            KPROF_COUNT(12, 1);
+            if (same & (same - 1ull)) C |= same;
+            cc &= ~same;
+          }
+        }
+        const uint32_t t = V == ~0ull ? 64u : (uint32_t)__ffsll((long long)~V) - 1u;  // first probe past ip_limit
+
+        KPROF_MARK(1);
+        KPROF_COUNT(6, 1);
+        // ---- the walk: wave-uniform replay of the reference's decisions ----
+        uint64_t ins = post ? 1ull : 0ull;  // lanes whose position was inserted, in probe order
+        uint32_t i = post ? 1u : 0u;        // next lane to probe
+        bool reprobe = post;                // the probe at lane i is the re-probe that follows a match
+        // Hop table (dense steps): a probe that arrives at lane j runs into the first lane
+        // g >= j that is a hit or shares a table slot; if g is a plain hit (candidate `old`,
+        // all of the match inside the 16 compared bytes) and the run cannot reach its 32nd
+        // probe on the way, the walk resumes at T = g + length.  Every lane works out its
+        // own (g, T) -- one cross-lane fetch -- so the wave-uniform walk is a chain of
+        // v_readlane hops, one per match; anything else stops the chain for one turn of the
+        // general walk below.
+        uint32_t hop = 0x8000u;
+        if (dense) {
+          const uint64_t ev = (H | C) >> lane;
+          const uint32_t d = ev ? (uint32_t)__ffsll((long long)ev) - 1u : 64u;
+          const uint32_t info = eqlen | ((uint32_t)((C >> lane) & 1ull) << 5);
+          const uint32_t gi = (uint32_t)__shfl((int)info, (int)((lane + d) & 63u), 64);
+          if (d < 32u && gi < 16u) hop = (lane + d) | ((lane + d + gi) << 8);
+        }
+        const uint32_t tt = ip_limit > W0 ? ip_limit - W0 : 0u;  // dense: first lane past ip_limit
+        for (;;) {
+          if (dense && (reprobe || K == 0u) && i < 64u) {
+            uint64_t sel = 0;  // match lanes of this chain
+            uint32_t cur = i;
+            while (cur < 64u) {
+              const uint32_t tv = __builtin_amdgcn_readlane(hop, cur);
+              if (tv & 0x8000u) break;
+              const uint32_t g = tv & 63u, nxt = tv >> 8;
+              sel |= 1ull << g;
+              ins |= (~0ull << cur) & (~0ull >> (63u - g));  // probes cur..g (table[h] = ip)
+              if (nxt <= 64u) ins |= 1ull << (nxt - 1u);      // ip-1 behind the match (snappy.nim:126)
+              cur = nxt;
+              if (cur >= tt) break;  // snappy.nim:118-120
+            }
+            if (sel) {
+              KPROF_COUNT(8, __popcll(sel));
+              if ((sel >> lane) & 1ull) {  // every match lane files its own record
+                const uint32_t k = nm + (uint32_t)__popcll(sel & zh_lanemask_lt());
+                m_pos[k] = (uint16_t)pos;
+                m_len[k] = (uint16_t)eqlen;
+                m_off[k] = (uint16_t)(pos - old);
+              }
+              nm += (uint32_t)__popcll(sel);
+              K = 0;
+              if (cur >= tt) {
+                finished = true;
                 break;
               }
-            } else if ((H >> jx) & 1ull) {
-              f = jx;
-              cand_lane_old = jx;
-              break;
+              if (cur >= 64u) {
+                post = true;
+                ip = W0 + cur;
+                break;
+              }
+              i = cur;
+              reprobe = true;
             }
           }
-          if (f == 64 && g < t) {
-            f = g;
-            cand_lane_old = g;
+          KPROF_COUNT(9, 1);
+          if (i >= t) {  // snappy.nim:93-95 / 118-120: the rest of the fragment is literals
+            finished = true;
+            break;
           }
-        }
-        // table inserts of the probes that really happened
-        const uint32_t last_plus1 = f < 64 ? f + 1 : t;
-        if (lane < last_plus1 && !((C >> lane) & 1ull)) s_table[h] = (uint16_t)pos;
-        if (C) {
-          uint64_t cc = last_plus1 >= 64 ? C : (C & ((1ull << last_plus1) - 1ull));
-          while (cc) {  // same-hash probes write in probe order (the later one wins)
-            const uint32_t jx = (uint32_t)__ffsll((long long)cc) - 1u;
-            cc &= cc - 1;
-            if (lane == jx) s_table[h] = (uint16_t)pos;
+          uint32_t g = i;
+          if (!reprobe) {
+            // the run's next probes are lanes i, i+1, ...: find the first that can be a hit
+            const uint32_t last_dense = dense ? i + (31u - K) : 63u;  // lane of probe #31 of the run
+            uint32_t lim = last_dense < 63u ? last_dense : 63u;
+            if (t - 1u < lim) lim = t - 1u;
+            const uint64_t E = (H | C) & (~0ull << i);
+            g = E ? (uint32_t)__ffsll((long long)E) - 1u : 64u;
+            if (g > lim) {  // lanes i..lim all miss
+              ins |= (~0ull << i) & (~0ull >> (63u - lim));
+              if (dense && lim == last_dense) {  // probe #32 on: the sparse schedule takes over
+                K = 32;
+                ip = W0 + lim + 1u;
+                post = false;
+              } else if (lim + 1u == t && t < 64u) {  // the next probe is past ip_limit
+                finished = true;
+              } else {  // lim == 63: the run continues in the next step
+                K += 64u - i;
+                post = false;
+                if (dense) {
+                  ip = W0 + 64u;
+                } else {
+                  ip = __builtin_amdgcn_readlane(pos, 63) + __builtin_amdgcn_readlane(step, 63);
+                }
+              }
+              break;
+            }
+            if (g > i) ins |= (~0ull << i) & ((1ull << g) - 1ull);
+            K += g - i;
           }
-        }
-        if (f < 64) {
-          const uint32_t mp = __builtin_amdgcn_readlane(pos, f);
+          // ---- probe lane g: its candidate is the last same-hash insert before it ----
+          uint32_t cand, flen;
+          bool hit, cand_in_step = false;
+          if ((C >> g) & 1ull) {
+            const uint32_t hg = __builtin_amdgcn_readlane(h, g);
+            const uint64_t same = __ballot(h == hg) & ins;  // ins holds only lanes probed before g
+            if (same) {
+              const uint32_t k = 63u - (uint32_t)__clzll((long long)same);
+              cand = __builtin_amdgcn_readlane(pos, k);
+              hit = __builtin_amdgcn_readlane(a0, k) == __builtin_amdgcn_readlane(a0, g);
+              flen = 4;  // only the first four bytes are known to match
+              cand_in_step = true;
+            } else {
+              cand = __builtin_amdgcn_readlane(old, g);
+              hit = (H >> g) & 1ull;
+              flen = __builtin_amdgcn_readlane(eqlen, g);
+            }
+          } else {
+            cand = __builtin_amdgcn_readlane(old, g);
+            hit = (H >> g) & 1ull;
+            flen = __builtin_amdgcn_readlane(eqlen, g);
+          }
+          ins |= 1ull << g;  // table[h] = ip precedes the comparison (snappy.nim:97-98,128)
+          if (!hit) {
+            if (reprobe) {  // snappy.nim:130-134: a fresh run starts behind the re-probe
+              reprobe = false;
+              K = 0;
+            } else {
+              K++;
+            }
+            i = g + 1u;
+            if (dense && K == 32u) {
+              ip = W0 + i;
+              post = false;
+              break;
+            }
+            if (i >= 64u) {
+              post = false;
+              ip = dense ? W0 + 64u
+                         : __builtin_amdgcn_readlane(pos, 63) + __builtin_amdgcn_readlane(step, 63);
+              break;
+            }
+            continue;
+          }
+          // ---- match at lane g (snappy.nim:103-114) ----
+          const uint32_t mp = __builtin_amdgcn_readlane(pos, g);
           const uint32_t limit = n < mp + 258u ? n : mp + 258u;
           uint32_t matched;
-          if (!cand_in_step) {
-            cand = __builtin_amdgcn_readlane(old, cand_lane_old);
-            flen = __builtin_amdgcn_readlane(eqlen, f);
-          } else {
-            flen = 4;  // only the first four bytes are known to match
-          }
           if (flen < 16u && !cand_in_step) {
             matched = flen;
           } else {
             // 4 + determineMatchLength(cand + 4, mp + 4, limit), internal.nim:251-270:
             // lane l compares bytes flen+4l .. flen+3+4l against the candidate
+            KPROF_COUNT(10, 1);
             zh_wave_sync();
             const uint32_t o = flen + 4u * lane;
             uint32_t avail = 0;
@@ -263,36 +338,39 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
             matched = flen + 4u * fl + __builtin_amdgcn_readlane(eq, fl);
           }
           if (matched > limit - mp) matched = limit - mp;
-          if (lane == (nm & 63u)) {
-            rp = mp;
-            rl = matched;
-            ro = mp - cand;
+          if (lane == 0) {
+            m_pos[nm] = (uint16_t)mp;
+            m_len[nm] = (uint16_t)matched;
+            m_off[nm] = (uint16_t)(mp - cand);
           }
           nm++;
-          if ((nm & 63u) == 0) {  // 64 staged matches -> one coalesced store per array
-            m_pos[nm - 64 + lane] = (uint16_t)rp;
-            m_len[nm - 64 + lane] = (uint16_t)rl;
-            m_off[nm - 64 + lane] = (uint16_t)ro;
-          }
           ip = mp + matched;
-          if (ip >= ip_limit) break;  // snappy.nim:118-120
-          post = true;
           K = 0;
-          continue;
+          post = true;
+          if (ip >= ip_limit) {  // snappy.nim:118-120
+            finished = true;
+            break;
+          }
+          const uint32_t ni = g + matched;  // dense: lane of the new ip
+          if (!dense || ni >= 64u) break;   // the step that follows inserts ip-1 as its lane 0
+          ins |= 1ull << (ni - 1u);         // table[hash(ip-1)] = ip-1 (snappy.nim:126)
+          i = ni;
+          reprobe = true;
         }
-        if (t < 64) break;  // snappy.nim:93-95: the rest of the fragment is literals
-        // 64 probes without a hit: continue the same literal run
-        const uint32_t p63 = __builtin_amdgcn_readlane(pos, 63), s63 = __builtin_amdgcn_readlane(step, 63);
-        K = post ? 62 : K + 64;
-        post = false;
-        ip = p63 + s63;
+        KPROF_MARK(3);
+        if (finished) break;  // nothing reads the table any more
+        // ---- table inserts of the probes that really happened, in probe order ----
+        const bool mine = (ins >> lane) & 1ull;
+        if (mine && !((C >> lane) & 1ull)) s_table[h] = (uint16_t)pos;
+        uint64_t cc = ins & C;
+        while (cc) {  // probes that share a slot write one by one (the later one wins)
+          const uint32_t jx = (uint32_t)__ffsll((long long)cc) - 1u;
+          cc &= cc - 1;
+          if (lane == jx) s_table[h] = (uint16_t)pos;
+        }
+        zh_wave_sync();
+        KPROF_MARK(4);
       }
-    }
-    if (lane < (nm & 63u)) {
-      const uint32_t b = nm & ~63u;
-      m_pos[b + lane] = (uint16_t)rp;
-      m_len[b + lane] = (uint16_t)rl;
-      m_off[b + lane] = (uint16_t)ro;
     }
     if (lane == 0) s_nmatch = nm;
   }
@@ -351,6 +429,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   }
   __threadfence_block();
   zh_wave_sync();
+  KPROF_MARK(3);
   const uint32_t nmatch = s_nmatch;
 
   // ---- coverage bitmap + match histograms (lanes over matches) ----
@@ -388,6 +467,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
     a.f_nlit[f] = n - covered;
     a.f_extra_bits[f] = extra_bits;
   }
+  KPROF_MARK(5);
+  KPROF_COUNT(11, 1);
+  KPROF_FLUSH(0, 13);
 }
 
 extern "C" void zh_launch_l1_match(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
