@@ -11,6 +11,7 @@
 // site sequence, otherwise the emulator aborts -- i.e. kernels must keep
 // cross-lane ops in wave-uniform control flow, which is also what gfx950 wants.
 #pragma once
+#define ZH_EMU 1
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -143,15 +144,16 @@ inline unsigned __brev(unsigned v) {
 }
 
 // names of the amdgcn builtins the kernels use (wrapped in zh_wave.h)
-inline unsigned emu_amdgcn_readfirstlane(unsigned v) {
+// (both return int, like the real builtins: a careless widening sign-extends here too)
+inline int emu_amdgcn_readfirstlane(unsigned v) {
   uint64_t live;
   const uint64_t* ex = emu::wave_exchange(v, &live);
-  return live ? (unsigned)ex[__builtin_ctzll(live)] : v;
+  return (int)(live ? (unsigned)ex[__builtin_ctzll(live)] : v);
 }
-inline unsigned emu_amdgcn_readlane(unsigned v, unsigned lane) {
+inline int emu_amdgcn_readlane(unsigned v, unsigned lane) {
   uint64_t live;
   const uint64_t* ex = emu::wave_exchange(v, &live);
-  return (unsigned)ex[lane & 63];
+  return (int)(unsigned)ex[lane & 63];
 }
 inline unsigned emu_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh) {
   return (unsigned)(((((uint64_t)hi) << 32) | lo) >> ((sh & 3) * 8));

@@ -15,7 +15,9 @@ from ._binding import Engine
 from .common import (ZippyError, dfDetect, dfZlib, dfGzip, dfDeflate, NoCompression, BestSpeed,
                      BestCompression, DefaultCompression, HuffmanOnly)
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libzippy_hip.so")
+# ZIPPY_HIP_LIB: tuning builds of the same library (tools/); never a different implementation
+LIB_PATH = os.environ.get("ZIPPY_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                         "libzippy_hip.so")
 
 _engine = None
 

@@ -143,6 +143,7 @@ __device__ __forceinline__ uint32_t zh_wave_xor(uint32_t v) {
 }
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ uint32_t zh_wave_scan(uint32_t v) {
+#ifdef ZH_EMU
   const unsigned lane = zh_lane();
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -150,6 +151,17 @@ __device__ __forceinline__ uint32_t zh_wave_scan(uint32_t v) {
     if (lane >= (unsigned)o) v += t;
   }
   return v;
+#else
+  // DPP: shifts inside the four 16-lane rows, then the row totals are handed on
+  // (row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143); no LDS round trip
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+  return v;
+#endif
 }
 __device__ __forceinline__ uint64_t zh_lanemask_lt() { return (1ull << zh_lane()) - 1ull; }
 
@@ -163,6 +175,14 @@ __device__ __forceinline__ uint64_t zh_ld64(const uint32_t* w, uint32_t byte_pos
   uint32_t a = w[i], b = w[i + 1], c = w[i + 2];
   return (uint64_t)__builtin_amdgcn_alignbyte(b, a, s) |
          ((uint64_t)__builtin_amdgcn_alignbyte(c, b, s) << 32);
+}
+// (hi:lo) >> (sh & 31), low 32 bits
+__device__ __forceinline__ uint32_t zh_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
+#ifdef ZH_EMU
+  return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u));
+#else
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
+#endif
 }
 __device__ __forceinline__ uint32_t zh_ld8(const uint32_t* w, uint32_t byte_pos) {
   return (w[byte_pos >> 2] >> ((byte_pos & 3u) * 8u)) & 0xffu;

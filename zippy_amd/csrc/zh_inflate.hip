@@ -19,6 +19,7 @@
 // block copies, table construction and the coalesced write-back of the window.
 // Algorithmic traffic: compressed bytes read once, output written once.
 #include "zh_common.h"
+#include "zh_kprof.h"
 #include "zh_tables.h"
 
 
@@ -28,9 +29,10 @@ __constant__ zh::LenTables c_len = zh::make_len_tables();
 __constant__ zh::DistTables c_dist = zh::make_dist_tables();
 __constant__ uint8_t c_clcl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-constexpr uint32_t kLitBits = 10, kDistBits = 8;
-constexpr uint32_t kRing = 16384;       // bytes of recent output kept in LDS
-constexpr uint32_t kFlushChunk = 4096;  // write-back granularity
+constexpr uint32_t kLitBits = 9, kDistBits = 7;
+constexpr uint32_t kRing = 5120;    // bytes of recent output kept in LDS (a multiple of 1024)
+constexpr uint32_t kFlushAt = 2048;  // pending output that triggers a write-back
+constexpr uint32_t kInWords = 128;   // staging ring of the compressed stream (dwords, power of two)
 
 }  // namespace
 
@@ -214,18 +216,29 @@ __device__ int build_table(const uint8_t* lens, uint32_t n, uint32_t* lut, uint3
 
 }  // namespace
 
+// The decode loop works on 64 bit positions at a time ("round"): lane l decodes the whole
+// token that WOULD start l bits behind the current stream position -- literal, or length +
+// extra + distance + extra -- from its own 64-bit view of the stream (two LDS lookups,
+// inflate.nim:93-100 / 199-222 for all 64 offsets at once).  A wave-uniform walk then follows
+// the real chain of token starts through those lanes (one v_readlane per symbol), a DPP prefix
+// sum of the chain's output lengths places every token, literals are stored by their lanes in
+// one LDS write per run, and LZ copies (inflate.nim:227-250) run in order, 64 bytes per
+// instruction.  Anything the 10-/8-bit LUTs cannot finish (longer codes, end of block,
+// invalid symbols) stops the chain and is decoded alone with the canonical slow path.
 __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restrict__ d_src,
                                                         uint8_t* __restrict__ d_dst,
                                                         ZhInflateArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kRing];
   __shared__ uint32_t s_lit[1u << kLitBits];
   __shared__ uint32_t s_dst[1u << kDistBits];  // also hosts the 7-bit code-length table
+  __shared__ uint32_t s_in[kInWords];          // staging ring of the compressed stream
   __shared__ HuffTab s_tab_lit, s_tab_dist, s_tab_cl;
   __shared__ uint16_t s_val_lit[288], s_val_dist[32], s_val_cl[20];
   __shared__ uint8_t s_lens[320 + 16];
   __shared__ uint32_t s_cnt[16];
 
   const unsigned lane = zh_lane();
+  KPROF_DECL(11);  // cycles: 0 headers+tables, 1 token decode + walk, 2 literal stores + copies, 3 write-back, 4 other; counts 5..10
   const uint32_t sid = blockIdx.x;
   if (a.status[sid] != ZH_OK) return;  // unwrap already failed this stream
 
@@ -237,9 +250,8 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
   const int count_only = a.count_only;
   const bool dst_al16 = (((uintptr_t)dst) & 15u) == 0;
 
-  // ---- input: two 256-byte windows of the stream held in registers (one dword per
-  // lane), addressed relative to the 4-byte aligned base below `src`; the bit buffer
-  // is topped up 32 aligned bits at a time with v_readlane (bitstreams.nim:22-49) ----
+  // ---- input: the stream is addressed in bits from the 4-byte aligned base below `src`;
+  // 64 dwords at a time go through a 512-byte LDS ring (bitstreams.nim:22-49's refill) ----
   const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
   const uint32_t* asrc = reinterpret_cast<const uint32_t*>(src - mis);
   const uint64_t end = mis + src_len;  // first byte offset (from asrc) past the stream
@@ -249,126 +261,176 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
     if (off + 4 > end) v &= (1u << (8 * (uint32_t)(end - off))) - 1u;
     return v;
   };
-  uint64_t buf = 0;   // bit buffer (LSB first)
-  int32_t cnt = 0;    // valid bits in buf
-  uint64_t wbase = 0; // byte offset (from asrc) of lane 0 of wcur
-  uint32_t widx = 0;  // next dword of wcur to consume
-  uint32_t wcur = 0, wnxt = 0;
-  auto seek = [&](uint64_t sb) {  // restart the bit reader at byte offset sb (from asrc)
-    wbase = sb & ~(uint64_t)255;
-    wcur = load_dword(wbase + 4 * lane);
-    wnxt = load_dword(wbase + 256 + 4 * lane);
-    widx = (uint32_t)(sb - wbase) >> 2;
-    const uint32_t w = __builtin_amdgcn_readlane(wcur, widx);
-    widx++;
-    buf = (uint64_t)(w >> (8 * ((uint32_t)sb & 3u)));
-    cnt = 32 - 8 * (int32_t)((uint32_t)sb & 3u);
+  uint64_t bp = 0;      // stream position in bits (from asrc)
+  uint64_t in_hi = 0;   // dwords below in_hi are staged (the ring holds the last kInWords of them)
+  uint32_t wnxt = 0;    // lane l: dword in_hi + l, loaded ahead of its use
+  auto stage = [&]() {
+    zh_wave_sync();
+    s_in[(uint32_t)(in_hi + lane) & (kInWords - 1u)] = wnxt;
+    in_hi += 64;
+    wnxt = load_dword((in_hi + lane) * 4);
+    zh_wave_sync();
   };
-  auto refill = [&]() {  // guarantees cnt > 32
-    if (cnt <= 32) {
-      if (widx == 64) {
-        wcur = wnxt;
-        wbase += 256;
-        wnxt = load_dword(wbase + 256 + 4 * lane);
-        widx = 0;
-      }
-      const uint32_t w = __builtin_amdgcn_readlane(wcur, widx);
-      widx++;
-      buf |= (uint64_t)w << cnt;
-      cnt += 32;
+  auto seek = [&](uint64_t bitpos) {  // restart the staging at bitpos
+    bp = bitpos;
+    in_hi = bitpos >> 5;
+    wnxt = load_dword((in_hi + lane) * 4);
+    stage();
+  };
+  auto ensure = [&]() {  // the round below reads up to five dwords from bp >> 5
+    if (in_hi < (bp >> 5) + 8u) stage();
+  };
+  auto fetch = [&]() -> uint64_t {  // the 64 stream bits at bp (wave-uniform)
+    ensure();
+    const uint32_t wi = (uint32_t)(bp >> 5), sh = (uint32_t)bp & 31u;
+    const uint32_t d0 = zh_bcast(s_in[wi & (kInWords - 1u)]), d1 = zh_bcast(s_in[(wi + 1u) & (kInWords - 1u)]),
+                   d2 = zh_bcast(s_in[(wi + 2u) & (kInWords - 1u)]);
+    return (uint64_t)zh_alignbit(d1, d0, sh) | ((uint64_t)zh_alignbit(d2, d1, sh) << 32);
+  };
+  // header bit reader: hb caches the bits at bp
+  uint64_t hb = 0;
+  uint32_t hc = 0;
+  auto need = [&]() {
+    if (hc < 32u) {
+      hb = fetch();
+      hc = 64;
     }
   };
-  // bits consumed so far (from asrc); the role of `bitsBuffered < 0`
-  auto past_end = [&]() -> bool { return (wbase + 4ull * widx) * 8 - (uint64_t)cnt > end * 8; };
-  auto take = [&](uint32_t nbits) -> uint32_t {
-    const uint32_t v = (uint32_t)buf & ((1u << nbits) - 1u);
-    buf >>= nbits;
-    cnt -= (int32_t)nbits;
+  auto take = [&](uint32_t nbits) -> uint32_t {  // nbits <= 16, after need()
+    const uint32_t v = (uint32_t)hb & ((1u << nbits) - 1u);
+    hb >>= nbits;
+    hc -= nbits;
+    bp += nbits;
     return v;
   };
-  // inflate.nim:67-91 decodeSymbolSlow for codes longer than the LUT; returns the
-  // symbol (0xffff = unassigned code) and consumes its bits
-  auto decode_slow = [&](uint32_t lut_bits, const HuffTab* tab, const uint16_t* values) -> uint32_t {
-    const uint32_t k = __brev((uint32_t)buf) >> 16;
+  auto past_end = [&]() -> bool { return bp > end * 8; };  // the role of `bitsBuffered < 0`
+  // inflate.nim:67-91 decodeSymbolSlow for codes longer than the LUT on the bits in `bits`;
+  // returns the symbol (0xffff = unassigned code) and its length in *nb
+  auto decode_slow = [&](uint32_t bits, uint32_t lut_bits, const HuffTab* tab, const uint16_t* values,
+                         uint32_t* nb) -> uint32_t {
+    const uint32_t k = __brev(bits) >> 16;
     uint32_t cl = lut_bits + 1;
     while (cl < 16 && k >= zh_bcast(tab->max_codes[cl])) cl++;
+    *nb = 0;
     if (cl >= 16) return 0xffffu;
     const uint32_t id = ((k >> (16 - cl)) - zh_bcast(tab->first_code[cl]) +
                          zh_bcast(tab->first_symbol[cl])) & 0xffffu;
-    take(cl);
+    *nb = cl;
     return zh_bcast(values[id]);
   };
 
-  seek((uint64_t)mis + a.body_pos[sid]);
+  seek(((uint64_t)mis + a.body_pos[sid]) * 8);
 
-  uint64_t op = 0;          // bytes produced (including the pending literals' predecessors)
-  uint32_t unflushed = 0;   // op - (bytes already written back to HBM)
+  uint64_t op = 0;         // bytes produced
+  uint32_t rp = 0;         // op mod kRing
+  uint32_t unflushed = 0;  // op - (bytes already written back to HBM); op - unflushed is a multiple of 1024
   int st = ZH_OK;
-  uint64_t pend = 0;        // up to 8 decoded literals not yet stored in the ring
-  uint32_t psh = 0;         // 8 * number of pending literals
+  auto wrap = [&](uint32_t x) -> uint32_t { return x >= kRing ? x - kRing : x; };  // x < 2 * kRing
 
-  // write the oldest `nbytes` unflushed ring bytes back to HBM (nbytes <= unflushed <= kRing)
+  // write the oldest `nbytes` unflushed ring bytes back to HBM
   auto flush = [&](uint32_t nbytes) {
+    KPROF_MARK(2);
     zh_wave_sync();
-    if (!count_only) {
+    if (!count_only && nbytes) {
       const uint64_t from = op - unflushed;
       const uint64_t upto = from + nbytes;
+      uint32_t r = wrap(rp + kRing - unflushed);  // ring offset of `from` (a multiple of 1024)
       uint64_t p = from;
-      if (dst_al16) {  // `from` is a multiple of kFlushChunk here (chunks go out whole)
+      if (dst_al16) {
         for (; p + 1024 <= upto; p += 1024) {
-          const uint64_t q = p + lane * 16u;
-          *reinterpret_cast<uint4*>(dst + q) = *reinterpret_cast<const uint4*>(&s_win[q & (kRing - 1u)]);
+          *reinterpret_cast<uint4*>(dst + p + lane * 16u) = *reinterpret_cast<const uint4*>(&s_win[r + lane * 16u]);
+          r = wrap(r + 1024u);
         }
       }
-      for (uint64_t q = p + lane; q < upto; q += 64) dst[q] = s_win[q & (kRing - 1u)];
+      for (uint64_t q = p + lane; q < upto; q += 64) dst[q] = s_win[wrap(r + (uint32_t)(q - p))];
     }
     unflushed -= nbytes;
     zh_wave_sync();
+    KPROF_MARK(3);
   };
-  // store the pending literals in the ring; checks that are only needed now and then
-  // (end of input, slot capacity, write-back) ride along here
-  auto flush_pend = [&]() {
-    const uint32_t npend = psh >> 3;
-    if (npend) {
-      if (!count_only && lane < npend) s_win[(op + lane) & (kRing - 1u)] = (uint8_t)(pend >> (8 * lane));
-      op += npend;
-      unflushed += npend;
-      psh = 0;
-      pend = 0;
+  // room for `nbytes` more output in the ring; afterwards everything older than the ring is in HBM
+  auto make_room = [&](uint32_t nbytes) {
+    if (unflushed + nbytes > kRing - 1024u) flush(unflushed & ~1023u);
+  };
+  // inflate.nim:224-250: one LZ copy of `length` bytes from `dist` back, at op (wave-uniform)
+  auto lz_copy = [&](uint32_t length, uint32_t dist) {
+    if (dist > op) {  // inflate.nim:224-225
+      st = ZH_ERR_INVALID_BUFFER;
+      return;
     }
-    if (unflushed >= kFlushChunk + 2048) {
-      if (past_end()) st = ZH_ERR_END_OF_BUFFER;
-      else if (op > cap && !count_only) st = ZH_ERR_DST_TOO_SMALL;
-      else flush(kFlushChunk);
+    if (!count_only) {
+      if (op + length > cap) {
+        st = ZH_ERR_DST_TOO_SMALL;
+        return;
+      }
+      make_room(length);
+      zh_wave_sync();
+      // byte-sequential LZ77 copy semantics; an overlapping copy (dist < length) repeats the
+      // dist-byte pattern, so every lane reads its source from the region already written
+      if (dist > kRing) {
+        // older than the ring: written back at least 1 KiB of output ago.  Wait for those
+        // stores, then read through L2 (this CU's L1 may hold a stale copy of the line).
+        KPROF_COUNT(8, 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        for (uint32_t i = lane; i < length; i += 64)
+          s_win[wrap(rp + i)] = __hip_atomic_load(dst + (op - dist + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        const uint32_t sb = wrap(rp + kRing - dist);  // ring offset of the source
+        if (dist + length > kRing) {
+          // the destination wraps onto the source's ring slots: read each 64-byte group before
+          // the next is written (program order on the GPU; the syncs keep the emulator honest)
+          for (uint32_t base = 0; base < length; base += 64) {
+            const uint32_t i = base + lane;
+            const uint8_t v = s_win[wrap(sb + i)];
+            zh_wave_sync();
+            if (i < length) s_win[wrap(rp + i)] = v;
+            zh_wave_sync();
+          }
+        } else if (dist >= length) {
+          for (uint32_t i = lane; i < length; i += 64) s_win[wrap(rp + i)] = s_win[wrap(sb + i)];
+        } else if (dist == 1) {
+          const uint8_t v = s_win[sb];
+          for (uint32_t i = lane; i < length; i += 64) s_win[wrap(rp + i)] = v;
+        } else {
+          for (uint32_t i = lane; i < length; i += 64) s_win[wrap(rp + i)] = s_win[wrap(sb + i % dist)];
+        }
+      }
     }
+    op += length;
+    rp = wrap(rp + length);
+    unflushed += length;
   };
 
   bool final_block = false;
   while (!final_block && st == ZH_OK) {  // inflate.nim:273-289
-    refill();
+    KPROF_MARK(4);
+    hc = 0;
+    need();
     const uint32_t bfinal = take(1), btype = take(2);
     if (bfinal) final_block = true;
 
     if (btype == 0) {  // inflate.nim:252-266 inflateNoCompression
-      take((uint32_t)cnt & 7u);
-      refill();
+      bp = (bp + 7u) & ~(uint64_t)7;
+      hc = 0;
+      need();
       const uint32_t len = take(16), nlen = take(16);
       if (len + nlen != 65535u) { st = ZH_ERR_INVALID_BUFFER; break; }
-      const uint64_t byte_pos = wbase + 4ull * widx - (uint64_t)(cnt >> 3);  // from asrc
+      const uint64_t byte_pos = bp >> 3;  // from asrc
       if (byte_pos + len > end) { st = ZH_ERR_END_OF_BUFFER; break; }
       if (op + len > cap && !count_only) { st = ZH_ERR_DST_TOO_SMALL; break; }
       const uint8_t* raw = reinterpret_cast<const uint8_t*>(asrc) + byte_pos;
       for (uint32_t done = 0; done < len;) {
-        const uint32_t n = len - done < kFlushChunk ? len - done : kFlushChunk;
+        const uint32_t n = len - done < 2048u ? len - done : 2048u;
+        if (!count_only) make_room(n);
         zh_wave_sync();
         if (!count_only)
-          for (uint32_t i = lane; i < n; i += 64) s_win[(op + i) & (kRing - 1u)] = raw[done + i];
+          for (uint32_t i = lane; i < n; i += 64) s_win[wrap(rp + i)] = raw[done + i];
         op += n;
+        rp = wrap(rp + n);
         unflushed += n;
         done += n;
-        if (unflushed >= kFlushChunk + 2048) flush(kFlushChunk);
       }
-      seek(byte_pos + len);
+      seek((byte_pos + len) * 8);
       continue;
     }
     if (btype == 3) { st = ZH_ERR_BLOCK_HEADER; break; }
@@ -387,7 +449,7 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
       if (lane < 20) s_lens[lane] = 0;
       zh_wave_sync();
       for (uint32_t i = 0; i < hclen; i++) {
-        refill();
+        need();
         const uint32_t v = take(3);
         if (lane == 0) s_lens[c_clcl_order[i]] = (uint8_t)v;
       }
@@ -397,14 +459,16 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
       const uint32_t total = hlit + hdist;
       uint32_t prev = 0;
       while (i != total) {
-        refill();
+        need();
         uint32_t sym;
-        const uint32_t e = zh_bcast(s_dst[(uint32_t)buf & 127u]);
+        const uint32_t e = zh_bcast(s_dst[(uint32_t)hb & 127u]);
         if (e) {
           take(e & 15u);
           sym = e >> 16;
         } else {
-          sym = decode_slow(7, &s_tab_cl, s_val_cl);
+          uint32_t nb;
+          sym = decode_slow((uint32_t)hb, 7, &s_tab_cl, s_val_cl, &nb);
+          take(nb);
         }
         if (past_end()) { st = ZH_ERR_END_OF_BUFFER; break; }
         if (sym <= 15) {
@@ -437,94 +501,149 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
       st = build_table(s_lens + dist_at, hdist, s_dst, kDistBits, 1, &s_tab_dist, s_val_dist, s_cnt);
       if (st != ZH_OK) break;
     }
+    KPROF_MARK(0);
 
-    for (;;) {  // inflate.nim:173-250
-      refill();
-      uint32_t e = zh_bcast(s_lit[(uint32_t)buf & ((1u << kLitBits) - 1u)]);
-      if (e & 0x8000u) {  // literal straight out of the LUT: the hot path
-        const uint32_t nb = e & 15u;
-        buf >>= nb;
-        cnt -= (int32_t)nb;
-        pend |= (uint64_t)(e >> 16) << psh;
-        psh += 8;
-        if (psh == 64) {
-          flush_pend();
-          if (st != ZH_OK) break;
-        }
-        continue;
+    for (;;) {  // inflate.nim:173-250, one round = 64 bit positions
+      ensure();
+      KPROF_COUNT(7, 1);
+      // ---- every lane decodes the token that would start at bit bp + lane ----
+      const uint32_t bl = (uint32_t)bp + lane;  // only bits 0..4 and the dword index delta matter
+      const uint32_t wi = (uint32_t)((bp + lane) >> 5), sh = bl & 31u;
+      const uint32_t d0 = s_in[wi & (kInWords - 1u)], d1 = s_in[(wi + 1u) & (kInWords - 1u)],
+                     d2 = s_in[(wi + 2u) & (kInWords - 1u)];
+      const uint32_t v_lo = zh_alignbit(d1, d0, sh), v_hi = zh_alignbit(d2, d1, sh);
+      const uint64_t v = (uint64_t)v_lo | ((uint64_t)v_hi << 32);
+      const uint32_t e = s_lit[v_lo & ((1u << kLitBits) - 1u)];
+      const uint32_t L = e & 15u, eb = (e >> 4) & 15u;
+      const bool is_lit = (e & 0x8000u) != 0;
+      const uint32_t lenval = (e >> 16) + ((v_lo >> L) & ((1u << eb) - 1u));
+      const uint32_t o2 = L + eb;  // <= 15
+      const uint32_t de = s_dst[(uint32_t)(v >> o2) & ((1u << kDistBits) - 1u)];
+      const uint32_t o3 = o2 + (de & 15u), deb = (de >> 4) & 15u;
+      const uint32_t distval = (de >> 16) + ((uint32_t)(v >> o3) & ((1u << deb) - 1u));
+      uint32_t tbits;  // bits of the whole token; 0x8000: not decodable here
+      if (is_lit) tbits = L;
+      else if (e != 0 && ((e >> 8) & 3u) == kKindBase && de != 0 && ((de >> 8) & 3u) == kKindBase) tbits = o3 + deb;
+      else tbits = 0x8000u;
+      const uint32_t outlen = is_lit ? 1u : lenval;
+
+      // ---- the chain of real token starts ----
+      uint64_t chain = 0;
+      uint32_t pos = 0;
+      while (pos < 64u) {
+        const uint32_t tv = __builtin_amdgcn_readlane(tbits, pos);
+        if (tv & 0x8000u) break;
+        chain |= 1ull << pos;
+        pos += tv;
       }
-      if (e == 0) {  // longer than the LUT, or unassigned
-        const uint32_t sym = decode_slow(kLitBits, &s_tab_lit, s_val_lit);
-        e = litlen_entry(sym, 0);
-        if (e & 0x8000u) {
-          pend |= (uint64_t)(e >> 16) << psh;
-          psh += 8;
-          if (psh == 64) {
-            flush_pend();
-            if (st != ZH_OK) break;
+      const bool in_chain = (chain >> lane) & 1ull;
+      const uint32_t incl = zh_wave_scan(in_chain ? outlen : 0u);
+      const uint32_t opre = incl - (in_chain ? outlen : 0u);  // output offset of this lane's token
+      const uint64_t litmask = chain & __ballot(is_lit);
+      uint64_t mm = chain & ~litmask;
+      KPROF_COUNT(5, __popcll(chain));
+      KPROF_MARK(1);
+      // ---- output: literal runs by their lanes, copies in order ----
+      {
+        const uint32_t rp0 = rp;
+        uint32_t done_lanes = 0;  // chain lanes below this bit offset are finished
+        while (mm && st == ZH_OK) {
+          const uint32_t g = (uint32_t)__ffsll((long long)mm) - 1u;
+          mm &= mm - 1;
+          const uint64_t grp = litmask & ((1ull << g) - 1ull) & (~0ull << done_lanes);
+          if (grp) {
+            const uint32_t nl = (uint32_t)__popcll(grp);
+            if (!count_only) {
+              if (op + nl > cap) { st = ZH_ERR_DST_TOO_SMALL; break; }
+              if ((grp >> lane) & 1ull) s_win[wrap(rp0 + opre)] = (uint8_t)(e >> 16);
+            }
+            op += nl;
+            rp = wrap(rp + nl);
+            unflushed += nl;
           }
-          continue;
+          KPROF_COUNT(6, 1);
+          lz_copy(__builtin_amdgcn_readlane(lenval, g), __builtin_amdgcn_readlane(distval, g));
+          done_lanes = g + 1u;
         }
-      } else {
-        take(e & 15u);
+        if (st == ZH_OK) {
+          const uint64_t grp = done_lanes < 64u ? litmask & (~0ull << done_lanes) : 0ull;
+          if (grp) {
+            const uint32_t nl = (uint32_t)__popcll(grp);
+            if (!count_only) {
+              if (op + nl > cap) st = ZH_ERR_DST_TOO_SMALL;
+              else if ((grp >> lane) & 1ull) s_win[wrap(rp0 + opre)] = (uint8_t)(e >> 16);
+            }
+            op += nl;
+            rp = wrap(rp + nl);
+            unflushed += nl;
+          }
+        }
       }
-      // literals decoded from beyond the end of the input are caught here at the latest
-      if (past_end()) { st = ZH_ERR_END_OF_BUFFER; break; }
-      flush_pend();
       if (st != ZH_OK) break;
-      const uint32_t kind = (e >> 8) & 3u;
-      if (kind == kKindEob) break;
-      if (kind == kKindBad) { st = ZH_ERR_INVALID_BUFFER; break; }  // inflate.nim:202-204
-      const uint32_t length = (e >> 16) + take((e >> 4) & 15u);
-      refill();
-      uint32_t de = zh_bcast(s_dst[(uint32_t)buf & ((1u << kDistBits) - 1u)]);
-      if (de == 0) {
-        const uint32_t dsym = decode_slow(kDistBits, &s_tab_dist, s_val_dist);
-        de = dist_entry(dsym, 0);
-      } else {
-        take(de & 15u);
-      }
-      if (((de >> 8) & 3u) == kKindBad) { st = ZH_ERR_INVALID_BUFFER; break; }  // inflate.nim:211-213
-      const uint32_t dist = (de >> 16) + take((de >> 4) & 15u);
-      if (dist > op) { st = ZH_ERR_INVALID_BUFFER; break; }  // inflate.nim:224-225
-      if (!count_only) {
-        // inflate.nim:227-250: byte-sequential LZ77 copy semantics; an overlapping copy
-        // (dist < length) repeats the dist-byte pattern, so every lane reads its source
-        // from the region that is already written.
-        zh_wave_sync();
-        if (dist > kRing) {
-          // source older than the ring: it was written back at least kRing - kFlushChunk -
-          // 2048 - 258 bytes ago.  Wait for those stores, then read through L2 (this CU's
-          // L1 may hold a stale copy of a partially written line).
-          if (op + length > cap) { st = ZH_ERR_DST_TOO_SMALL; break; }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          for (uint32_t i = lane; i < length; i += 64)
-            s_win[(op + i) & (kRing - 1u)] =
-                __hip_atomic_load(dst + (op - dist + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (dist + length > kRing) {
-          // the destination wraps onto the source's ring slots: each 64-byte group must be
-          // read before the next group is written (program order on the GPU; the explicit
-          // syncs keep the CPU emulator, whose lanes are not in lockstep, honest)
-          for (uint32_t base = 0; base < length; base += 64) {
-            const uint32_t i = base + lane;
-            const uint8_t v = s_win[(op - dist + i) & (kRing - 1u)];
-            zh_wave_sync();
-            if (i < length) s_win[(op + i) & (kRing - 1u)] = v;
-            zh_wave_sync();
-          }
-        } else if (dist >= length) {
-          for (uint32_t i = lane; i < length; i += 64)
-            s_win[(op + i) & (kRing - 1u)] = s_win[(op - dist + i) & (kRing - 1u)];
-        } else if (dist == 1) {
-          const uint8_t v = s_win[(op - 1) & (kRing - 1u)];
-          for (uint32_t i = lane; i < length; i += 64) s_win[(op + i) & (kRing - 1u)] = v;
+      bp += pos;
+      bool block_done = false;
+      if (pos < 64u) {
+        // ---- the token at bp stopped the chain: decode it alone (inflate.nim:67-102) ----
+        KPROF_COUNT(9, 1);
+        // (the builtin returns int: widen through uint32_t, or the low word sign-extends)
+        const uint32_t sv_lo = __builtin_amdgcn_readlane(v_lo, pos), sv_hi = __builtin_amdgcn_readlane(v_hi, pos);
+        uint64_t sv = (uint64_t)sv_lo | ((uint64_t)sv_hi << 32);
+        uint32_t se = __builtin_amdgcn_readlane(e, pos);
+        uint32_t used;
+        if (se == 0) {  // longer than the LUT, or unassigned
+          uint32_t nb;
+          const uint32_t sym = decode_slow((uint32_t)sv, kLitBits, &s_tab_lit, s_val_lit, &nb);
+          se = litlen_entry(sym, 0);
+          used = nb;
         } else {
-          for (uint32_t i = lane; i < length; i += 64)
-            s_win[(op + i) & (kRing - 1u)] = s_win[(op - dist + i % dist) & (kRing - 1u)];
+          used = se & 15u;
         }
+        sv >>= used;
+        const uint32_t kind = (se >> 8) & 3u;
+        if (se & 0x8000u) {  // a literal with a long code
+          if (!count_only) {
+            if (op + 1 > cap) st = ZH_ERR_DST_TOO_SMALL;
+            else if (lane == 0) s_win[rp] = (uint8_t)(se >> 16);
+          }
+          op += 1;
+          rp = wrap(rp + 1u);
+          unflushed += 1;
+        } else if (kind == kKindEob) {
+          block_done = true;
+        } else if (kind == kKindBad) {  // inflate.nim:202-204
+          st = ZH_ERR_INVALID_BUFFER;
+        } else {
+          const uint32_t seb = (se >> 4) & 15u;
+          const uint32_t length = (se >> 16) + ((uint32_t)sv & ((1u << seb) - 1u));
+          sv >>= seb;
+          used += seb;
+          uint32_t sde = zh_bcast(s_dst[(uint32_t)sv & ((1u << kDistBits) - 1u)]);
+          uint32_t dnb;
+          if (sde == 0) {
+            const uint32_t dsym = decode_slow((uint32_t)sv, kDistBits, &s_tab_dist, s_val_dist, &dnb);
+            sde = dist_entry(dsym, 0);
+          } else {
+            dnb = sde & 15u;
+          }
+          sv >>= dnb;
+          used += dnb;
+          if (((sde >> 8) & 3u) == kKindBad) {  // inflate.nim:211-213
+            st = ZH_ERR_INVALID_BUFFER;
+          } else {
+            const uint32_t sdeb = (sde >> 4) & 15u;
+            const uint32_t dist = (sde >> 16) + ((uint32_t)sv & ((1u << sdeb) - 1u));
+            used += sdeb;
+            KPROF_COUNT(6, 1);
+            lz_copy(length, dist);
+          }
+        }
+        bp += used;
       }
-      op += length;
-      unflushed += length;
+      KPROF_MARK(2);
+      // tokens decoded from beyond the end of the input are caught here at the latest
+      if (st == ZH_OK && past_end()) st = ZH_ERR_END_OF_BUFFER;
+      if (st != ZH_OK || block_done) break;
+      if (unflushed >= kFlushAt) flush(unflushed & ~1023u);
     }
   }
 
@@ -536,6 +655,9 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
     a.out_len[sid] = op;
     a.status[sid] = st;
   }
+  KPROF_MARK(4);
+  KPROF_COUNT(10, 1);
+  KPROF_FLUSH(16, 11);
 }
 
 // Final check of each stream against its trailer (gzip.nim:80-88, zippy.nim:152-162).
