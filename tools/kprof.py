@@ -15,7 +15,8 @@ sys.path.insert(0, ROOT)
 
 L1 = ["stage-in", "step: vector part", "step: fast walk", "step: slow walk", "step: table inserts",
       "stats phase", "#steps", "#fast steps", "#events fast", "#events slow", "#match extensions",
-      "#waves", "#refine iterations"]
+      "#waves", "#slow: run continues", "#slow: 32 lanes no event", "#slow: shared slot",
+      "#slow: end of step"]
 INF = ["headers+tables", "token decode + walk", "literal stores + copies", "write-back", "other",
        "#symbols in chains", "#matches", "#rounds", "#far copies", "#lone tokens", "#waves"]
 
@@ -69,7 +70,7 @@ def main():
     slots = (ctypes.c_ulonglong * 64)()
     eng.lib.zh_kprof_read(slots, 0)
     print("kernel ms:", {k: round(v, 3) for k, v in cplan.kernel_times() + uplan.kernel_times()})
-    show("zh_l1_match_kernel", L1, list(slots[0:13]))
+    show("zh_l1_match_kernel", L1, list(slots[0:16]))
     show("zh_inflate_kernel", INF, list(slots[16:27]))
 
 

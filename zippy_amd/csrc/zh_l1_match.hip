@@ -31,12 +31,15 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   __shared__ __attribute__((aligned(16))) uint32_t s_src[ZH_FRAG_SIZE / 4 + 8];
   __shared__ uint16_t s_table[16384];
   __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
-  __shared__ uint32_t s_cover[ZH_FRAG_SIZE / 32];  // bit p set: byte p lies inside a match
+  // parse: 8192 byte-wide counters (4 per dword) of the probes per table slot in one step,
+  // all zero between steps; afterwards the first 4 KiB are the coverage bitmap (bit p set:
+  // byte p lies inside a match)
+  __shared__ uint32_t s_scr[2048];
   __shared__ uint32_t s_nmatch;
-  __shared__ uint32_t s_scr[1024];  // per-step hash collision counters
+  uint32_t* const s_cover = s_scr;
 
   const unsigned lane = zh_lane();
-  KPROF_DECL(13);  // cycles: 0 stage-in, 1 vector part, 2 fast walk, 3 slow walk, 4 inserts, 5 stats; counts: 6..12
+  KPROF_DECL(16);  // cycles: 0 stage-in, 1 vector part, 2 fast walk, 3 slow walk, 4 inserts, 5 stats; counts: 6..12
   const uint32_t f = blockIdx.x;
   const ZhFragDesc fd = a.frags[f];
   const uint32_t n = fd.len;
@@ -65,8 +68,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
       s_src[w] = v;
     }
     for (uint32_t i = lane; i < ZH_HIST_STRIDE; i += 64) s_hist[i] = 0;
-    for (uint32_t i = lane; i < ZH_FRAG_SIZE / 32; i += 64) s_cover[i] = 0;
-    for (uint32_t i = lane; i < 1024; i += 64) s_scr[i] = 0;
+    for (uint32_t i = lane; i < 2048; i += 64) s_scr[i] = 0;
   }
 
   uint32_t table_size = 256, shift = 24;  // snappy.nim:24-29
@@ -137,7 +139,8 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         // round trip 2: the table slot; every lane also ticks a counter of its (folded) hash,
         // read back together with the candidate bytes
         const uint32_t old = s_table[h];
-        if (valid) atomicAdd(&s_scr[h & 1023u], 1u);
+        const uint32_t ck = (h & 8191u) >> 2, cs = (h & 3u) * 8u;
+        if (valid) atomicAdd(&s_scr[ck], 1u << cs);
         zh_wave_sync();  // (orders the counter traffic between lanes; emits nothing)
         const uint32_t a1 = __builtin_amdgcn_alignbyte(p2, p1, pos);
         const uint32_t a2 = __builtin_amdgcn_alignbyte(p3, p2, pos);
@@ -146,9 +149,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         const uint32_t ow = old >> 2;
         const uint32_t q0 = s_src[ow], q1 = s_src[ow + 1], q2 = s_src[ow + 2], q3 = s_src[ow + 3],
                        q4 = s_src[ow + 4];
-        const uint32_t cnt = valid ? s_scr[h & 1023u] : 0u;
+        const uint32_t cnt = valid ? (s_scr[ck] >> cs) & 255u : 0u;
         zh_wave_sync();
-        if (valid) s_scr[h & 1023u] = 0;
+        if (valid) s_scr[ck] = 0;
         const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(q1, q0, old);
         const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(q2, q1, old);
         const uint32_t x2 = a2 ^ __builtin_amdgcn_alignbyte(q3, q2, old);
@@ -164,18 +167,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
 
         const uint64_t V = __ballot(valid);  // a prefix of the lanes (pos + step is monotone)
         const uint64_t H = __ballot(valid && x0 == 0);
-        uint64_t C = 0;  // lanes that share their table slot with another lane of this step
-        {
-          uint64_t cc = __ballot(cnt > 1u);  // candidates: the counters are keyed by a folded hash
-          while (cc) {
-            const uint32_t jx = (uint32_t)__ffsll((long long)cc) - 1u;
-            const uint32_t hj = __builtin_amdgcn_readlane(h, jx);
-            const uint64_t same = __ballot(valid && h == hj);
-            KPROF_COUNT(12, 1);
-            if (same & (same - 1ull)) C |= same;
-            cc &= ~same;
-          }
-        }
+        // lanes that may share their table slot with another lane of this step (a superset:
+        // the counters see 13 of the 14 hash bits); the general walk below sorts them out exactly
+        const uint64_t C = __ballot(cnt > 1u);
         const uint32_t t = V == ~0ull ? 64u : (uint32_t)__ffsll((long long)~V) - 1u;  // first probe past ip_limit
 
         KPROF_MARK(1);
@@ -189,8 +183,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         // all of the match inside the 16 compared bytes) and the run cannot reach its 32nd
         // probe on the way, the walk resumes at T = g + length.  Every lane works out its
         // own (g, T) -- one cross-lane fetch -- so the wave-uniform walk is a chain of
-        // v_readlane hops, one per match; anything else stops the chain for one turn of the
-        // general walk below.
+        // v_readlane hops, one per match, in a loop small enough to stay in the instruction
+        // buffer (a taken branch to other code costs a lone wave ~50 cycles, the loop edge
+        // next to nothing); anything else stops the chain for one turn of the general walk.
         uint32_t hop = 0x8000u;
         if (dense) {
           const uint64_t ev = (H | C) >> lane;
@@ -204,6 +199,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
           if (dense && (reprobe || K == 0u) && i < 64u) {
             uint64_t sel = 0;  // match lanes of this chain
             uint32_t cur = i;
+            KPROF_MARK(3);
             while (cur < 64u) {
               const uint32_t tv = __builtin_amdgcn_readlane(hop, cur);
               if (tv & 0x8000u) break;
@@ -214,6 +210,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
               cur = nxt;
               if (cur >= tt) break;  // snappy.nim:118-120
             }
+            KPROF_MARK(2);
             if (sel) {
               KPROF_COUNT(8, __popcll(sel));
               if ((sel >> lane) & 1ull) {  // every match lane files its own record
@@ -224,7 +221,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
               }
               nm += (uint32_t)__popcll(sel);
               K = 0;
-              if (cur >= tt) {
+              if (cur >= tt) {  // snappy.nim:118-120
                 finished = true;
                 break;
               }
@@ -469,7 +466,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   }
   KPROF_MARK(5);
   KPROF_COUNT(11, 1);
-  KPROF_FLUSH(0, 13);
+  KPROF_FLUSH(0, 16);
 }
 
 extern "C" void zh_launch_l1_match(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
