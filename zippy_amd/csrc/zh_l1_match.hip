@@ -8,8 +8,12 @@
 // so the match list equals the reference's token stream fragment by fragment
 // (tests compare them token for token through zh_debug_tokens).
 //
-// LDS per wave: the fragment's bytes (32 KiB + pad), the u16 hash table
-// (32 KiB, snappy.nim:7), the symbol histograms and a coverage bitmap.
+// LDS per wave: the u16 hash table (32 KiB, snappy.nim:7), 4 KiB of per-step slot
+// counters (reused as the coverage bitmap afterwards) and the symbol histograms -- 38 KiB,
+// four waves per CU.  The fragment's own bytes are read through L1/L2 instead of a second
+// 32 KiB LDS copy: a lone wave runs at well under a tenth of its SIMD's issue rate (every
+// step is a chain of dependent round trips), so waves per CU, not latency per access, is
+// what buys throughput.
 // Output per fragment (HBM scratch): the match list (start, length, offset as
 // u16 SoA), the litlen/distance histograms (u16 x 320), literal count and the
 // sum of extra bits -- everything the Huffman and emission kernels need.
@@ -26,15 +30,13 @@ constexpr uint32_t kHashMul = 0x1e35a7bdu;  // snappy.nim:70-71
 }  // namespace
 
 __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restrict__ d_src,
-                                                         ZhCompressArgs a, int huffman_only,
-                                                         int serial_parse) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_src[ZH_FRAG_SIZE / 4 + 8];
+                                                         ZhCompressArgs a, int huffman_only) {
   __shared__ uint16_t s_table[16384];
   __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
-  // parse: 8192 byte-wide counters (4 per dword) of the probes per table slot in one step,
-  // all zero between steps; afterwards the first 4 KiB are the coverage bitmap (bit p set:
-  // byte p lies inside a match)
-  __shared__ uint32_t s_scr[2048];
+  // parse: 4096 byte-wide counters (4 per dword) of the probes per table slot in one step,
+  // all zero between steps; afterwards the coverage bitmap (bit p set: byte p lies inside
+  // a match)
+  __shared__ uint32_t s_scr[1024];
   __shared__ uint32_t s_nmatch;
   uint32_t* const s_cover = s_scr;
 
@@ -48,28 +50,18 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   uint16_t* m_len = a.m_len + (size_t)f * ZH_MAX_MATCHES_PER_FRAG;
   uint16_t* m_off = a.m_off + (size_t)f * ZH_MAX_MATCHES_PER_FRAG;
 
-  // ---- stage the fragment into LDS (coalesced), clear state ----
-  {
-    const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
-    const uint32_t* asrc = reinterpret_cast<const uint32_t*>(src - mis);
-    const uint32_t nwords = (n + 3) / 4;
-    const uint32_t nalign = (n + mis + 3) / 4;  // aligned dwords that hold fragment bytes
-    for (uint32_t w = lane; w < nwords + 2; w += 64) {
-      uint32_t v = 0;
-      if (w < nwords) {
-        // aligned dword pair -> the 4 bytes at fragment offset 4w (never reads past the
-        // aligned dword that holds the fragment's last byte)
-        const uint32_t lo = asrc[w];
-        const uint32_t hi = (mis && w + 1 < nalign) ? asrc[w + 1] : 0u;
-        v = __builtin_amdgcn_alignbyte(hi, lo, mis);
-        const uint32_t valid = n - 4 * w;  // bytes of this word inside the fragment
-        if (valid < 4) v &= (1u << (8 * valid)) - 1u;
-      }
-      s_src[w] = v;
-    }
-    for (uint32_t i = lane; i < ZH_HIST_STRIDE; i += 64) s_hist[i] = 0;
-    for (uint32_t i = lane; i < 2048; i += 64) s_scr[i] = 0;
-  }
+  // ---- the fragment's bytes: aligned dwords of the stream below `src`, never past the
+  // dword that holds its last byte ----
+  const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
+  const uint32_t* asrc = reinterpret_cast<const uint32_t*>(src - mis);
+  const uint32_t last_dw = n ? (n + mis - 1u) >> 2 : 0u;
+  auto dw = [&](uint32_t i) -> uint32_t { return asrc[i < last_dw ? i : last_dw]; };
+  auto ld32 = [&](uint32_t p) -> uint32_t {  // the 4 bytes at fragment offset p (p + 4 <= n + 3)
+    const uint32_t q = p + mis, i = q >> 2;
+    return __builtin_amdgcn_alignbyte(dw(i + 1), dw(i), q);
+  };
+  for (uint32_t i = lane; i < ZH_HIST_STRIDE; i += 64) s_hist[i] = 0;
+  for (uint32_t i = lane; i < 1024; i += 64) s_scr[i] = 0;
 
   uint32_t table_size = 256, shift = 24;  // snappy.nim:24-29
   while (table_size < 16384u && table_size < n) {
@@ -105,7 +97,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   // resolved exactly, one by one), else `old`.  Only the lanes the reference would have
   // probed or inserted write the table, in probe order, so the table evolves exactly as
   // in the serial walk and the match list equals the reference's token stream.
-  if (!serial_parse) {
+  {
     uint32_t nm = 0;
     if (!huffman_only && n >= 15) {
       const uint32_t ip_limit = n - 15;
@@ -131,31 +123,29 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         const bool valid = pos + step <= ip_limit;  // the reference's `nextIp > ipLimit` test
         if (!valid) pos = 1;  // keep LDS reads in range; the lane is never walked
         // round trip 1: 16 source bytes at pos (five aligned dwords)
-        const uint32_t pw = pos >> 2;
-        const uint32_t p0 = s_src[pw], p1 = s_src[pw + 1], p2 = s_src[pw + 2], p3 = s_src[pw + 3],
-                       p4 = s_src[pw + 4];
-        const uint32_t a0 = __builtin_amdgcn_alignbyte(p1, p0, pos);
+        const uint32_t pq = pos + mis, pw = pq >> 2;
+        const uint32_t p0 = dw(pw), p1 = dw(pw + 1), p2 = dw(pw + 2), p3 = dw(pw + 3), p4 = dw(pw + 4);
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(p1, p0, pq);
         const uint32_t h = (a0 * kHashMul) >> shift;
         // round trip 2: the table slot; every lane also ticks a counter of its (folded) hash,
         // read back together with the candidate bytes
         const uint32_t old = s_table[h];
-        const uint32_t ck = (h & 8191u) >> 2, cs = (h & 3u) * 8u;
+        const uint32_t ck = (h & 4095u) >> 2, cs = (h & 3u) * 8u;
         if (valid) atomicAdd(&s_scr[ck], 1u << cs);
         zh_wave_sync();  // (orders the counter traffic between lanes; emits nothing)
-        const uint32_t a1 = __builtin_amdgcn_alignbyte(p2, p1, pos);
-        const uint32_t a2 = __builtin_amdgcn_alignbyte(p3, p2, pos);
-        const uint32_t a3 = __builtin_amdgcn_alignbyte(p4, p3, pos);
+        const uint32_t a1 = __builtin_amdgcn_alignbyte(p2, p1, pq);
+        const uint32_t a2 = __builtin_amdgcn_alignbyte(p3, p2, pq);
+        const uint32_t a3 = __builtin_amdgcn_alignbyte(p4, p3, pq);
         // round trip 3: 16 bytes at the candidate the table held when the step began
-        const uint32_t ow = old >> 2;
-        const uint32_t q0 = s_src[ow], q1 = s_src[ow + 1], q2 = s_src[ow + 2], q3 = s_src[ow + 3],
-                       q4 = s_src[ow + 4];
+        const uint32_t oq = old + mis, ow = oq >> 2;
+        const uint32_t q0 = dw(ow), q1 = dw(ow + 1), q2 = dw(ow + 2), q3 = dw(ow + 3), q4 = dw(ow + 4);
         const uint32_t cnt = valid ? (s_scr[ck] >> cs) & 255u : 0u;
         zh_wave_sync();
         if (valid) s_scr[ck] = 0;
-        const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(q1, q0, old);
-        const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(q2, q1, old);
-        const uint32_t x2 = a2 ^ __builtin_amdgcn_alignbyte(q3, q2, old);
-        const uint32_t x3 = a3 ^ __builtin_amdgcn_alignbyte(q4, q3, old);
+        const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(q1, q0, oq);
+        const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(q2, q1, oq);
+        const uint32_t x2 = a2 ^ __builtin_amdgcn_alignbyte(q3, q2, oq);
+        const uint32_t x3 = a3 ^ __builtin_amdgcn_alignbyte(q4, q3, oq);
         // equal leading bytes 0..16, branch-free: ffs(0) - 1 = 0xffffffff -> min(.., 4) = 4
         const uint32_t c0 = min(((uint32_t)__ffs((int)x0) - 1u) >> 3, 4u);
         const uint32_t c1 = min(((uint32_t)__ffs((int)x1) - 1u) >> 3, 4u);
@@ -168,7 +158,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         const uint64_t V = __ballot(valid);  // a prefix of the lanes (pos + step is monotone)
         const uint64_t H = __ballot(valid && x0 == 0);
         // lanes that may share their table slot with another lane of this step (a superset:
-        // the counters see 13 of the 14 hash bits); the general walk below sorts them out exactly
+        // the counters see 12 of the 14 hash bits); the general walk below sorts them out exactly
         const uint64_t C = __ballot(cnt > 1u);
         const uint32_t t = V == ~0ull ? 64u : (uint32_t)__ffsll((long long)~V) - 1u;  // first probe past ip_limit
 
@@ -327,7 +317,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
             const uint32_t o = flen + 4u * lane;
             uint32_t avail = 0;
             if (mp + o < limit) avail = limit - (mp + o) < 4u ? limit - (mp + o) : 4u;
-            const uint32_t x = zh_ld32(s_src, mp + o) ^ zh_ld32(s_src, cand + o);
+            const uint32_t x = ld32(mp + o) ^ ld32(cand + o);
             uint32_t eq = min(((uint32_t)__ffs((int)x) - 1u) >> 3, 4u);
             if (eq > avail) eq = avail;
             const uint64_t stop = __ballot(eq < 4u);  // some lane always stops (limit <= mp + 258)
@@ -371,59 +361,6 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
     }
     if (lane == 0) s_nmatch = nm;
   }
-  // ---- greedy parse, one lane walks the fragment (snappy.nim:76-136 verbatim order;
-  // kept as the A/B reference for the wave-parallel parse above) ----
-  if (serial_parse && lane == 0) {
-    uint32_t nm = 0;
-    if (!huffman_only && n >= 15) {
-      const uint32_t ip_limit = n - 15;
-      uint32_t ip = 1;
-      uint32_t next_hash = (zh_ld32(s_src, ip) * kHashMul) >> shift;
-      bool done = false;
-      while (!done) {
-        uint32_t skip = 32, next_ip = ip, cand = 0;
-        for (;;) {  // probe loop, snappy.nim:86-101
-          ip = next_ip;
-          const uint32_t h = next_hash;
-          const uint32_t step = skip >> 5;
-          skip++;
-          next_ip = ip + step;
-          if (next_ip > ip_limit) { done = true; break; }
-          next_hash = (zh_ld32(s_src, next_ip) * kHashMul) >> shift;
-          cand = s_table[h];
-          s_table[h] = (uint16_t)ip;
-          if (zh_ld32(s_src, ip) == zh_ld32(s_src, cand)) break;
-        }
-        if (done) break;
-        for (;;) {  // match + immediate re-probe, snappy.nim:108-131
-          const uint32_t limit = n < ip + 258u ? n : ip + 258u;
-          uint32_t s1 = cand + 4, s2 = ip + 4;  // internal.nim:251-270
-          while (s2 + 4 <= limit && zh_ld32(s_src, s1) == zh_ld32(s_src, s2)) { s1 += 4; s2 += 4; }
-          while (s2 < limit && zh_ld8(s_src, s1) == zh_ld8(s_src, s2)) { s1++; s2++; }
-          const uint32_t matched = s2 - ip;
-          m_pos[nm] = (uint16_t)ip;
-          m_len[nm] = (uint16_t)matched;
-          m_off[nm] = (uint16_t)(ip - cand);
-          nm++;
-          ip += matched;
-          if (ip >= ip_limit) { done = true; break; }
-          const uint64_t input = zh_ld64(s_src, ip - 1);
-          const uint32_t prev_hash = ((uint32_t)input * kHashMul) >> shift;
-          const uint32_t cur = (uint32_t)(input >> 8);
-          const uint32_t cur_hash = (cur * kHashMul) >> shift;
-          s_table[prev_hash] = (uint16_t)(ip - 1);
-          cand = s_table[cur_hash];
-          s_table[cur_hash] = (uint16_t)ip;
-          if (cur != zh_ld32(s_src, cand)) {
-            next_hash = ((uint32_t)(input >> 16) * kHashMul) >> shift;
-            ip++;
-            break;
-          }
-        }
-      }
-    }
-    s_nmatch = nm;
-  }
   __threadfence_block();
   zh_wave_sync();
   KPROF_MARK(3);
@@ -448,9 +385,15 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   }
   zh_wave_sync();
   // ---- literal histogram (lanes over positions) ----
-  for (uint32_t base = 0; base < n; base += 64) {
-    const uint32_t p = base + lane;
-    if (p < n && !((s_cover[p >> 5] >> (p & 31u)) & 1u)) atomicAdd(&s_hist[zh_ld8(s_src, p)], 1u);
+  for (uint32_t base = 0; base < n; base += 256) {  // four positions per lane and pass
+    const uint32_t p = base + 4u * lane;
+    if (p < n) {
+      const uint32_t w = ld32(p);
+      const uint32_t cov = s_cover[p >> 5] >> (p & 31u);  // p is a multiple of 4: same word for all four
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++)
+        if (p + k < n && !((cov >> k) & 1u)) atomicAdd(&s_hist[(w >> (8u * k)) & 255u], 1u);
+    }
   }
   extra_bits = zh_wave_sum(extra_bits);
   covered = zh_wave_sum(covered);
@@ -472,7 +415,6 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
 extern "C" void zh_launch_l1_match(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
                                    int huffman_only) {
   if (!a.nfrags) return;
-  static const int serial_parse = getenv("ZH_L1_SERIAL") != nullptr;  // A/B switch, see kernel
   hipLaunchKernelGGL(zh_l1_match_kernel, dim3(a.nfrags), dim3(64), 0, stream, d_src, a,
-                     huffman_only, serial_parse);
+                     huffman_only);
 }
