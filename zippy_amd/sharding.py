@@ -1,0 +1,79 @@
+"""Sharding of a batch of independent buffers over the GPUs of one node.
+
+zippy's compress()/uncompress() are pure functions of one buffer (src/zippy.nim:11-16,
+100-104): there is no exchange step inside the path, so a batch shards by contiguous
+ranges of the buffer index and every rank runs the single-GPU engine on its own range
+(SURVEY.md 8e).  The only communication is moving WHOLE buffers when a batch starts
+or has to end on one rank: point-to-point sends of contiguous byte ranges (RCCL
+send/recv over xGMI on GPUs -- root to each peer over its own link -- or gloo on CPU
+in the tests), plus one all_gather of the per-buffer compressed lengths.
+
+One process per GPU (torch.distributed); tensors are uint8, on the device the
+process group works with.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_buffers, rank, world):
+    """Contiguous range [lo, hi) of buffer indices owned by `rank`."""
+    base, extra = divmod(n_buffers, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def scatter_fixed(batch, n_buffers, buf_bytes, root=0, group=None, device=None):
+    """Root holds `batch` (uint8 tensor [n_buffers * buf_bytes]); every rank gets its
+    contiguous shard as a new tensor.  One send per peer, all in flight together."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(n_buffers, rank, world)
+    if rank == root:
+        ops = []
+        for r in range(world):
+            rlo, rhi = shard_range(n_buffers, r, world)
+            if r != root and rhi > rlo:
+                ops.append(dist.P2POp(dist.isend, batch[rlo * buf_bytes:rhi * buf_bytes], r, group))
+        mine = batch[lo * buf_bytes:hi * buf_bytes].clone()
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return mine
+    mine = torch.empty((hi - lo) * buf_bytes, dtype=torch.uint8, device=device)
+    if hi > lo:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, mine, root, group)]):
+            w.wait()
+    return mine
+
+
+def gather_variable(local_bytes, local_lens, root=0, group=None):
+    """Every rank holds its shard's outputs back to back in `local_bytes` (uint8) with
+    per-buffer lengths `local_lens` (int64 tensor).  Returns on root (bytes, lens) for the
+    whole batch in buffer order, elsewhere (None, lens).  The lengths travel in one
+    all_gather; the payloads in one send per peer."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    counts = torch.tensor([local_lens.numel()], dtype=torch.int64, device=local_lens.device)
+    all_counts = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    all_counts = [int(c.item()) for c in all_counts]
+    width = max(all_counts) if all_counts else 0
+    padded = torch.zeros(width, dtype=torch.int64, device=local_lens.device)
+    padded[:local_lens.numel()] = local_lens
+    gathered = [torch.zeros_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded, group=group)
+    lens = torch.cat([g[:c] for g, c in zip(gathered, all_counts)])
+    totals = [int(g[:c].sum().item()) for g, c in zip(gathered, all_counts)]
+    if rank != root:
+        if totals[rank]:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local_bytes[:totals[rank]], root, group)]):
+                w.wait()
+        return None, lens
+    out = torch.empty(sum(totals), dtype=torch.uint8, device=local_bytes.device)
+    ops, off = [], 0
+    for r in range(world):
+        if r == root:
+            out[off:off + totals[r]] = local_bytes[:totals[r]]
+        elif totals[r]:
+            ops.append(dist.P2POp(dist.irecv, out[off:off + totals[r]], r, group))
+        off += totals[r]
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    return out, lens
