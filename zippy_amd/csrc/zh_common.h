@@ -163,6 +163,26 @@ __device__ __forceinline__ uint32_t zh_wave_scan(uint32_t v) {
   return v;
 #endif
 }
+// inclusive running maximum over the 64 lanes
+__device__ __forceinline__ uint32_t zh_wave_scan_max(uint32_t v) {
+#ifdef ZH_EMU
+  const unsigned lane = zh_lane();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(v, o, 64);
+    if (lane >= (unsigned)o && t > v) v = t;
+  }
+  return v;
+#else
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+  return v;
+#endif
+}
 __device__ __forceinline__ uint64_t zh_lanemask_lt() { return (1ull << zh_lane()) - 1ull; }
 
 // unaligned little-endian loads from a dword-typed LDS/global array

@@ -29,9 +29,9 @@ __constant__ zh::LenTables c_len = zh::make_len_tables();
 __constant__ zh::DistTables c_dist = zh::make_dist_tables();
 __constant__ uint8_t c_clcl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-constexpr uint32_t kLitBits = 9, kDistBits = 7;
-constexpr uint32_t kRing = 5120;    // bytes of recent output kept in LDS (a multiple of 1024)
-constexpr uint32_t kFlushAt = 2048;  // pending output that triggers a write-back
+constexpr uint32_t kLitBits = 10, kDistBits = 7;
+constexpr uint32_t kRing = 3072;    // bytes of recent output kept in LDS (a multiple of 1024)
+constexpr uint32_t kFlushAt = 1024;  // pending output that triggers a write-back
 constexpr uint32_t kInWords = 128;   // staging ring of the compressed stream (dwords, power of two)
 
 }  // namespace
@@ -232,6 +232,7 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
   __shared__ uint32_t s_lit[1u << kLitBits];
   __shared__ uint32_t s_dst[1u << kDistBits];  // also hosts the 7-bit code-length table
   __shared__ uint32_t s_in[kInWords];          // staging ring of the compressed stream
+  __shared__ uint8_t s_map[64];                // output byte -> token lane of the current round
   __shared__ HuffTab s_tab_lit, s_tab_dist, s_tab_cl;
   __shared__ uint16_t s_val_lit[288], s_val_dist[32], s_val_cl[20];
   __shared__ uint8_t s_lens[320 + 16];
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
       if (op + len > cap && !count_only) { st = ZH_ERR_DST_TOO_SMALL; break; }
       const uint8_t* raw = reinterpret_cast<const uint8_t*>(asrc) + byte_pos;
       for (uint32_t done = 0; done < len;) {
-        const uint32_t n = len - done < 2048u ? len - done : 2048u;
+        const uint32_t n = len - done < 1024u ? len - done : 1024u;
         if (!count_only) make_room(n);
         zh_wave_sync();
         if (!count_only)
@@ -543,8 +544,70 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
       uint64_t mm = chain & ~litmask;
       KPROF_COUNT(5, __popcll(chain));
       KPROF_MARK(1);
-      // ---- output: literal runs by their lanes, copies in order ----
-      {
+      // ---- output ----
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+      if (total - 1u < 64u) {
+        // 1..64 bytes (the usual round): one lane per OUTPUT byte.  Each byte finds its token
+        // (token starts scattered by output offset, running maximum), literals carry their
+        // value, match bytes read the ring (or written-back output behind it), bytes copied
+        // from this round's own output chase their source down to such a root by pointer
+        // doubling -- inflate.nim:227-250's byte-sequential copy semantics without a loop
+        // over the tokens.
+        const bool is_match = in_chain && !is_lit;
+        if (__ballot(is_match && (uint64_t)distval > op + opre)) {  // inflate.nim:224-225
+          st = ZH_ERR_INVALID_BUFFER;
+        } else if (!count_only && op + total > cap) {
+          st = ZH_ERR_DST_TOO_SMALL;
+        } else if (!count_only) {
+          KPROF_COUNT(6, __popcll(mm));
+          zh_wave_sync();
+          s_map[lane] = 0;
+          zh_wave_sync();
+          if (in_chain) s_map[opre] = (uint8_t)(lane + 1u);
+          zh_wave_sync();
+          const uint32_t tk = zh_wave_scan_max(s_map[lane]);  // token lane + 1 of output byte `lane`
+          const uint32_t j = (tk - 1u) & 63u;
+          const uint32_t f1 = (is_lit ? 0x100u : 0u) | (((e >> 16) & 0xffu) << 16);
+          const uint32_t g1 = (uint32_t)__shfl((int)f1, (int)j, 64);
+          const uint32_t gd = (uint32_t)__shfl((int)distval, (int)j, 64);
+          const bool live = lane < total;
+          uint32_t val = (g1 >> 16) & 0xffu;
+          uint32_t par = lane;  // source byte inside this round (itself: a root)
+          bool far = false;
+          uint32_t back = 0;
+          if (live && !(g1 & 0x100u)) {
+            if (gd <= lane) {
+              par = lane - gd;
+            } else {
+              back = gd - lane;  // bytes before this round's first
+              if (back <= kRing) val = s_win[wrap(rp + kRing - back)];
+              else far = true;
+            }
+          }
+          if (__ballot(far)) {
+            // older than the ring: written back long ago; read through L2 (this CU's L1 may
+            // hold a stale copy of a partially written line)
+            KPROF_COUNT(8, 1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (far) val = __hip_atomic_load(dst + (op - back), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (__ballot(par != lane)) {
+            for (;;) {
+              const uint32_t pp = (uint32_t)__shfl((int)par, (int)par, 64);
+              const bool changed = pp != par;
+              par = pp;
+              if (!__ballot(changed)) break;
+            }
+            val = (uint32_t)__shfl((int)val, (int)par, 64);
+          }
+          zh_wave_sync();
+          if (live) s_win[wrap(rp + lane)] = (uint8_t)val;
+        }
+        op += total;
+        rp = wrap(rp + total);
+        unflushed += total;
+      } else {
+        // long or empty rounds: literal runs by their lanes, copies in order
         const uint32_t rp0 = rp;
         uint32_t done_lanes = 0;  // chain lanes below this bit offset are finished
         while (mm && st == ZH_OK) {
