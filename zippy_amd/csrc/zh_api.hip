@@ -28,8 +28,11 @@ void zh_launch_unwrap(hipStream_t, const uint8_t* d_src, ZhInflateArgs a);
 void zh_launch_inflate(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a);
 void zh_launch_verify(hipStream_t, ZhInflateArgs a, const uint32_t* buf_crc, const uint32_t* buf_adler);
 void zh_launch_l1_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int huffman_only);
-void zh_launch_chain_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
-                           int max_chain, uint16_t* head_scratch);
+void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint16_t* head_scratch,
+                          uint16_t* prevw);
+void zh_launch_chain_search(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
+                            int max_chain, const uint16_t* prevw, uint32_t* best);
+void zh_launch_chain_select(hipStream_t, ZhCompressArgs a, const uint32_t* best);
 void zh_launch_frag_stats(hipStream_t, const uint8_t* d_src, ZhCompressArgs a);
 void zh_launch_huffman(hipStream_t, ZhCompressArgs a);
 void zh_launch_layout(hipStream_t, uint8_t* d_dst, ZhCompressArgs a, const uint32_t* buf_crc,
@@ -176,8 +179,10 @@ struct zh_plan {
   uint32_t npieces = 0;
   uint32_t *piece_crc = nullptr, *piece_adler = nullptr, *piece_len = nullptr;
   uint32_t *buf_crc = nullptr, *buf_adler = nullptr;
-  uint16_t* head_scratch = nullptr;
-  size_t head_bytes = 0;
+  uint16_t* head_scratch = nullptr;  // chain levels: `head` per block, previous-position links and
+  size_t head_bytes = 0;             // best match per position (zh_chain_match.hip)
+  uint16_t* chain_prev = nullptr;
+  uint32_t* chain_best = nullptr;
   uint64_t dst_lo = 0, dst_hi = 0;  // byte range of d_dst covered by the slots
   uint64_t* out_len = nullptr;
   int32_t* status = nullptr;
@@ -320,6 +325,8 @@ extern "C" int zh_plan_compress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
                o_st = ar.reserve(n * 4);
   p->head_bytes = chain ? nb * ((size_t)2 << 17) : 0;
   const size_t o_head = ar.reserve(p->head_bytes);
+  const size_t o_cprev = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 2 : 0);
+  const size_t o_cbest = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 4 : 0);
   ar.reserve(256);
 
   if (hipMalloc(&p->arena, ar.size) != hipSuccess) {
@@ -376,6 +383,8 @@ extern "C" int zh_plan_compress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
   a.out_len = p->out_len = carve<uint64_t>(base, o_olen);
   a.status = p->status = carve<int32_t>(base, o_st);
   p->head_scratch = carve<uint16_t>(base, o_head);
+  p->chain_prev = carve<uint16_t>(base, o_cprev);
+  p->chain_best = carve<uint32_t>(base, o_cbest);
   *out = p;
   return ZH_OK;
 }
@@ -476,8 +485,12 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       const int* cfg = kChainConfig[p->level == -1 ? 6 : p->level];
       prof_mark(p, "memset_head");
       ZH_HIP(ctx, hipMemsetAsync(p->head_scratch, 0, p->head_bytes, s));
-      prof_mark(p, "zh_chain_match_kernel");
-      zh_launch_chain_match(s, d_src, a, cfg[0], cfg[1], cfg[2], p->head_scratch);
+      prof_mark(p, "zh_chain_prev_kernel");
+      zh_launch_chain_prev(s, d_src, a, p->head_scratch, p->chain_prev);
+      prof_mark(p, "zh_chain_search_kernel");
+      zh_launch_chain_search(s, d_src, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+      prof_mark(p, "zh_chain_select_kernel");
+      zh_launch_chain_select(s, a, p->chain_best);
       prof_mark(p, "zh_frag_stats_kernel");
       zh_launch_frag_stats(s, d_src, a);
     }
@@ -826,7 +839,9 @@ extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int lev
   } else {
     const int* cfg = kChainConfig[level == -1 ? 6 : level];
     ZH_HIP(ctx, hipMemsetAsync(p->head_scratch, 0, p->head_bytes, s));
-    zh_launch_chain_match(s, d_src.p, a, cfg[0], cfg[1], cfg[2], p->head_scratch);
+    zh_launch_chain_prev(s, d_src.p, a, p->head_scratch, p->chain_prev);
+    zh_launch_chain_search(s, d_src.p, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+    zh_launch_chain_select(s, a, p->chain_best);
   }
   const size_t nf = a.nfrags;
   std::vector<uint32_t> nmatch(nf);

@@ -1,20 +1,27 @@
-// Hash-chain LZ77 matcher for levels -1 (= 6) and 2..9: one wave per <= 4 MiB
-// block (the reference resets the LZ history per block, lz77.nim:63-64, so the
-// block is the independent unit; there is no 32 KiB fragment independence here).
+// Hash-chain LZ77 matcher for levels -1 (= 6) and 2..9: lz77.nim:10-130 encodeLz77,
+// re-cut so that almost all of it is position-parallel.
 //
-// Replaces lz77.nim:10-130 encodeLz77, decision for decision: 17-bit hash of 4
-// bytes into `head`, 32 K-entry `chain` of window positions, window position 0
-// as the "empty" sentinel, bounded chain walk with the good/nice/chain
-// parameters of internal.nim:177-189, the decreasing-offset wrap test, greedy
-// acceptance of matches longer than 4, hash insertion for the bytes skipped by
-// a match.  The walk state is wave-uniform; the 64 lanes split each candidate
-// comparison (internal.nim:251-270 determineMatchLength) 4 bytes per lane.
-// `chain` (64 KiB) lives in LDS, `head` (256 KiB > LDS) in an HBM scratch slice
-// that stays L2-resident.
+// The reference walks a block once: at every position it inserts the position into
+// `head`/`chain` (also for the bytes a match skips, lz77.nim:121-126), so the chain state
+// a position sees does NOT depend on the parse: it is "every earlier position of the
+// block, newest first, linked by equal 17-bit hash".  Hence
+//   1. zh_chain_prev_kernel   (one wave per <= 4 MiB block, 64 positions per turn, in
+//      order): prevw[P] = the value the reference's `chain[windowPos]` receives when P is
+//      inserted = window position of the latest earlier position with the same hash, 0
+//      when there is none (the reference's "empty" sentinel, lz77.nim:88) -- stale
+//      entries older than the window included, exactly like its never-cleared `head`;
+//   2. zh_chain_search_kernel (one THREAD per position): the reference's bounded chain
+//      walk (good / nice / chain of internal.nim:177-189, the decreasing-offset wrap test,
+//      the self-loop test, determineMatchLength) with `chain[w]` read as prevw[] of the
+//      position that owns window slot w at that time -> best (length, offset) per position;
+//   3. zh_chain_select_kernel (one wave per block): the greedy parse itself
+//      (lz77.nim:73-130): accept matches longer than 4, hop over them, literals otherwise;
+//      64 positions per turn through v_readlane hops.
+// The match list / fragment bookkeeping handed to the Huffman and emission kernels is
+// the same as the BestSpeed matcher's; output is byte-identical to the serial walk.
 //
 // zh_frag_stats_kernel then derives the per-fragment histograms from the match
-// list (the addLiteral/addCopy bookkeeping of lz77.nim:19-50) for the matchers
-// that do not fuse it.
+// list (the addLiteral/addCopy bookkeeping of lz77.nim:19-50).
 #include "zh_common.h"
 #include "zh_tables.h"
 
@@ -24,25 +31,138 @@ __constant__ zh::DistTables c_dist = zh::make_dist_tables();
 constexpr uint32_t kHashMul = 0x1e35a7bdu;
 constexpr uint32_t kHashBits = 17;
 
-__device__ inline uint32_t load32(const uint8_t* p) {
-  return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
+__device__ inline uint64_t load64u(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+__device__ inline uint32_t load32u(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
 }
 }  // namespace
 
-__global__ __launch_bounds__(64) void zh_chain_match_kernel(const uint8_t* __restrict__ d_src,
-                                                            ZhCompressArgs a, int good, int nice,
-                                                            int max_chain,
-                                                            uint16_t* __restrict__ head_scratch) {
-  __shared__ uint16_t s_chain[32768];
+// ---- 1. previous same-hash window position of every inserted position ----
+__global__ __launch_bounds__(64) void zh_chain_prev_kernel(const uint8_t* __restrict__ d_src,
+                                                           ZhCompressArgs a,
+                                                           uint16_t* __restrict__ head_scratch,
+                                                           uint16_t* __restrict__ prevw) {
+  __shared__ uint32_t s_cnt[1024];  // byte-wide counters of the group's hashes (12 bits)
   const unsigned lane = zh_lane();
   const uint32_t b = blockIdx.x;
   const ZhBlockDesc bd = a.blocks[b];
-  const uint8_t* src = d_src + bd.src_off;  // block-relative addressing below
+  const uint8_t* src = d_src + bd.src_off;
   const uint32_t block_len = (uint32_t)bd.len;
   uint16_t* head = head_scratch + ((size_t)b << kHashBits);  // zeroed by the host before launch
-
-  for (uint32_t i = lane; i < 32768; i += 64) s_chain[i] = 0;
+  uint16_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  const uint32_t nins = block_len > 4u ? block_len - 4u : 0u;  // positions with pos + 4 < block end
+  for (uint32_t i = lane; i < 1024; i += 64) s_cnt[i] = 0;
   zh_wave_sync();
+  for (uint32_t base = 0; base < nins; base += 64) {
+    const uint32_t P = base + lane;
+    const bool valid = P < nins;
+    const uint32_t h = valid ? (load32u(src + P) * kHashMul) >> (32 - kHashBits) : 0u;
+    // `head` lives in HBM/L2; read and written past this CU's L1 so that the next turn sees it
+    uint32_t old = valid ? __hip_atomic_load(head + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const uint32_t ck = (h & 4095u) >> 2, cs = (h & 3u) * 8u;
+    if (valid) atomicAdd(&s_cnt[ck], 1u << cs);
+    zh_wave_sync();
+    const uint32_t cnt = valid ? (s_cnt[ck] >> cs) & 255u : 0u;
+    zh_wave_sync();
+    if (valid) s_cnt[ck] = 0;
+    bool last = true;  // last position of the group with this hash: it ends up in `head`
+    uint64_t cc = __ballot(cnt > 1u);
+    while (cc) {  // groups of lanes that may share a hash: resolve exactly, in position order
+      const uint32_t jx = (uint32_t)__ffsll((long long)cc) - 1u;
+      const uint32_t hj = __builtin_amdgcn_readlane(h, jx);
+      const uint64_t same = __ballot(valid && h == hj);
+      if ((same >> lane) & 1ull) {
+        const uint64_t below = same & zh_lanemask_lt();
+        if (below) old = (base + 63u - (uint32_t)__clzll((long long)below)) & 32767u;
+        last = (same >> lane) >> 1 == 0;
+      }
+      cc &= ~same;
+    }
+    if (valid) {
+      pw[P] = (uint16_t)old;
+      if (last) __hip_atomic_store(head + h, (uint16_t)(P & 32767u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    zh_wave_sync();
+  }
+}
+
+// ---- 2. best match of every position (lz77.nim:83-112) ----
+__global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __restrict__ d_src,
+                                                              ZhCompressArgs a, int good, int nice,
+                                                              int max_chain,
+                                                              const uint16_t* __restrict__ prevw,
+                                                              uint32_t* __restrict__ best) {
+  const uint32_t f = blockIdx.x / (ZH_FRAG_SIZE / 256u);
+  const uint32_t local = (blockIdx.x % (ZH_FRAG_SIZE / 256u)) * 256u + threadIdx.x;
+  const ZhFragDesc fd = a.frags[f];
+  if (local >= fd.len) return;
+  const ZhBlockDesc bd = a.blocks[fd.block];
+  const uint8_t* src = d_src + bd.src_off;
+  const uint32_t block_len = (uint32_t)bd.len;
+  const uint32_t pos = (f - bd.first_frag) * ZH_FRAG_SIZE + local;  // block-relative
+  const uint16_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  uint32_t result = 0;
+  if (pos + 4u < block_len) {
+    const uint32_t window_pos = pos & 32767u;
+    const uint32_t limit = block_len < pos + 258u ? block_len : pos + 258u;
+    uint32_t hash_pos = pw[pos];
+    int tries = max_chain;
+    int prev_offset = 0, longest_offset = 0, longest_len = 0;
+    while (tries > 0 && hash_pos != 0) {
+      tries--;
+      const int offset = hash_pos <= window_pos ? (int)(window_pos - hash_pos)
+                                                : (int)(window_pos - hash_pos + 32768u);
+      if (offset <= 0 || offset < prev_offset) break;
+      prev_offset = offset;
+      // determineMatchLength(src, pos - offset, pos, limit), internal.nim:251-270
+      const uint8_t* s1 = src + (pos - (uint32_t)offset);
+      uint32_t s2 = pos;
+      int match_len = 0;
+      bool done = false;
+      while (s2 + 8u <= limit) {
+        const uint64_t x = load64u(src + s2) ^ load64u(s1 + match_len);
+        if (x != 0) {
+          match_len += (int)((uint32_t)__builtin_ctzll(x) >> 3);
+          done = true;
+          break;
+        }
+        s2 += 8;
+        match_len += 8;
+      }
+      if (!done)
+        while (s2 < limit && src[s2] == s1[match_len]) {
+          s2++;
+          match_len++;
+        }
+      if (match_len > longest_len) {
+        if (match_len >= good) tries >>= 2;
+        longest_len = match_len;
+        longest_offset = offset;
+      }
+      // chain[hashPos]: the value stored when the position in that window slot was inserted
+      const uint32_t nxt = pw[pos - (uint32_t)offset];
+      if (longest_len >= nice || hash_pos == nxt) break;
+      hash_pos = nxt;
+    }
+    if (longest_len > 4) result = (uint32_t)longest_len | ((uint32_t)longest_offset << 16);  // lz77.nim:114
+  }
+  best[(size_t)bd.first_frag * ZH_FRAG_SIZE + pos] = result;
+}
+
+// ---- 3. the greedy parse (lz77.nim:73-130) over the per-position results ----
+__global__ __launch_bounds__(64) void zh_chain_select_kernel(ZhCompressArgs a,
+                                                             const uint32_t* __restrict__ best) {
+  const unsigned lane = zh_lane();
+  const uint32_t b = blockIdx.x;
+  const ZhBlockDesc bd = a.blocks[b];
+  const uint32_t block_len = (uint32_t)bd.len;
+  const uint32_t* bst = best + (size_t)bd.first_frag * ZH_FRAG_SIZE;
 
   uint32_t cur_frag = 0, frag_matches = 0;  // fragment currently receiving matches
   auto close_frags_until = [&](uint32_t frag) {  // publish counts of fragments [cur_frag, frag)
@@ -52,90 +172,37 @@ __global__ __launch_bounds__(64) void zh_chain_match_kernel(const uint8_t* __res
       cur_frag++;
     }
   };
-  if (lane == 0)
-    for (uint32_t k = 0; k < bd.nfrag; k++) a.f_spill[bd.first_frag + k] = 0;
+  for (uint32_t k = lane; k < bd.nfrag; k += 64) a.f_spill[bd.first_frag + k] = 0;
+  zh_wave_sync();
 
   uint32_t pos = 0;
-  if (block_len > 4) {  // lz77.nim:54-56: blocks of <= 4 bytes are all literals
-    while (pos < block_len) {
-      if (pos + 4 >= block_len) break;  // lz77.nim:74-76: the tail is literals
-      const uint32_t window_pos = pos & 32767u;
-      const uint32_t hash = (load32(src + pos) * kHashMul) >> (32 - kHashBits);
-      // updateChain (lz77.nim:69-71)
-      uint32_t hash_pos = zh_bcast(head[hash]);
-      zh_wave_sync();
-      if (lane == 0) {
-        s_chain[window_pos] = (uint16_t)hash_pos;
-        head[hash] = (uint16_t)window_pos;
-      }
-      zh_wave_sync();
-
-      const uint32_t limit = block_len < pos + 258u ? block_len : pos + 258u;
-      int tries = max_chain;
-      int prev_offset = 0, longest_offset = 0, longest_len = 0;
-      while (tries > 0 && hash_pos != 0) {  // lz77.nim:88-112
-        tries--;
-        const int offset = hash_pos <= window_pos ? (int)(window_pos - hash_pos)
-                                                  : (int)(window_pos - hash_pos + 32768u);
-        if (offset <= 0 || offset < prev_offset) break;
-        prev_offset = offset;
-        // determineMatchLength(src, pos - offset, pos, limit), 4 bytes per lane
-        int match_len = 0;
-        bool stopped = false;
-        for (uint32_t base = 0; pos + base < limit; base += 256) {
-          const uint32_t o = base + lane * 4;
-          uint32_t avail = 0;
-          if (pos + o < limit) avail = limit - (pos + o) < 4 ? limit - (pos + o) : 4;
-          uint32_t eq = 0;
-          while (eq < avail && src[pos + o + eq] == src[pos - offset + o + eq]) eq++;
-          const uint64_t stop = __ballot(eq < 4);  // mismatch, or this lane hit the limit
-          if (stop) {
-            const uint32_t fl = (uint32_t)__ffsll((long long)stop) - 1;
-            match_len = (int)(base + fl * 4 + __shfl(eq, fl, 64));
-            stopped = true;
-            break;
-          }
-        }
-        if (!stopped) match_len = (int)(limit - pos);
-        if (match_len > longest_len) {
-          if (match_len >= good) tries >>= 2;
-          longest_len = match_len;
-          longest_offset = offset;
-        }
-        const uint32_t nxt = zh_bcast(s_chain[hash_pos]);
-        if (longest_len >= nice || hash_pos == nxt) break;
-        hash_pos = nxt;
-      }
-
-      if (longest_len > 4) {  // lz77.nim:114
-        const uint32_t frag = pos >> 15;
+  // lz77.nim:54-56,74-76: the last four positions (and blocks of <= 4 bytes) are literals
+  const uint32_t nmain = block_len > 4u ? block_len - 4u : 0u;
+  while (pos < nmain) {
+    const uint32_t base = pos & ~63u;
+    const uint32_t v = base + lane < nmain ? bst[base + lane] : 0u;
+    uint32_t cur = pos - base;
+    while (cur < 64u && base + cur < nmain) {
+      const uint32_t r = __builtin_amdgcn_readlane(v, cur);
+      const uint32_t len = r & 0xffffu;
+      if (len) {
+        const uint32_t p = base + cur, frag = p >> 15;
         close_frags_until(frag);
         if (lane == 0) {
           const size_t slot = (size_t)(bd.first_frag + frag) * ZH_MAX_MATCHES_PER_FRAG + frag_matches;
-          a.m_pos[slot] = (uint16_t)(pos & 32767u);
-          a.m_len[slot] = (uint16_t)longest_len;
-          a.m_off[slot] = (uint16_t)longest_offset;
-          const uint32_t end = pos + (uint32_t)longest_len;
+          a.m_pos[slot] = (uint16_t)(p & 32767u);
+          a.m_len[slot] = (uint16_t)len;
+          a.m_off[slot] = (uint16_t)(r >> 16);
+          const uint32_t end = p + len;
           if ((end - 1) >> 15 != frag) a.f_spill[bd.first_frag + frag + 1] = end & 32767u;
         }
         frag_matches++;
-        for (int i = 1; i < longest_len; i++) {  // lz77.nim:121-126
-          pos++;
-          if (pos + 4 < block_len) {
-            const uint32_t wp = pos & 32767u;
-            const uint32_t h = (load32(src + pos) * kHashMul) >> (32 - kHashBits);
-            const uint32_t old = zh_bcast(head[h]);
-            zh_wave_sync();
-            if (lane == 0) {
-              s_chain[wp] = (uint16_t)old;
-              head[h] = (uint16_t)wp;
-            }
-            zh_wave_sync();
-          }
-        }
+        cur += len;
+      } else {
+        cur++;
       }
-      pos++;
     }
+    pos = base + cur;
   }
   close_frags_until(bd.nfrag);
 }
@@ -202,11 +269,22 @@ __global__ __launch_bounds__(64) void zh_frag_stats_kernel(const uint8_t* __rest
   }
 }
 
-extern "C" void zh_launch_chain_match(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
-                                      int good, int nice, int max_chain, uint16_t* head_scratch) {
+extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
+                                     uint16_t* head_scratch, uint16_t* prevw) {
   if (!a.nblocks) return;
-  hipLaunchKernelGGL(zh_chain_match_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a, good,
-                     nice, max_chain, head_scratch);
+  hipLaunchKernelGGL(zh_chain_prev_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a, head_scratch,
+                     prevw);
+}
+extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
+                                       int good, int nice, int max_chain, const uint16_t* prevw,
+                                       uint32_t* best) {
+  if (!a.nfrags) return;
+  hipLaunchKernelGGL(zh_chain_search_kernel, dim3(a.nfrags * (ZH_FRAG_SIZE / 256u)), dim3(256), 0, stream,
+                     d_src, a, good, nice, max_chain, prevw, best);
+}
+extern "C" void zh_launch_chain_select(hipStream_t stream, ZhCompressArgs a, const uint32_t* best) {
+  if (!a.nblocks) return;
+  hipLaunchKernelGGL(zh_chain_select_kernel, dim3(a.nblocks), dim3(64), 0, stream, a, best);
 }
 extern "C" void zh_launch_frag_stats(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a) {
   if (!a.nfrags) return;
