@@ -58,6 +58,21 @@ def cpu_baseline(bufs, level, cores):
     }
 
 
+def hbm_traffic(kernel, n, size):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/
+    (tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs of this same command, units and
+    gfx950 corrections as the MI355X guide prescribes); None when no pass matches this workload."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        if t.get("buffers") == n and t.get("buffer_bytes") == size:
+            return t["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,12 +205,12 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 3),
                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 6),
-                "traffic": None,
+                "traffic": hbm_traffic(dom, n, size),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": round(avg[dom], 4),
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             cores = min(os.cpu_count() or 1, 32)
             per_core = max(2, min(24, (16 << 20) // size * 2))
             sample = [host[i].tobytes() for i in range(min(n, cores * per_core))]

@@ -176,52 +176,88 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         // v_readlane hops, one per match, in a loop small enough to stay in the instruction
         // buffer (a taken branch to other code costs a lone wave ~50 cycles, the loop edge
         // next to nothing); anything else stops the chain for one turn of the general walk.
+        // hop word: bits 0-5 lane g of the match (or 63), bit 6 "there is a match at g",
+        // bits 8-14 the lane the walk resumes at, bit 15 "not for the chain".  Besides matches
+        // the chain can take "nothing but misses up to lane 63": the literal run then goes on
+        // in the next step (only from lanes >= 32, so that it cannot reach its 32nd probe here).
         uint32_t hop = 0x8000u;
         if (dense) {
           const uint64_t ev = (H | C) >> lane;
           const uint32_t d = ev ? (uint32_t)__ffsll((long long)ev) - 1u : 64u;
           const uint32_t info = eqlen | ((uint32_t)((C >> lane) & 1ull) << 5);
           const uint32_t gi = (uint32_t)__shfl((int)info, (int)((lane + d) & 63u), 64);
-          if (d < 32u && gi < 16u) hop = (lane + d) | ((lane + d + gi) << 8);
+          if (d < 32u && gi < 16u) hop = (lane + d) | 0x40u | ((lane + d + gi) << 8);
+          else if (!ev && lane >= 32u) hop = 63u | (64u << 8);
         }
         const uint32_t tt = ip_limit > W0 ? ip_limit - W0 : 0u;  // dense: first lane past ip_limit
         for (;;) {
-          if (dense && (reprobe || K == 0u) && i < 64u) {
+          if (dense && i < 64u) {
             uint64_t sel = 0;  // match lanes of this chain
-            uint32_t cur = i;
+            uint32_t cur = i, tv = 0;
+            bool took = false;
             KPROF_MARK(3);
-            while (cur < 64u) {
-              const uint32_t tv = __builtin_amdgcn_readlane(hop, cur);
-              if (tv & 0x8000u) break;
-              const uint32_t g = tv & 63u, nxt = tv >> 8;
-              sel |= 1ull << g;
-              ins |= (~0ull << cur) & (~0ull >> (63u - g));  // probes cur..g (table[h] = ip)
-              if (nxt <= 64u) ins |= 1ull << (nxt - 1u);      // ip-1 behind the match (snappy.nim:126)
-              cur = nxt;
-              if (cur >= tt) break;  // snappy.nim:118-120
+            // a run that continues from the previous step may only hop if it finds its match
+            // before its 32nd probe (hops behind a match need d < 32 only, which the table has)
+            if (!reprobe && K) {
+              tv = __builtin_amdgcn_readlane(hop, cur);
+              if ((tv & 0x8000u) || !(tv & 0x40u) || K + ((tv & 63u) - cur) > 31u) cur = 64;
+            }
+            if (cur < 64u) {
+              while (cur < 64u) {
+                tv = __builtin_amdgcn_readlane(hop, cur);
+                if (tv & 0x8000u) break;
+                const uint32_t g = tv & 63u, nxt = tv >> 8;
+                sel |= (uint64_t)((tv >> 6) & 1u) << g;
+                ins |= (~0ull << cur) & (~0ull >> (63u - g));  // probes cur..g (table[h] = ip)
+                if (nxt <= 64u) ins |= 1ull << (nxt - 1u);      // ip-1 behind the match (snappy.nim:126)
+                if (!(tv & 0x40u)) {  // misses to the end of the step: only if ip_limit is not in it
+                  if (tt < 64u) {
+                    tv = 0x8000u;
+                    break;
+                  }
+                  K = (took || reprobe ? 63u : K + 64u) - cur;  // probes cur+1..63, or K more from cur
+                }
+                took = true;
+                cur = nxt;
+                if (cur >= tt) break;  // snappy.nim:118-120
+              }
+            } else {
+              cur = i;
             }
             KPROF_MARK(2);
-            if (sel) {
-              KPROF_COUNT(8, __popcll(sel));
-              if ((sel >> lane) & 1ull) {  // every match lane files its own record
-                const uint32_t k = nm + (uint32_t)__popcll(sel & zh_lanemask_lt());
-                m_pos[k] = (uint16_t)pos;
-                m_len[k] = (uint16_t)eqlen;
-                m_off[k] = (uint16_t)(pos - old);
+            if (took) {
+              if (sel) {
+                KPROF_COUNT(8, __popcll(sel));
+                if ((sel >> lane) & 1ull) {  // every match lane files its own record
+                  const uint32_t k = nm + (uint32_t)__popcll(sel & zh_lanemask_lt());
+                  m_pos[k] = (uint16_t)pos;
+                  m_len[k] = (uint16_t)eqlen;
+                  m_off[k] = (uint16_t)(pos - old);
+                }
+                nm += (uint32_t)__popcll(sel);
               }
-              nm += (uint32_t)__popcll(sel);
-              K = 0;
-              if (cur >= tt) {  // snappy.nim:118-120
-                finished = true;
+              if (tv & 0x40u) {  // the chain ends behind a match
+                K = 0;
+                if (cur >= tt) {  // snappy.nim:118-120
+                  finished = true;
+                  break;
+                }
+                if (cur >= 64u) {
+                  post = true;
+                  ip = W0 + cur;
+                  break;
+                }
+                i = cur;
+                reprobe = true;
+              } else if (!(tv & 0x8000u)) {  // ... or in a literal run at the end of the step
+                post = false;
+                ip = W0 + 64u;
                 break;
+              } else {  // (ip_limit inside the step: the general walk finishes it)
+                K = 0;
+                i = cur;
+                reprobe = true;
               }
-              if (cur >= 64u) {
-                post = true;
-                ip = W0 + cur;
-                break;
-              }
-              i = cur;
-              reprobe = true;
             }
           }
           KPROF_COUNT(9, 1);
