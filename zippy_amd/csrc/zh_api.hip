@@ -27,7 +27,9 @@ void zh_launch_checksum_combine(hipStream_t, const ZhBufDesc* bufs, uint32_t nbu
 void zh_launch_unwrap(hipStream_t, const uint8_t* d_src, ZhInflateArgs a);
 void zh_launch_inflate(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a);
 void zh_launch_verify(hipStream_t, ZhInflateArgs a, const uint32_t* buf_crc, const uint32_t* buf_adler);
-void zh_launch_l1_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int huffman_only);
+void zh_launch_l1_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int huffman_only,
+                        uint16_t* table_pool);
+uint32_t zh_l1_table_slots(void);
 void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint16_t* head_scratch,
                           uint16_t* prevw);
 void zh_launch_chain_search(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
@@ -181,6 +183,7 @@ struct zh_plan {
   uint32_t *buf_crc = nullptr, *buf_adler = nullptr;
   uint16_t* head_scratch = nullptr;  // chain levels: `head` per block, previous-position links and
   size_t head_bytes = 0;             // best match per position (zh_chain_match.hip)
+  uint16_t* l1_tables = nullptr;  // BestSpeed: pool of per-wave hash tables (zh_l1_match.hip)
   uint16_t* chain_prev = nullptr;
   uint32_t* chain_best = nullptr;
   uint64_t dst_lo = 0, dst_hi = 0;  // byte range of d_dst covered by the slots
@@ -325,6 +328,7 @@ extern "C" int zh_plan_compress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
                o_st = ar.reserve(n * 4);
   p->head_bytes = chain ? nb * ((size_t)2 << 17) : 0;
   const size_t o_head = ar.reserve(p->head_bytes);
+  const size_t o_l1tab = ar.reserve(level == 1 ? (size_t)zh_l1_table_slots() * 32768 : 0);
   const size_t o_cprev = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 2 : 0);
   const size_t o_cbest = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 4 : 0);
   ar.reserve(256);
@@ -383,6 +387,7 @@ extern "C" int zh_plan_compress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
   a.out_len = p->out_len = carve<uint64_t>(base, o_olen);
   a.status = p->status = carve<int32_t>(base, o_st);
   p->head_scratch = carve<uint16_t>(base, o_head);
+  p->l1_tables = carve<uint16_t>(base, o_l1tab);
   p->chain_prev = carve<uint16_t>(base, o_cprev);
   p->chain_best = carve<uint32_t>(base, o_cbest);
   *out = p;
@@ -480,7 +485,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     ZH_HIP(ctx, hipMemsetAsync(d_dst + p->dst_lo, 0, p->dst_hi - p->dst_lo, s));
     if (p->level == 1 || p->level == -2) {
       prof_mark(p, "zh_l1_match_kernel");
-      zh_launch_l1_match(s, d_src, a, p->level == -2);
+      zh_launch_l1_match(s, d_src, a, p->level == -2, p->l1_tables);
     } else if (p->level != 0) {
       const int* cfg = kChainConfig[p->level == -1 ? 6 : p->level];
       prof_mark(p, "memset_head");
@@ -835,7 +840,7 @@ extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int lev
   hipStream_t s = ctx->stream;
   const ZhCompressArgs& a = p->ca;
   if (level == 1 || level == -2) {
-    zh_launch_l1_match(s, d_src.p, a, level == -2);
+    zh_launch_l1_match(s, d_src.p, a, level == -2, p->l1_tables);
   } else {
     const int* cfg = kChainConfig[level == -1 ? 6 : level];
     ZH_HIP(ctx, hipMemsetAsync(p->head_scratch, 0, p->head_bytes, s));

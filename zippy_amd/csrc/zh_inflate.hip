@@ -504,48 +504,89 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
     }
     KPROF_MARK(0);
 
-    for (;;) {  // inflate.nim:173-250, one round = 64 bit positions
+    for (;;) {  // inflate.nim:173-250, one round = up to 128 bit positions
       ensure();
       KPROF_COUNT(7, 1);
-      // ---- every lane decodes the token that would start at bit bp + lane ----
-      const uint32_t bl = (uint32_t)bp + lane;  // only bits 0..4 and the dword index delta matter
-      const uint32_t wi = (uint32_t)((bp + lane) >> 5), sh = bl & 31u;
+      // ---- every lane decodes the tokens that would start at bits bp + lane (window A)
+      // and bp + 64 + lane (window B): two independent dependency chains per lane, so the
+      // second costs little latency; B is used when A's chain runs into it cleanly and
+      // both together make at most 64 bytes ----
+      const uint32_t wi = (uint32_t)((bp + lane) >> 5), sh = ((uint32_t)bp + lane) & 31u;
       const uint32_t d0 = s_in[wi & (kInWords - 1u)], d1 = s_in[(wi + 1u) & (kInWords - 1u)],
-                     d2 = s_in[(wi + 2u) & (kInWords - 1u)];
-      const uint32_t v_lo = zh_alignbit(d1, d0, sh), v_hi = zh_alignbit(d2, d1, sh);
-      const uint64_t v = (uint64_t)v_lo | ((uint64_t)v_hi << 32);
-      const uint32_t e = s_lit[v_lo & ((1u << kLitBits) - 1u)];
-      const uint32_t L = e & 15u, eb = (e >> 4) & 15u;
-      const bool is_lit = (e & 0x8000u) != 0;
-      const uint32_t lenval = (e >> 16) + ((v_lo >> L) & ((1u << eb) - 1u));
-      const uint32_t o2 = L + eb;  // <= 15
-      const uint32_t de = s_dst[(uint32_t)(v >> o2) & ((1u << kDistBits) - 1u)];
-      const uint32_t o3 = o2 + (de & 15u), deb = (de >> 4) & 15u;
-      const uint32_t distval = (de >> 16) + ((uint32_t)(v >> o3) & ((1u << deb) - 1u));
-      uint32_t tbits;  // bits of the whole token; 0x8000: not decodable here
-      if (is_lit) tbits = L;
-      else if (e != 0 && ((e >> 8) & 3u) == kKindBase && de != 0 && ((de >> 8) & 3u) == kKindBase) tbits = o3 + deb;
-      else tbits = 0x8000u;
-      const uint32_t outlen = is_lit ? 1u : lenval;
+                     d2 = s_in[(wi + 2u) & (kInWords - 1u)], d3 = s_in[(wi + 3u) & (kInWords - 1u)],
+                     d4 = s_in[(wi + 4u) & (kInWords - 1u)];
+      struct Tok {
+        uint32_t v_lo, v_hi, e, tbits, outlen, distval;
+        bool is_lit;
+      };
+      auto decode_tok = [&](uint32_t v_lo, uint32_t v_hi) -> Tok {
+        Tok t;
+        t.v_lo = v_lo;
+        t.v_hi = v_hi;
+        const uint64_t v = (uint64_t)v_lo | ((uint64_t)v_hi << 32);
+        const uint32_t e = s_lit[v_lo & ((1u << kLitBits) - 1u)];
+        const uint32_t L = e & 15u, eb = (e >> 4) & 15u;
+        t.e = e;
+        t.is_lit = (e & 0x8000u) != 0;
+        const uint32_t lenval = (e >> 16) + ((v_lo >> L) & ((1u << eb) - 1u));
+        const uint32_t o2 = L + eb;  // <= 15
+        const uint32_t de = s_dst[(uint32_t)(v >> o2) & ((1u << kDistBits) - 1u)];
+        const uint32_t o3 = o2 + (de & 15u), deb = (de >> 4) & 15u;
+        t.distval = (de >> 16) + ((uint32_t)(v >> o3) & ((1u << deb) - 1u));
+        if (t.is_lit) t.tbits = L;  // bits of the whole token; 0x8000: not decodable here
+        else if (e != 0 && ((e >> 8) & 3u) == kKindBase && de != 0 && ((de >> 8) & 3u) == kKindBase) t.tbits = o3 + deb;
+        else t.tbits = 0x8000u;
+        t.outlen = t.is_lit ? 1u : lenval;
+        return t;
+      };
+      const Tok A = decode_tok(zh_alignbit(d1, d0, sh), zh_alignbit(d2, d1, sh));
+      const Tok B = decode_tok(zh_alignbit(d3, d2, sh), zh_alignbit(d4, d3, sh));
 
       // ---- the chain of real token starts ----
-      uint64_t chain = 0;
+      uint64_t chain = 0, chainB = 0;
       uint32_t pos = 0;
       while (pos < 64u) {
-        const uint32_t tv = __builtin_amdgcn_readlane(tbits, pos);
+        const uint32_t tv = __builtin_amdgcn_readlane(A.tbits, pos);
         if (tv & 0x8000u) break;
         chain |= 1ull << pos;
         pos += tv;
       }
+      const uint32_t posA = pos;
+      bool useB = pos >= 64u;
+      if (useB) {
+        while (pos < 128u) {
+          const uint32_t tv = __builtin_amdgcn_readlane(B.tbits, pos - 64u);
+          if (tv & 0x8000u) break;
+          chainB |= 1ull << (pos - 64u);
+          pos += tv;
+        }
+      }
       const bool in_chain = (chain >> lane) & 1ull;
-      const uint32_t incl = zh_wave_scan(in_chain ? outlen : 0u);
-      const uint32_t opre = incl - (in_chain ? outlen : 0u);  // output offset of this lane's token
-      const uint64_t litmask = chain & __ballot(is_lit);
+      const uint32_t incl = zh_wave_scan(in_chain ? A.outlen : 0u);
+      const uint32_t opre = incl - (in_chain ? A.outlen : 0u);  // output offset of this lane's A token
+      const uint32_t totalA = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+      uint32_t opreB = 0, totalB = 0;
+      bool in_chainB = false;
+      if (useB) {
+        in_chainB = (chainB >> lane) & 1ull;
+        const uint32_t inclB = zh_wave_scan(in_chainB ? B.outlen : 0u);
+        totalB = (uint32_t)__builtin_amdgcn_readlane(inclB, 63);
+        opreB = totalA + inclB - (in_chainB ? B.outlen : 0u);
+        if (totalA + totalB > 64u || totalA == 0u) {  // window A alone this time
+          useB = false;
+          in_chainB = false;
+          chainB = 0;
+          totalB = 0;
+          pos = posA;
+        }
+      }
+      const uint64_t litmask = chain & __ballot(A.is_lit);
       uint64_t mm = chain & ~litmask;
-      KPROF_COUNT(5, __popcll(chain));
+      KPROF_COUNT(5, __popcll(chain) + __popcll(chainB));
       KPROF_MARK(1);
       // ---- output ----
-      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+      const uint32_t total = totalA + totalB;
+      const uint32_t e = A.e, lenval = A.outlen, distval = A.distval;  // (names of the long-round path)
       if (total - 1u < 64u) {
         // 1..64 bytes (the usual round): one lane per OUTPUT byte.  Each byte finds its token
         // (token starts scattered by output offset, running maximum), literals carry their
@@ -553,23 +594,35 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
         // from this round's own output chase their source down to such a root by pointer
         // doubling -- inflate.nim:227-250's byte-sequential copy semantics without a loop
         // over the tokens.
-        const bool is_match = in_chain && !is_lit;
-        if (__ballot(is_match && (uint64_t)distval > op + opre)) {  // inflate.nim:224-225
+        const bool is_match = in_chain && !A.is_lit, is_matchB = in_chainB && !B.is_lit;
+        if (__ballot((is_match && (uint64_t)A.distval > op + opre) ||
+                     (is_matchB && (uint64_t)B.distval > op + opreB))) {  // inflate.nim:224-225
           st = ZH_ERR_INVALID_BUFFER;
         } else if (!count_only && op + total > cap) {
           st = ZH_ERR_DST_TOO_SMALL;
         } else if (!count_only) {
-          KPROF_COUNT(6, __popcll(mm));
+          KPROF_COUNT(6, __popcll(mm) + __popcll(__ballot(is_matchB)));
           zh_wave_sync();
           s_map[lane] = 0;
           zh_wave_sync();
           if (in_chain) s_map[opre] = (uint8_t)(lane + 1u);
+          if (in_chainB) s_map[opreB] = (uint8_t)(lane + 65u);
           zh_wave_sync();
-          const uint32_t tk = zh_wave_scan_max(s_map[lane]);  // token lane + 1 of output byte `lane`
+          const uint32_t tk = zh_wave_scan_max(s_map[lane]);  // token (window, lane) + 1 of output byte `lane`
           const uint32_t j = (tk - 1u) & 63u;
-          const uint32_t f1 = (is_lit ? 0x100u : 0u) | (((e >> 16) & 0xffu) << 16);
-          const uint32_t g1 = (uint32_t)__shfl((int)f1, (int)j, 64);
-          const uint32_t gd = (uint32_t)__shfl((int)distval, (int)j, 64);
+          const bool fromB = tk > 64u;
+          const uint32_t f1 = (A.is_lit ? 0x100u : 0u) | (((A.e >> 16) & 0xffu) << 16);
+          uint32_t g1 = (uint32_t)__shfl((int)f1, (int)j, 64);
+          uint32_t gd = (uint32_t)__shfl((int)A.distval, (int)j, 64);
+          if (useB) {
+            const uint32_t f1B = (B.is_lit ? 0x100u : 0u) | (((B.e >> 16) & 0xffu) << 16);
+            const uint32_t g1B = (uint32_t)__shfl((int)f1B, (int)j, 64);
+            const uint32_t gdB = (uint32_t)__shfl((int)B.distval, (int)j, 64);
+            if (fromB) {
+              g1 = g1B;
+              gd = gdB;
+            }
+          }
           const bool live = lane < total;
           uint32_t val = (g1 >> 16) & 0xffu;
           uint32_t par = lane;  // source byte inside this round (itself: a root)
@@ -607,7 +660,7 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
         rp = wrap(rp + total);
         unflushed += total;
       } else {
-        // long or empty rounds: literal runs by their lanes, copies in order
+        // long or empty rounds (window A only): literal runs by their lanes, copies in order
         const uint32_t rp0 = rp;
         uint32_t done_lanes = 0;  // chain lanes below this bit offset are finished
         while (mm && st == ZH_OK) {
@@ -645,13 +698,21 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
       if (st != ZH_OK) break;
       bp += pos;
       bool block_done = false;
-      if (pos < 64u) {
+      if (pos < 64u || (useB && pos < 128u)) {
         // ---- the token at bp stopped the chain: decode it alone (inflate.nim:67-102) ----
         KPROF_COUNT(9, 1);
         // (the builtin returns int: widen through uint32_t, or the low word sign-extends)
-        const uint32_t sv_lo = __builtin_amdgcn_readlane(v_lo, pos), sv_hi = __builtin_amdgcn_readlane(v_hi, pos);
+        uint32_t sv_lo, sv_hi, se;
+        if (pos < 64u) {
+          sv_lo = __builtin_amdgcn_readlane(A.v_lo, pos);
+          sv_hi = __builtin_amdgcn_readlane(A.v_hi, pos);
+          se = __builtin_amdgcn_readlane(A.e, pos);
+        } else {
+          sv_lo = __builtin_amdgcn_readlane(B.v_lo, pos - 64u);
+          sv_hi = __builtin_amdgcn_readlane(B.v_hi, pos - 64u);
+          se = __builtin_amdgcn_readlane(B.e, pos - 64u);
+        }
         uint64_t sv = (uint64_t)sv_lo | ((uint64_t)sv_hi << 32);
-        uint32_t se = __builtin_amdgcn_readlane(e, pos);
         uint32_t used;
         if (se == 0) {  // longer than the LUT, or unassigned
           uint32_t nb;

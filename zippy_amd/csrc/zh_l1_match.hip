@@ -30,8 +30,8 @@ constexpr uint32_t kHashMul = 0x1e35a7bdu;  // snappy.nim:70-71
 }  // namespace
 
 __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restrict__ d_src,
-                                                         ZhCompressArgs a, int huffman_only) {
-  __shared__ uint16_t s_table[16384];
+                                                         ZhCompressArgs a, int huffman_only,
+                                                         uint16_t* __restrict__ table_pool) {
   __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
   // parse: 4096 byte-wide counters (4 per dword) of the probes per table slot in one step,
   // all zero between steps; afterwards the coverage bitmap (bit p set: byte p lies inside
@@ -41,8 +41,11 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   uint32_t* const s_cover = s_scr;
 
   const unsigned lane = zh_lane();
+  // this wave's hash table (u16 x 16384, snappy.nim:7) in the L2/MALL-resident pool: read with
+  // L1-bypassing loads, written through, re-zeroed for every fragment the wave takes
+  uint16_t* const s_table = table_pool + (size_t)blockIdx.x * 16384u;
+  for (uint32_t f = blockIdx.x; f < a.nfrags; f += gridDim.x) {
   KPROF_DECL(16);  // cycles: 0 stage-in, 1 vector part, 2 fast walk, 3 slow walk, 4 inserts, 5 stats; counts: 6..12
-  const uint32_t f = blockIdx.x;
   const ZhFragDesc fd = a.frags[f];
   const uint32_t n = fd.len;
   const uint8_t* src = d_src + fd.src_off;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
     shift--;
   }
   if (!huffman_only)
-    for (uint32_t i = lane; i < table_size / 2; i += 64) reinterpret_cast<uint32_t*>(s_table)[i] = 0;
+    for (uint32_t i = lane; i < table_size / 8; i += 64) reinterpret_cast<uint4*>(s_table)[i] = make_uint4(0, 0, 0, 0);
   zh_wave_sync();
   KPROF_MARK(0);
 
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         const uint32_t h = (a0 * kHashMul) >> shift;
         // round trip 2: the table slot; every lane also ticks a counter of its (folded) hash,
         // read back together with the candidate bytes
-        const uint32_t old = s_table[h];
+        const uint32_t old = __hip_atomic_load(s_table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t ck = (h & 4095u) >> 2, cs = (h & 3u) * 8u;
         if (valid) atomicAdd(&s_scr[ck], 1u << cs);
         zh_wave_sync();  // (orders the counter traffic between lanes; emits nothing)
@@ -446,11 +449,24 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   KPROF_MARK(5);
   KPROF_COUNT(11, 1);
   KPROF_FLUSH(0, 16);
+  zh_wave_sync();
+  }  // next fragment of this wave
+}
+
+// waves that share the table pool: 16 per CU on 256 CUs (ZH_L1_SLOTS: tuning override)
+extern "C" uint32_t zh_l1_table_slots(void) {
+  static const uint32_t slots = [] {
+    const char* e = getenv("ZH_L1_SLOTS");
+    const long v = e ? atol(e) : 0;
+    return v >= 64 && v <= 16384 ? (uint32_t)v : 4096u;
+  }();
+  return slots;
 }
 
 extern "C" void zh_launch_l1_match(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
-                                   int huffman_only) {
+                                   int huffman_only, uint16_t* table_pool) {
   if (!a.nfrags) return;
-  hipLaunchKernelGGL(zh_l1_match_kernel, dim3(a.nfrags), dim3(64), 0, stream, d_src, a,
-                     huffman_only);
+  const uint32_t grid = a.nfrags < zh_l1_table_slots() ? a.nfrags : zh_l1_table_slots();
+  hipLaunchKernelGGL(zh_l1_match_kernel, dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
+                     table_pool);
 }
