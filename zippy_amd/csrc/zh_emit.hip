@@ -3,7 +3,9 @@
 // Replaces deflate.nim:403-466 (the literal/length/distance bit packing loop)
 // and the data copy of addNoCompressionBlock (deflate.nim:200-205).  The
 // reference packs serially through BitStreamWriter.addBits; here every source
-// position of the fragment is a lane-item: a literal contributes its code, a
+// position of the fragment is an item (four per lane and pass, so that the loads of a
+// pass -- one source dword and the match fields per lane -- are in flight together):
+// a literal contributes its code, a
 // match start contributes code + length extra + distance code + distance extra
 // (<= 48 bits, assembled exactly as deflate.nim:417-433), bytes inside a match
 // contribute nothing.  A wave prefix sum of the bit lengths gives each item its
@@ -19,7 +21,7 @@ namespace {
 __constant__ zh::LenTables c_len = zh::make_len_tables();
 __constant__ zh::DistTables c_dist = zh::make_dist_tables();
 constexpr uint32_t kStageWords = 1024;                 // 4 KiB staging window
-constexpr uint32_t kFlushBits = (kStageWords - 128) * 32;  // flush threshold
+constexpr uint32_t kFlushBits = (kStageWords - 200) * 32;  // flush threshold: a 256-position pass adds < 6400 bits
 }  // namespace
 
 __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__ d_src,
@@ -98,56 +100,93 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   bool first_word_pending = true;                       // gwords[0] may be shared with the previous writer
   uint32_t mbase = 0;                                   // matches before the current batch
 
-  for (uint32_t base = 0; base < n; base += 64) {
-    const uint32_t p = base + lane;
-    const bool in = p < n;
-    const bool is_start = in && ((s_start[p >> 5] >> (p & 31u)) & 1u);
-    const bool is_cov = in && ((s_cover[p >> 5] >> (p & 31u)) & 1u);
-    const uint64_t start_mask = __ballot(is_start);
-    uint64_t val = 0;
-    uint32_t nbits = 0;
-    if (is_start) {
-      const uint32_t m = mbase + (uint32_t)__popcll(start_mask & zh_lanemask_lt());
-      const uint32_t length = m_len[m], offset = m_off[m];
-      const uint32_t li = c_len.index_of[length - 3], di = zh_dist_code(offset);
-      const uint32_t lc = s_lit[257 + li], dc = s_dist[di];
-      // deflate.nim:417-433
-      val = lc & 0xffffu;
-      nbits = lc >> 16;
-      val |= (uint64_t)(length - c_len.base[li]) << nbits;
-      nbits += c_len.extra[li];
-      val |= (uint64_t)(dc & 0xffffu) << nbits;
-      nbits += dc >> 16;
-      val |= (uint64_t)(offset - c_dist.base[di]) << nbits;
-      nbits += c_dist.extra[di];
-    } else if (in && !is_cov) {
-      const uint32_t lc = s_lit[src[p]];
-      val = lc & 0xffffu;
-      nbits = lc >> 16;
-    }
-    mbase += (uint32_t)__popcll(start_mask);
+  // the fragment's bytes: aligned dwords of the stream below `src`, never past the dword that
+  // holds its last byte
+  const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
+  const uint32_t* asrc = reinterpret_cast<const uint32_t*>(src - mis);
+  const uint32_t last_dw = (n + mis - 1u) >> 2;  // n >= 1 here
+  auto dw = [&](uint32_t i) -> uint32_t { return asrc[i < last_dw ? i : last_dw]; };
 
-    const uint32_t incl = zh_wave_scan(nbits);
-    const uint32_t total = __shfl(incl, 63, 64);
-    if (nbits) {
-      const uint32_t bp = stage_bits + incl - nbits;
-      const uint32_t w = bp >> 5, s = bp & 31u;
-      const uint64_t lo64 = val << s;  // nbits <= 48, so only s + nbits > 64 loses bits here
-      atomicOr(&s_stage[w], (uint32_t)lo64);
-      if (s + nbits > 32) atomicOr(&s_stage[w + 1], (uint32_t)(lo64 >> 32));
-      if (s + nbits > 64) atomicOr(&s_stage[w + 2], (uint32_t)(val >> (64 - s)));
+  for (uint32_t base = 0; base < n; base += 256) {
+    const uint32_t p0 = base + 4u * lane;  // this lane's four positions p0 .. p0+3
+    const bool in = p0 < n;
+    const uint32_t bw = in ? p0 >> 5 : 0u, bs = p0 & 31u;  // p0 is a multiple of 4: one bitmap word
+    const uint32_t st4 = in ? (s_start[bw] >> bs) & 15u : 0u;
+    uint32_t skip4 = in ? (s_cover[bw] >> bs) & 15u : 15u;
+    if (in && n - p0 < 4u) skip4 |= 15u << (n - p0);  // positions past the fragment
+    const uint32_t q = p0 + mis;
+    const uint32_t w = in ? __builtin_amdgcn_alignbyte(dw((q >> 2) + 1u), dw(q >> 2), q) : 0u;
+    // match index of this lane's first start
+    const uint32_t nst = (uint32_t)__popc(st4);
+    const uint32_t incl_st = zh_wave_scan(nst);
+    uint32_t m = mbase + incl_st - nst;
+    mbase += (uint32_t)__builtin_amdgcn_readlane(incl_st, 63);
+    // the match fields first (independent loads), then the codes
+    uint32_t ml[4], mo[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      ml[k] = 0;
+      mo[k] = 0;
+      if ((st4 >> k) & 1u) {
+        ml[k] = m_len[m];
+        mo[k] = m_off[m];
+        m++;
+      }
+    }
+    uint64_t val[4];
+    uint32_t nb[4], lane_bits = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      uint64_t v = 0;
+      uint32_t nbits = 0;
+      if ((st4 >> k) & 1u) {
+        const uint32_t length = ml[k], offset = mo[k];
+        const uint32_t li = c_len.index_of[length - 3], di = zh_dist_code(offset);
+        const uint32_t lc = s_lit[257 + li], dc = s_dist[di];
+        // deflate.nim:417-433
+        v = lc & 0xffffu;
+        nbits = lc >> 16;
+        v |= (uint64_t)(length - c_len.base[li]) << nbits;
+        nbits += c_len.extra[li];
+        v |= (uint64_t)(dc & 0xffffu) << nbits;
+        nbits += dc >> 16;
+        v |= (uint64_t)(offset - c_dist.base[di]) << nbits;
+        nbits += c_dist.extra[di];
+      } else if (!((skip4 >> k) & 1u)) {
+        const uint32_t lc = s_lit[(w >> (8u * k)) & 255u];
+        v = lc & 0xffffu;
+        nbits = lc >> 16;
+      }
+      val[k] = v;
+      nb[k] = nbits;
+      lane_bits += nbits;
+    }
+
+    const uint32_t incl = zh_wave_scan(lane_bits);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+    uint32_t bp = stage_bits + incl - lane_bits;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      if (nb[k]) {
+        const uint32_t wd = bp >> 5, sft = bp & 31u;
+        const uint64_t lo64 = val[k] << sft;  // nbits <= 48, so only sft + nbits > 64 loses bits here
+        atomicOr(&s_stage[wd], (uint32_t)lo64);
+        if (sft + nb[k] > 32) atomicOr(&s_stage[wd + 1], (uint32_t)(lo64 >> 32));
+        if (sft + nb[k] > 64) atomicOr(&s_stage[wd + 2], (uint32_t)(val[k] >> (64 - sft)));
+        bp += nb[k];
+      }
     }
     stage_bits += total;
 
-    const bool last = base + 64 >= n;
+    const bool last = base + 256 >= n;
     if (stage_bits >= kFlushBits || last) {
       zh_wave_sync();
       const uint32_t full = stage_bits >> 5;           // complete words
       const uint32_t rem = stage_bits & 31u;
-      for (uint32_t w = lane; w < full; w += 64) {
-        const uint32_t v = s_stage[w];
-        if (w == 0 && first_word_pending) atomicOr(&gwords[0], v);
-        else gwords[w] = v;
+      for (uint32_t wv = lane; wv < full; wv += 64) {
+        const uint32_t v = s_stage[wv];
+        if (wv == 0 && first_word_pending) atomicOr(&gwords[0], v);
+        else gwords[wv] = v;
       }
       zh_wave_sync();
       if (last) {
@@ -155,7 +194,7 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
       } else {
         const uint32_t carry = s_stage[full];
         zh_wave_sync();
-        for (uint32_t w = lane; w <= full + 2 && w < kStageWords + 4; w += 64) s_stage[w] = 0;
+        for (uint32_t wv = lane; wv <= full + 2 && wv < kStageWords + 4; wv += 64) s_stage[wv] = 0;
         zh_wave_sync();
         if (lane == 0) s_stage[0] = carry;
         if (full) first_word_pending = false;
