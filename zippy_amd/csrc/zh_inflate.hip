@@ -545,6 +545,7 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
       // ---- the chain of real token starts ----
       uint64_t chain = 0, chainB = 0;
       uint32_t pos = 0;
+#ifdef ZH_EMU
       while (pos < 64u) {
         const uint32_t tv = __builtin_amdgcn_readlane(A.tbits, pos);
         if (tv & 0x8000u) break;
@@ -561,6 +562,44 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
           pos += tv;
         }
       }
+#else
+      // the same two loops, seven instructions and one taken branch per symbol (hipcc's
+      // structured form of them is twice that); lane select and s_bitset use pos[5:0]
+      {
+        uint32_t tv;
+        asm volatile(
+            "1:\n\t"
+            "v_readlane_b32 %[tv], %[tb], %[pos]\n\t"
+            "s_bitcmp1_b32 %[tv], 15\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "s_bitset1_b64 %[ch], %[pos]\n\t"
+            "s_add_u32 %[pos], %[pos], %[tv]\n\t"
+            "s_cmp_lt_u32 %[pos], 64\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "2:"
+            : [tv] "=&s"(tv), [pos] "+s"(pos), [ch] "+s"(chain)
+            : [tb] "v"(A.tbits)
+            : "scc");
+      }
+      const uint32_t posA = pos;
+      bool useB = pos >= 64u;
+      if (useB) {
+        uint32_t tv;
+        asm volatile(
+            "1:\n\t"
+            "v_readlane_b32 %[tv], %[tb], %[pos]\n\t"
+            "s_bitcmp1_b32 %[tv], 15\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "s_bitset1_b64 %[ch], %[pos]\n\t"
+            "s_add_u32 %[pos], %[pos], %[tv]\n\t"
+            "s_cmp_lt_u32 %[pos], 0x80\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "2:"
+            : [tv] "=&s"(tv), [pos] "+s"(pos), [ch] "+s"(chainB)
+            : [tb] "v"(B.tbits)
+            : "scc");
+      }
+#endif
       const bool in_chain = (chain >> lane) & 1ull;
       const uint32_t incl = zh_wave_scan(in_chain ? A.outlen : 0u);
       const uint32_t opre = incl - (in_chain ? A.outlen : 0u);  // output offset of this lane's A token
