@@ -33,10 +33,10 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
                                                          ZhCompressArgs a, int huffman_only,
                                                          uint16_t* __restrict__ table_pool) {
   __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
-  // parse: 4096 byte-wide counters (4 per dword) of the probes per table slot in one step,
-  // all zero between steps; afterwards the coverage bitmap (bit p set: byte p lies inside
-  // a match)
-  __shared__ uint32_t s_scr[1024];
+  // parse: 8192 byte-wide counters (4 per dword) of the probes per table slot in one step,
+  // all zero between steps; afterwards the first 4 KiB are the coverage bitmap (bit p set:
+  // byte p lies inside a match)
+  __shared__ uint32_t s_scr[2048];
   __shared__ uint32_t s_nmatch;
   uint32_t* const s_cover = s_scr;
 
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
     return __builtin_amdgcn_alignbyte(dw(i + 1), dw(i), q);
   };
   for (uint32_t i = lane; i < ZH_HIST_STRIDE; i += 64) s_hist[i] = 0;
-  for (uint32_t i = lane; i < 1024; i += 64) s_scr[i] = 0;
+  for (uint32_t i = lane; i < 2048; i += 64) s_scr[i] = 0;
 
   uint32_t table_size = 256, shift = 24;  // snappy.nim:24-29
   while (table_size < 16384u && table_size < n) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         // round trip 2: the table slot; every lane also ticks a counter of its (folded) hash,
         // read back together with the candidate bytes
         const uint32_t old = __hip_atomic_load(s_table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t ck = (h & 4095u) >> 2, cs = (h & 3u) * 8u;
+        const uint32_t ck = (h & 8191u) >> 2, cs = (h & 3u) * 8u;
         if (valid) atomicAdd(&s_scr[ck], 1u << cs);
         zh_wave_sync();  // (orders the counter traffic between lanes; emits nothing)
         const uint32_t a1 = __builtin_amdgcn_alignbyte(p2, p1, pq);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         const uint64_t V = __ballot(valid);  // a prefix of the lanes (pos + step is monotone)
         const uint64_t H = __ballot(valid && x0 == 0);
         // lanes that may share their table slot with another lane of this step (a superset:
-        // the counters see 12 of the 14 hash bits); the general walk below sorts them out exactly
+        // the counters see 13 of the 14 hash bits); the general walk below sorts them out exactly
         const uint64_t C = __ballot(cnt > 1u);
         const uint32_t t = V == ~0ull ? 64u : (uint32_t)__ffsll((long long)~V) - 1u;  // first probe past ip_limit
 
@@ -196,71 +196,97 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         for (;;) {
           if (dense && i < 64u) {
             uint64_t sel = 0;  // match lanes of this chain
-            uint32_t cur = i, tv = 0;
-            bool took = false;
+            uint32_t cur = zh_bcast(i), tv = 0x8000u;
             KPROF_MARK(3);
             // a run that continues from the previous step may only hop if it finds its match
             // before its 32nd probe (hops behind a match need d < 32 only, which the table has)
+            bool go = true;
             if (!reprobe && K) {
               tv = __builtin_amdgcn_readlane(hop, cur);
-              if ((tv & 0x8000u) || !(tv & 0x40u) || K + ((tv & 63u) - cur) > 31u) cur = 64;
+              go = !(tv & 0x8000u) && (tv & 0x40u) && K + ((tv & 63u) - cur) <= 31u;
             }
-            if (cur < 64u) {
-              while (cur < 64u) {
+            const uint32_t lim = zh_bcast(tt < 64u ? tt : 64u);
+            if (go && cur < lim) {
+#ifdef ZH_EMU
+              do {
                 tv = __builtin_amdgcn_readlane(hop, cur);
-                if (tv & 0x8000u) break;
+                if ((tv & 0x8040u) != 0x40u) break;  // not a match hop
                 const uint32_t g = tv & 63u, nxt = tv >> 8;
-                sel |= (uint64_t)((tv >> 6) & 1u) << g;
+                sel |= 1ull << g;
                 ins |= (~0ull << cur) & (~0ull >> (63u - g));  // probes cur..g (table[h] = ip)
-                if (nxt <= 64u) ins |= 1ull << (nxt - 1u);      // ip-1 behind the match (snappy.nim:126)
-                if (!(tv & 0x40u)) {  // misses to the end of the step: only if ip_limit is not in it
-                  if (tt < 64u) {
-                    tv = 0x8000u;
-                    break;
-                  }
-                  K = (took || reprobe ? 63u : K + 64u) - cur;  // probes cur+1..63, or K more from cur
-                }
-                took = true;
+                ins |= 1ull << (nxt <= 64u ? nxt - 1u : g);     // ip-1 behind the match (snappy.nim:126)
                 cur = nxt;
-                if (cur >= tt) break;  // snappy.nim:118-120
-              }
-            } else {
-              cur = i;
+              } while (cur < lim);
+#else
+              // the same loop in 19 instructions with one taken branch per match
+              uint32_t t0, g, nxt;
+              uint64_t m1, m2;
+              asm volatile(
+                  "1:\n\t"
+                  "v_readlane_b32 %[tv], %[hop], %[cur]\n\t"
+                  "s_and_b32 %[t0], %[tv], 0x8040\n\t"
+                  "s_cmp_eq_u32 %[t0], 64\n\t"
+                  "s_cbranch_scc0 2f\n\t"
+                  "s_and_b32 %[g], %[tv], 63\n\t"
+                  "s_lshr_b32 %[nxt], %[tv], 8\n\t"
+                  "s_bitset1_b64 %[sel], %[g]\n\t"
+                  "s_lshl_b64 %[m1], -1, %[cur]\n\t"
+                  "s_sub_u32 %[t0], 63, %[g]\n\t"
+                  "s_lshr_b64 %[m2], -1, %[t0]\n\t"
+                  "s_and_b64 %[m1], %[m1], %[m2]\n\t"
+                  "s_or_b64 %[ins], %[ins], %[m1]\n\t"
+                  "s_sub_u32 %[t0], %[nxt], 1\n\t"
+                  "s_cmp_lt_u32 %[t0], 64\n\t"
+                  "s_cselect_b32 %[t0], %[t0], %[g]\n\t"
+                  "s_bitset1_b64 %[ins], %[t0]\n\t"
+                  "s_mov_b32 %[cur], %[nxt]\n\t"
+                  "s_cmp_lt_u32 %[cur], %[lim]\n\t"
+                  "s_cbranch_scc1 1b\n\t"
+                  "2:"
+                  : [tv] "=&s"(tv), [cur] "+s"(cur), [sel] "+s"(sel), [ins] "+s"(ins), [t0] "=&s"(t0),
+                    [g] "=&s"(g), [nxt] "=&s"(nxt), [m1] "=&s"(m1), [m2] "=&s"(m2)
+                  : [hop] "v"(hop), [lim] "s"(lim)
+                  : "scc");
+#endif
+            }
+            const bool chained = cur != i;  // at least one match: the probe at cur is a re-probe
+            // "nothing but misses up to lane 63" (a hop word without match and stop flags):
+            // the literal run goes on in the next step
+            bool run_out = false;
+            if (go && cur < lim && !(tv & 0x8040u) && tt >= 64u) {
+              K = (chained || reprobe ? 63u : K + 64u) - cur;  // probes cur+1..63, or 64-cur more
+              ins |= ~0ull << cur;
+              run_out = true;
             }
             KPROF_MARK(2);
-            if (took) {
-              if (sel) {
-                KPROF_COUNT(8, __popcll(sel));
-                if ((sel >> lane) & 1ull) {  // every match lane files its own record
-                  const uint32_t k = nm + (uint32_t)__popcll(sel & zh_lanemask_lt());
-                  m_pos[k] = (uint16_t)pos;
-                  m_len[k] = (uint16_t)eqlen;
-                  m_off[k] = (uint16_t)(pos - old);
-                }
-                nm += (uint32_t)__popcll(sel);
+            if (sel) {
+              KPROF_COUNT(8, __popcll(sel));
+              if ((sel >> lane) & 1ull) {  // every match lane files its own record
+                const uint32_t k = nm + (uint32_t)__popcll(sel & zh_lanemask_lt());
+                m_pos[k] = (uint16_t)pos;
+                m_len[k] = (uint16_t)eqlen;
+                m_off[k] = (uint16_t)(pos - old);
               }
-              if (tv & 0x40u) {  // the chain ends behind a match
-                K = 0;
-                if (cur >= tt) {  // snappy.nim:118-120
-                  finished = true;
-                  break;
-                }
-                if (cur >= 64u) {
-                  post = true;
-                  ip = W0 + cur;
-                  break;
-                }
-                i = cur;
-                reprobe = true;
-              } else if (!(tv & 0x8000u)) {  // ... or in a literal run at the end of the step
-                post = false;
-                ip = W0 + 64u;
+              nm += (uint32_t)__popcll(sel);
+            }
+            if (run_out) {
+              post = false;
+              ip = W0 + 64u;
+              break;
+            }
+            if (chained) {
+              K = 0;
+              if (cur >= tt) {  // snappy.nim:118-120
+                finished = true;
                 break;
-              } else {  // (ip_limit inside the step: the general walk finishes it)
-                K = 0;
-                i = cur;
-                reprobe = true;
               }
+              if (cur >= 64u) {
+                post = true;
+                ip = W0 + cur;
+                break;
+              }
+              i = cur;
+              reprobe = true;
             }
           }
           KPROF_COUNT(9, 1);
