@@ -87,6 +87,22 @@ def test_gpu_config3_uncompress_1mib_streams(eng):
     assert outs == bufs + bufs[:16] + bufs[:16]
 
 
+def test_gpu_level1_identical_at_scale(eng):
+    """Every table slot of the matcher busy at once (512 x 1 MiB = 16384 fragments over 4096
+    persistent waves) and every stream slot of inflate: outputs still equal the oracle's, byte
+    for byte (a stale hash-table read would only change the parse, not break the round trip)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    bufs = [b.tobytes() for b in synth.gen_batch("mix", 512, 1 << 20, first_index=9000)]
+    outs, sts = eng.compress_batch(bufs, 1, oracle.dfGzip)
+    assert all(s == 0 for s in sts)
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
+        want = list(ex.map(lambda b: oracle.compress(b, 1, oracle.dfGzip, fname_len=0), bufs))
+    assert outs == want
+    back, sts = eng.uncompress_batch(outs)
+    assert all(s == 0 for s in sts) and back == bufs
+
+
 def test_gpu_config4_default_compression_ratio(eng):
     """BASELINE.json configs[3] at test size: DefaultCompression, identical to the oracle."""
     bufs = [b.tobytes() for b in synth.gen_batch("mix", 12, 1 << 20)]
