@@ -30,8 +30,6 @@ __constant__ zh::DistTables c_dist = zh::make_dist_tables();
 __constant__ uint8_t c_clcl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 constexpr uint32_t kLitBits = 10, kDistBits = 7;
-constexpr uint32_t kRing = 3072;    // bytes of recent output kept in LDS (a multiple of 1024)
-constexpr uint32_t kFlushAt = 1024;  // pending output that triggers a write-back
 constexpr uint32_t kInWords = 128;   // staging ring of the compressed stream (dwords, power of two)
 
 }  // namespace
@@ -228,7 +226,6 @@ __device__ int build_table(const uint8_t* lens, uint32_t n, uint32_t* lut, uint3
 __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restrict__ d_src,
                                                         uint8_t* __restrict__ d_dst,
                                                         ZhInflateArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[kRing];
   __shared__ uint32_t s_lit[1u << kLitBits];
   __shared__ uint32_t s_dst[1u << kDistBits];  // also hosts the 7-bit code-length table
   __shared__ uint32_t s_in[kInWords];          // staging ring of the compressed stream
@@ -249,7 +246,6 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
   uint8_t* dst = d_dst + bd.dst_off;
   const uint64_t cap = bd.dst_cap;
   const int count_only = a.count_only;
-  const bool dst_al16 = (((uintptr_t)dst) & 15u) == 0;
 
   // ---- input: the stream is addressed in bits from the 4-byte aligned base below `src`;
   // 64 dwords at a time go through a 512-byte LDS ring (bitstreams.nim:22-49's refill) ----
@@ -322,36 +318,14 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
 
   seek(((uint64_t)mis + a.body_pos[sid]) * 8);
 
-  uint64_t op = 0;         // bytes produced
-  uint32_t rp = 0;         // op mod kRing
-  uint32_t unflushed = 0;  // op - (bytes already written back to HBM); op - unflushed is a multiple of 1024
+  uint64_t op = 0;  // bytes produced
   int st = ZH_OK;
-  auto wrap = [&](uint32_t x) -> uint32_t { return x >= kRing ? x - kRing : x; };  // x < 2 * kRing
-
-  // write the oldest `nbytes` unflushed ring bytes back to HBM
-  auto flush = [&](uint32_t nbytes) {
-    KPROF_MARK(2);
-    zh_wave_sync();
-    if (!count_only && nbytes) {
-      const uint64_t from = op - unflushed;
-      const uint64_t upto = from + nbytes;
-      uint32_t r = wrap(rp + kRing - unflushed);  // ring offset of `from` (a multiple of 1024)
-      uint64_t p = from;
-      if (dst_al16) {
-        for (; p + 1024 <= upto; p += 1024) {
-          *reinterpret_cast<uint4*>(dst + p + lane * 16u) = *reinterpret_cast<const uint4*>(&s_win[r + lane * 16u]);
-          r = wrap(r + 1024u);
-        }
-      }
-      for (uint64_t q = p + lane; q < upto; q += 64) dst[q] = s_win[wrap(r + (uint32_t)(q - p))];
-    }
-    unflushed -= nbytes;
-    zh_wave_sync();
-    KPROF_MARK(3);
-  };
-  // room for `nbytes` more output in the ring; afterwards everything older than the ring is in HBM
-  auto make_room = [&](uint32_t nbytes) {
-    if (unflushed + nbytes > kRing - 1024u) flush(unflushed & ~1023u);
+  // The LZ window is the output itself: match sources are read back from HBM/L2 past this
+  // CU's L1 (which may hold a stale copy of a line the wave has since extended), after the
+  // wave's earlier stores have completed.
+  auto own_output_visible = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); };
+  auto ld_out = [&](uint64_t at) -> uint32_t {
+    return __hip_atomic_load(dst + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // inflate.nim:224-250: one LZ copy of `length` bytes from `dist` back, at op (wave-uniform)
   auto lz_copy = [&](uint32_t length, uint32_t dist) {
@@ -364,42 +338,21 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
         st = ZH_ERR_DST_TOO_SMALL;
         return;
       }
-      make_room(length);
-      zh_wave_sync();
       // byte-sequential LZ77 copy semantics; an overlapping copy (dist < length) repeats the
       // dist-byte pattern, so every lane reads its source from the region already written
-      if (dist > kRing) {
-        // older than the ring: written back at least 1 KiB of output ago.  Wait for those
-        // stores, then read through L2 (this CU's L1 may hold a stale copy of the line).
-        KPROF_COUNT(8, 1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        for (uint32_t i = lane; i < length; i += 64)
-          s_win[wrap(rp + i)] = __hip_atomic_load(dst + (op - dist + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      KPROF_COUNT(8, 1);
+      own_output_visible();
+      const uint64_t sb = op - dist;
+      if (dist >= length) {
+        for (uint32_t i = lane; i < length; i += 64) dst[op + i] = (uint8_t)ld_out(sb + i);
+      } else if (dist == 1) {
+        const uint8_t v = (uint8_t)ld_out(sb);
+        for (uint32_t i = lane; i < length; i += 64) dst[op + i] = v;
       } else {
-        const uint32_t sb = wrap(rp + kRing - dist);  // ring offset of the source
-        if (dist + length > kRing) {
-          // the destination wraps onto the source's ring slots: read each 64-byte group before
-          // the next is written (program order on the GPU; the syncs keep the emulator honest)
-          for (uint32_t base = 0; base < length; base += 64) {
-            const uint32_t i = base + lane;
-            const uint8_t v = s_win[wrap(sb + i)];
-            zh_wave_sync();
-            if (i < length) s_win[wrap(rp + i)] = v;
-            zh_wave_sync();
-          }
-        } else if (dist >= length) {
-          for (uint32_t i = lane; i < length; i += 64) s_win[wrap(rp + i)] = s_win[wrap(sb + i)];
-        } else if (dist == 1) {
-          const uint8_t v = s_win[sb];
-          for (uint32_t i = lane; i < length; i += 64) s_win[wrap(rp + i)] = v;
-        } else {
-          for (uint32_t i = lane; i < length; i += 64) s_win[wrap(rp + i)] = s_win[wrap(sb + i % dist)];
-        }
+        for (uint32_t i = lane; i < length; i += 64) dst[op + i] = (uint8_t)ld_out(sb + i % dist);
       }
     }
     op += length;
-    rp = wrap(rp + length);
-    unflushed += length;
   };
 
   bool final_block = false;
@@ -420,17 +373,9 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
       if (byte_pos + len > end) { st = ZH_ERR_END_OF_BUFFER; break; }
       if (op + len > cap && !count_only) { st = ZH_ERR_DST_TOO_SMALL; break; }
       const uint8_t* raw = reinterpret_cast<const uint8_t*>(asrc) + byte_pos;
-      for (uint32_t done = 0; done < len;) {
-        const uint32_t n = len - done < 1024u ? len - done : 1024u;
-        if (!count_only) make_room(n);
-        zh_wave_sync();
-        if (!count_only)
-          for (uint32_t i = lane; i < n; i += 64) s_win[wrap(rp + i)] = raw[done + i];
-        op += n;
-        rp = wrap(rp + n);
-        unflushed += n;
-        done += n;
-      }
+      if (!count_only)
+        for (uint32_t i = lane; i < len; i += 64) dst[op + i] = raw[i];
+      op += len;
       seek((byte_pos + len) * 8);
       continue;
     }
@@ -672,16 +617,13 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
               par = lane - gd;
             } else {
               back = gd - lane;  // bytes before this round's first
-              if (back <= kRing) val = s_win[wrap(rp + kRing - back)];
-              else far = true;
+              far = true;
             }
           }
           if (__ballot(far)) {
-            // older than the ring: written back long ago; read through L2 (this CU's L1 may
-            // hold a stale copy of a partially written line)
             KPROF_COUNT(8, 1);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (far) val = __hip_atomic_load(dst + (op - back), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            own_output_visible();
+            if (far) val = ld_out(op - back);
           }
           if (__ballot(par != lane)) {
             for (;;) {
@@ -692,15 +634,12 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
             }
             val = (uint32_t)__shfl((int)val, (int)par, 64);
           }
-          zh_wave_sync();
-          if (live) s_win[wrap(rp + lane)] = (uint8_t)val;
+          if (live) dst[op + lane] = (uint8_t)val;
         }
         op += total;
-        rp = wrap(rp + total);
-        unflushed += total;
       } else {
         // long or empty rounds (window A only): literal runs by their lanes, copies in order
-        const uint32_t rp0 = rp;
+        const uint64_t op0 = op;
         uint32_t done_lanes = 0;  // chain lanes below this bit offset are finished
         while (mm && st == ZH_OK) {
           const uint32_t g = (uint32_t)__ffsll((long long)mm) - 1u;
@@ -710,11 +649,9 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
             const uint32_t nl = (uint32_t)__popcll(grp);
             if (!count_only) {
               if (op + nl > cap) { st = ZH_ERR_DST_TOO_SMALL; break; }
-              if ((grp >> lane) & 1ull) s_win[wrap(rp0 + opre)] = (uint8_t)(e >> 16);
+              if ((grp >> lane) & 1ull) dst[op0 + opre] = (uint8_t)(e >> 16);
             }
             op += nl;
-            rp = wrap(rp + nl);
-            unflushed += nl;
           }
           KPROF_COUNT(6, 1);
           lz_copy(__builtin_amdgcn_readlane(lenval, g), __builtin_amdgcn_readlane(distval, g));
@@ -726,11 +663,9 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
             const uint32_t nl = (uint32_t)__popcll(grp);
             if (!count_only) {
               if (op + nl > cap) st = ZH_ERR_DST_TOO_SMALL;
-              else if ((grp >> lane) & 1ull) s_win[wrap(rp0 + opre)] = (uint8_t)(e >> 16);
+              else if ((grp >> lane) & 1ull) dst[op0 + opre] = (uint8_t)(e >> 16);
             }
             op += nl;
-            rp = wrap(rp + nl);
-            unflushed += nl;
           }
         }
       }
@@ -766,11 +701,9 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
         if (se & 0x8000u) {  // a literal with a long code
           if (!count_only) {
             if (op + 1 > cap) st = ZH_ERR_DST_TOO_SMALL;
-            else if (lane == 0) s_win[rp] = (uint8_t)(se >> 16);
+            else if (lane == 0) dst[op] = (uint8_t)(se >> 16);
           }
           op += 1;
-          rp = wrap(rp + 1u);
-          unflushed += 1;
         } else if (kind == kKindEob) {
           block_done = true;
         } else if (kind == kKindBad) {  // inflate.nim:202-204
@@ -806,14 +739,10 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
       // tokens decoded from beyond the end of the input are caught here at the latest
       if (st == ZH_OK && past_end()) st = ZH_ERR_END_OF_BUFFER;
       if (st != ZH_OK || block_done) break;
-      if (unflushed >= kFlushAt) flush(unflushed & ~1023u);
     }
   }
 
-  if (st == ZH_OK) {
-    if (op > cap && !count_only) st = ZH_ERR_DST_TOO_SMALL;
-    else flush(unflushed);
-  }
+  if (st == ZH_OK && op > cap && !count_only) st = ZH_ERR_DST_TOO_SMALL;
   if (lane == 0) {
     a.out_len[sid] = op;
     a.status[sid] = st;
