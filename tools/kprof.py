@@ -17,8 +17,8 @@ L1 = ["stage-in", "step: vector part", "step: fast walk", "step: slow walk", "st
       "stats phase", "#steps", "#fast steps", "#events fast", "#events slow", "#match extensions",
       "#waves", "#slow: run continues", "#slow: 32 lanes no event", "#slow: shared slot",
       "#slow: end of step"]
-INF = ["headers+tables", "token decode + walk", "literal stores + copies", "write-back", "other",
-       "#symbols in chains", "#matches", "#rounds", "#far copies", "#lone tokens", "#waves"]
+INF_O = ["waiting for a round", "working", "#rounds", "#waves"]
+INF_D = ["waiting for the output wave", "working", "#rounds", "#waves"]
 
 
 def show(title, names, vals):
@@ -71,7 +71,8 @@ def main():
     eng.lib.zh_kprof_read(slots, 0)
     print("kernel ms:", {k: round(v, 3) for k, v in cplan.kernel_times() + uplan.kernel_times()})
     show("zh_l1_match_kernel", L1, list(slots[0:16]))
-    show("zh_inflate_kernel", INF, list(slots[16:27]))
+    show("zh_inflate_kernel: output wave", INF_O, list(slots[16:20]))
+    show("zh_inflate_kernel: decode wave", INF_D, list(slots[24:28]))
 
 
 if __name__ == "__main__":

@@ -214,18 +214,47 @@ __device__ int build_table(const uint8_t* lens, uint32_t n, uint32_t* lut, uint3
 
 }  // namespace
 
-// The decode loop works on 64 bit positions at a time ("round"): lane l decodes the whole
-// token that WOULD start l bits behind the current stream position -- literal, or length +
-// extra + distance + extra -- from its own 64-bit view of the stream (two LDS lookups,
-// inflate.nim:93-100 / 199-222 for all 64 offsets at once).  A wave-uniform walk then follows
-// the real chain of token starts through those lanes (one v_readlane per symbol), a DPP prefix
-// sum of the chain's output lengths places every token, literals are stored by their lanes in
-// one LDS write per run, and LZ copies (inflate.nim:227-250) run in order, 64 bytes per
-// instruction.  Anything the 10-/8-bit LUTs cannot finish (longer codes, end of block,
-// invalid symbols) stops the chain and is decoded alone with the canonical slow path.
-__global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restrict__ d_src,
-                                                        uint8_t* __restrict__ d_dst,
-                                                        ZhInflateArgs a) {
+// Two waves per stream, one producer and one consumer, a barrier per round:
+//
+// DECODE wave: owns the bit stream.  A round covers up to 128 bit positions: lane l decodes
+//   the whole tokens -- literal, or length + extra + distance + extra -- that WOULD start l
+//   and 64 + l bits behind the current position, each from its own 64-bit view of the stream
+//   (two LDS lookups, inflate.nim:93-100 / 199-222 for all offsets at once).  A wave-uniform
+//   walk then follows the real chain of token starts through those lanes (seven instructions
+//   per symbol), DPP prefix sums of the chain's output lengths place every token, and the
+//   round goes into one of two descriptor buffers in LDS.  Anything the 10-/7-bit LUTs cannot
+//   finish (longer codes, end of block, invalid symbols) stops the chain and is decoded alone
+//   with the canonical slow path (inflate.nim:67-91) as the round's "tail".  Block headers,
+//   table construction and stored blocks happen here too.
+// OUTPUT wave: owns the output.  Rounds of <= 64 bytes (the usual case) get one lane per
+//   OUTPUT byte: token starts are scattered by output offset and a running maximum tells
+//   every byte its token; literals carry their value, match bytes read earlier output back
+//   through L2 (the LZ window is the output itself), bytes copied from the round's own output
+//   chase their source down by pointer doubling -- inflate.nim:227-250's byte-sequential copy
+//   semantics without a loop over the tokens.  Longer rounds run their copies in order.
+// While the output wave works on round k the decode wave is already on round k + 1.
+namespace {
+
+constexpr uint32_t kTailNone = 0, kTailLiteral = 1, kTailMatch = 2, kTailStored = 3, kTailEnd = 4;
+
+struct RoundDesc {
+  // per lane and window: output offset (16) | output length (9) << 16 | in chain << 25 | literal << 26
+  uint32_t rec[2][64];
+  uint16_t val[2][64];  // literal byte, or match distance
+  uint32_t total;       // bytes the chain tokens produce
+  uint32_t use_b;       // window B holds tokens too
+  uint32_t tail;        // what follows the chain (kTail*)
+  uint32_t tail_a;      // literal byte | match length | stored length | final status
+  uint32_t tail_b;      // match distance
+  uint32_t pad;
+  uint64_t tail_off;    // stored run: offset of its first byte in the compressed stream
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __restrict__ d_src,
+                                                         uint8_t* __restrict__ d_dst,
+                                                         ZhInflateArgs a) {
   __shared__ uint32_t s_lit[1u << kLitBits];
   __shared__ uint32_t s_dst[1u << kDistBits];  // also hosts the 7-bit code-length table
   __shared__ uint32_t s_in[kInWords];          // staging ring of the compressed stream
@@ -234,11 +263,13 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
   __shared__ uint16_t s_val_lit[288], s_val_dist[32], s_val_cl[20];
   __shared__ uint8_t s_lens[320 + 16];
   __shared__ uint32_t s_cnt[16];
+  __shared__ RoundDesc s_desc[2];
+  __shared__ int32_t s_ostatus;  // raised by the output wave, polled by the decode wave
 
   const unsigned lane = zh_lane();
-  KPROF_DECL(11);  // cycles: 0 headers+tables, 1 token decode + walk, 2 literal stores + copies, 3 write-back, 4 other; counts 5..10
+  const bool decoder = threadIdx.x < 64;
   const uint32_t sid = blockIdx.x;
-  if (a.status[sid] != ZH_OK) return;  // unwrap already failed this stream
+  if (a.status[sid] != ZH_OK) return;  // unwrap already failed this stream (both waves leave)
 
   const ZhBufDesc bd = a.bufs[sid];
   const uint8_t* src = d_src + bd.src_off;
@@ -246,11 +277,196 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
   uint8_t* dst = d_dst + bd.dst_off;
   const uint64_t cap = bd.dst_cap;
   const int count_only = a.count_only;
-
-  // ---- input: the stream is addressed in bits from the 4-byte aligned base below `src`;
-  // 64 dwords at a time go through a 512-byte LDS ring (bitstreams.nim:22-49's refill) ----
   const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
   const uint32_t* asrc = reinterpret_cast<const uint32_t*>(src - mis);
+  if (threadIdx.x == 0) s_ostatus = ZH_OK;
+  __syncthreads();
+
+  if (!decoder) {
+    // =========================== OUTPUT wave ===========================
+    KPROF_DECL(4);  // output wave: 0 waiting for a round, 1 working; 2 rounds; 3 waves
+    uint64_t op = 0;  // bytes produced
+    int st = ZH_OK;
+    // match sources are read back past this CU's L1 (which may hold a stale copy of a line the
+    // wave has since extended), after the wave's earlier stores have completed
+    auto own_output_visible = [&]() {
+      zh_wave_sync();  // (lanes read what other lanes stored: a rendezvous for the emulator)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    };
+    auto ld_out = [&](uint64_t at) -> uint32_t {
+      return __hip_atomic_load(dst + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // inflate.nim:224-250: one LZ copy of `length` bytes from `dist` back, at op (wave-uniform)
+    auto lz_copy = [&](uint32_t length, uint32_t dist) {
+      if (dist > op) {  // inflate.nim:224-225
+        st = ZH_ERR_INVALID_BUFFER;
+        return;
+      }
+      if (!count_only) {
+        if (op + length > cap) {
+          st = ZH_ERR_DST_TOO_SMALL;
+          return;
+        }
+        // an overlapping copy (dist < length) repeats the dist-byte pattern, so every lane
+        // reads its source from the region already written
+        own_output_visible();
+        const uint64_t sb = op - dist;
+        if (dist >= length) {
+          for (uint32_t i = lane; i < length; i += 64) dst[op + i] = (uint8_t)ld_out(sb + i);
+        } else if (dist == 1) {
+          const uint8_t v = (uint8_t)ld_out(sb);
+          for (uint32_t i = lane; i < length; i += 64) dst[op + i] = v;
+        } else {
+          for (uint32_t i = lane; i < length; i += 64) dst[op + i] = (uint8_t)ld_out(sb + i % dist);
+        }
+      }
+      op += length;
+    };
+    for (uint32_t k = 0;; k++) {
+      KPROF_MARK(1);
+      __syncthreads();  // round k is in s_desc[k & 1]
+      KPROF_MARK(0);
+      KPROF_COUNT(2, 1);
+      const RoundDesc& d = s_desc[k & 1u];
+      const uint32_t total = d.total, use_b = d.use_b, tail = d.tail, tail_a = d.tail_a, tail_b = d.tail_b;
+      const uint64_t tail_off = d.tail_off;
+      const uint32_t recA = d.rec[0][lane], valA = d.val[0][lane];
+      uint32_t recB = 0, valB = 0;
+      if (use_b) {
+        recB = d.rec[1][lane];
+        valB = d.val[1][lane];
+      }
+      if (tail == kTailEnd) {
+        if (st == ZH_OK) st = (int)tail_a;
+        break;
+      }
+      if (st != ZH_OK) continue;  // failed: keep taking rounds until the decode wave stops
+      const bool in_chain = (recA >> 25) & 1u, is_lit = (recA >> 26) & 1u;
+      const bool in_chainB = (recB >> 25) & 1u, is_litB = (recB >> 26) & 1u;
+      const uint32_t opre = recA & 0xffffu, opreB = recB & 0xffffu;
+      if (total - 1u < 64u) {
+        const bool is_match = in_chain && !is_lit, is_matchB = in_chainB && !is_litB;
+        if (__ballot((is_match && (uint64_t)valA > op + opre) ||
+                     (is_matchB && (uint64_t)valB > op + opreB))) {  // inflate.nim:224-225
+          st = ZH_ERR_INVALID_BUFFER;
+        } else if (!count_only && op + total > cap) {
+          st = ZH_ERR_DST_TOO_SMALL;
+        } else if (!count_only) {
+          zh_wave_sync();
+          s_map[lane] = 0;
+          zh_wave_sync();
+          if (in_chain) s_map[opre] = (uint8_t)(lane + 1u);
+          if (in_chainB) s_map[opreB] = (uint8_t)(lane + 65u);
+          zh_wave_sync();
+          const uint32_t tk = zh_wave_scan_max(s_map[lane]);  // token (window, lane) + 1 of output byte `lane`
+          const uint32_t j = (tk - 1u) & 63u;
+          const uint32_t f1 = (is_lit ? 0x10000u : 0u) | valA;
+          uint32_t g1 = (uint32_t)__shfl((int)f1, (int)j, 64);
+          if (use_b) {
+            const uint32_t f1B = (is_litB ? 0x10000u : 0u) | valB;
+            const uint32_t g1B = (uint32_t)__shfl((int)f1B, (int)j, 64);
+            if (tk > 64u) g1 = g1B;
+          }
+          const uint32_t gd = g1 & 0xffffu;
+          const bool live = lane < total;
+          uint32_t val = gd & 0xffu;
+          uint32_t par = lane;  // source byte inside this round (itself: a root)
+          bool far = false;
+          uint32_t back = 0;
+          if (live && !(g1 & 0x10000u)) {
+            if (gd <= lane) {
+              par = lane - gd;
+            } else {
+              back = gd - lane;  // bytes before this round's first
+              far = true;
+            }
+          }
+          if (__ballot(far)) {
+            own_output_visible();
+            if (far) val = ld_out(op - back);
+          }
+          if (__ballot(par != lane)) {
+            for (;;) {
+              const uint32_t pp = (uint32_t)__shfl((int)par, (int)par, 64);
+              const bool changed = pp != par;
+              par = pp;
+              if (!__ballot(changed)) break;
+            }
+            val = (uint32_t)__shfl((int)val, (int)par, 64);
+          }
+          if (live) dst[op + lane] = (uint8_t)val;
+        }
+        op += total;
+      } else if (total) {
+        // long rounds (window A only): literal runs by their lanes, copies in order
+        const uint64_t litmask = __ballot(in_chain && is_lit);
+        uint64_t mm = __ballot(in_chain && !is_lit);
+        const uint32_t outlen = (recA >> 16) & 0x1ffu;
+        const uint64_t op0 = op;
+        uint32_t done_lanes = 0;  // chain lanes below this bit offset are finished
+        while (mm && st == ZH_OK) {
+          const uint32_t g = (uint32_t)__ffsll((long long)mm) - 1u;
+          mm &= mm - 1;
+          const uint64_t grp = litmask & ((1ull << g) - 1ull) & (~0ull << done_lanes);
+          if (grp) {
+            const uint32_t nl = (uint32_t)__popcll(grp);
+            if (!count_only) {
+              if (op + nl > cap) { st = ZH_ERR_DST_TOO_SMALL; break; }
+              if ((grp >> lane) & 1ull) dst[op0 + opre] = (uint8_t)valA;
+            }
+            op += nl;
+          }
+          lz_copy(__builtin_amdgcn_readlane(outlen, g), __builtin_amdgcn_readlane(valA, g));
+          done_lanes = g + 1u;
+        }
+        if (st == ZH_OK) {
+          const uint64_t grp = done_lanes < 64u ? litmask & (~0ull << done_lanes) : 0ull;
+          if (grp) {
+            const uint32_t nl = (uint32_t)__popcll(grp);
+            if (!count_only) {
+              if (op + nl > cap) st = ZH_ERR_DST_TOO_SMALL;
+              else if ((grp >> lane) & 1ull) dst[op0 + opre] = (uint8_t)valA;
+            }
+            op += nl;
+          }
+        }
+      }
+      if (st == ZH_OK) {
+        if (tail == kTailLiteral) {
+          if (!count_only) {
+            if (op + 1 > cap) st = ZH_ERR_DST_TOO_SMALL;
+            else if (lane == 0) dst[op] = (uint8_t)tail_a;
+          }
+          op += 1;
+        } else if (tail == kTailMatch) {
+          lz_copy(tail_a, tail_b);
+        } else if (tail == kTailStored) {  // inflate.nim:252-266: tail_a raw bytes
+          if (!count_only) {
+            if (op + tail_a > cap) {
+              st = ZH_ERR_DST_TOO_SMALL;
+            } else {
+              const uint8_t* raw = reinterpret_cast<const uint8_t*>(asrc) + tail_off;
+              for (uint32_t i = lane; i < tail_a; i += 64) dst[op + i] = raw[i];
+            }
+          }
+          op += tail_a;
+        }
+      }
+      if (st != ZH_OK && lane == 0) s_ostatus = st;
+    }
+    if (st == ZH_OK && op > cap && !count_only) st = ZH_ERR_DST_TOO_SMALL;
+    if (lane == 0) {
+      a.out_len[sid] = op;
+      a.status[sid] = st;
+    }
+    KPROF_COUNT(3, 1);
+    KPROF_FLUSH(16, 4);
+    return;
+  }
+
+  // =========================== DECODE wave ===========================
+  // input: the stream is addressed in bits from the 4-byte aligned base below `src`; 64 dwords
+  // at a time go through a 512-byte LDS ring (bitstreams.nim:22-49's refill)
   const uint64_t end = mis + src_len;  // first byte offset (from asrc) past the stream
   auto load_dword = [&](uint64_t off) -> uint32_t {  // bytes past the end read as zero
     if (off >= end) return 0u;
@@ -316,48 +532,30 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
     return zh_bcast(values[id]);
   };
 
-  seek(((uint64_t)mis + a.body_pos[sid]) * 8);
-
-  uint64_t op = 0;  // bytes produced
+  KPROF_DECL(4);  // decode wave: 0 waiting for the output wave, 1 working; 2 rounds; 3 waves
+  uint32_t rk = 0;  // rounds handed over so far
   int st = ZH_OK;
-  // The LZ window is the output itself: match sources are read back from HBM/L2 past this
-  // CU's L1 (which may hold a stale copy of a line the wave has since extended), after the
-  // wave's earlier stores have completed.
-  auto own_output_visible = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); };
-  auto ld_out = [&](uint64_t at) -> uint32_t {
-    return __hip_atomic_load(dst + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  // inflate.nim:224-250: one LZ copy of `length` bytes from `dist` back, at op (wave-uniform)
-  auto lz_copy = [&](uint32_t length, uint32_t dist) {
-    if (dist > op) {  // inflate.nim:224-225
-      st = ZH_ERR_INVALID_BUFFER;
-      return;
+  // hand a round without chain tokens to the output wave
+  auto send_tail = [&](uint32_t tail, uint32_t ta, uint32_t tb, uint64_t toff) {
+    RoundDesc& d = s_desc[rk & 1u];
+    if (lane == 0) {
+      d.total = 0;
+      d.use_b = 0;
+      d.tail = tail;
+      d.tail_a = ta;
+      d.tail_b = tb;
+      d.tail_off = toff;
     }
-    if (!count_only) {
-      if (op + length > cap) {
-        st = ZH_ERR_DST_TOO_SMALL;
-        return;
-      }
-      // byte-sequential LZ77 copy semantics; an overlapping copy (dist < length) repeats the
-      // dist-byte pattern, so every lane reads its source from the region already written
-      KPROF_COUNT(8, 1);
-      own_output_visible();
-      const uint64_t sb = op - dist;
-      if (dist >= length) {
-        for (uint32_t i = lane; i < length; i += 64) dst[op + i] = (uint8_t)ld_out(sb + i);
-      } else if (dist == 1) {
-        const uint8_t v = (uint8_t)ld_out(sb);
-        for (uint32_t i = lane; i < length; i += 64) dst[op + i] = v;
-      } else {
-        for (uint32_t i = lane; i < length; i += 64) dst[op + i] = (uint8_t)ld_out(sb + i % dist);
-      }
-    }
-    op += length;
+    KPROF_MARK(1);
+    __syncthreads();
+    KPROF_MARK(0);
+    rk++;
+    if (st == ZH_OK && s_ostatus != ZH_OK) st = s_ostatus;
   };
 
+  seek(((uint64_t)mis + a.body_pos[sid]) * 8);
   bool final_block = false;
   while (!final_block && st == ZH_OK) {  // inflate.nim:273-289
-    KPROF_MARK(4);
     hc = 0;
     need();
     const uint32_t bfinal = take(1), btype = take(2);
@@ -371,11 +569,7 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
       if (len + nlen != 65535u) { st = ZH_ERR_INVALID_BUFFER; break; }
       const uint64_t byte_pos = bp >> 3;  // from asrc
       if (byte_pos + len > end) { st = ZH_ERR_END_OF_BUFFER; break; }
-      if (op + len > cap && !count_only) { st = ZH_ERR_DST_TOO_SMALL; break; }
-      const uint8_t* raw = reinterpret_cast<const uint8_t*>(asrc) + byte_pos;
-      if (!count_only)
-        for (uint32_t i = lane; i < len; i += 64) dst[op + i] = raw[i];
-      op += len;
+      send_tail(kTailStored, len, 0, byte_pos);
       seek((byte_pos + len) * 8);
       continue;
     }
@@ -447,21 +641,18 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
       st = build_table(s_lens + dist_at, hdist, s_dst, kDistBits, 1, &s_tab_dist, s_val_dist, s_cnt);
       if (st != ZH_OK) break;
     }
-    KPROF_MARK(0);
 
     for (;;) {  // inflate.nim:173-250, one round = up to 128 bit positions
       ensure();
-      KPROF_COUNT(7, 1);
       // ---- every lane decodes the tokens that would start at bits bp + lane (window A)
-      // and bp + 64 + lane (window B): two independent dependency chains per lane, so the
-      // second costs little latency; B is used when A's chain runs into it cleanly and
-      // both together make at most 64 bytes ----
+      // and bp + 64 + lane (window B): two independent dependency chains per lane; B is
+      // used when A's chain runs into it cleanly and both together make at most 64 bytes ----
       const uint32_t wi = (uint32_t)((bp + lane) >> 5), sh = ((uint32_t)bp + lane) & 31u;
       const uint32_t d0 = s_in[wi & (kInWords - 1u)], d1 = s_in[(wi + 1u) & (kInWords - 1u)],
                      d2 = s_in[(wi + 2u) & (kInWords - 1u)], d3 = s_in[(wi + 3u) & (kInWords - 1u)],
                      d4 = s_in[(wi + 4u) & (kInWords - 1u)];
       struct Tok {
-        uint32_t v_lo, v_hi, e, tbits, outlen, distval;
+        uint32_t v_lo, v_hi, e, tbits, outlen, val;  // val: literal byte or match distance
         bool is_lit;
       };
       auto decode_tok = [&](uint32_t v_lo, uint32_t v_hi) -> Tok {
@@ -477,7 +668,7 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
         const uint32_t o2 = L + eb;  // <= 15
         const uint32_t de = s_dst[(uint32_t)(v >> o2) & ((1u << kDistBits) - 1u)];
         const uint32_t o3 = o2 + (de & 15u), deb = (de >> 4) & 15u;
-        t.distval = (de >> 16) + ((uint32_t)(v >> o3) & ((1u << deb) - 1u));
+        t.val = t.is_lit ? (e >> 16) & 0xffu : (de >> 16) + ((uint32_t)(v >> o3) & ((1u << deb) - 1u));
         if (t.is_lit) t.tbits = L;  // bits of the whole token; 0x8000: not decodable here
         else if (e != 0 && ((e >> 8) & 3u) == kKindBase && de != 0 && ((de >> 8) & 3u) == kKindBase) t.tbits = o3 + deb;
         else t.tbits = 0x8000u;
@@ -559,122 +750,23 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
         if (totalA + totalB > 64u || totalA == 0u) {  // window A alone this time
           useB = false;
           in_chainB = false;
-          chainB = 0;
           totalB = 0;
           pos = posA;
         }
       }
-      const uint64_t litmask = chain & __ballot(A.is_lit);
-      uint64_t mm = chain & ~litmask;
-      KPROF_COUNT(5, __popcll(chain) + __popcll(chainB));
-      KPROF_MARK(1);
-      // ---- output ----
-      const uint32_t total = totalA + totalB;
-      const uint32_t e = A.e, lenval = A.outlen, distval = A.distval;  // (names of the long-round path)
-      if (total - 1u < 64u) {
-        // 1..64 bytes (the usual round): one lane per OUTPUT byte.  Each byte finds its token
-        // (token starts scattered by output offset, running maximum), literals carry their
-        // value, match bytes read the ring (or written-back output behind it), bytes copied
-        // from this round's own output chase their source down to such a root by pointer
-        // doubling -- inflate.nim:227-250's byte-sequential copy semantics without a loop
-        // over the tokens.
-        const bool is_match = in_chain && !A.is_lit, is_matchB = in_chainB && !B.is_lit;
-        if (__ballot((is_match && (uint64_t)A.distval > op + opre) ||
-                     (is_matchB && (uint64_t)B.distval > op + opreB))) {  // inflate.nim:224-225
-          st = ZH_ERR_INVALID_BUFFER;
-        } else if (!count_only && op + total > cap) {
-          st = ZH_ERR_DST_TOO_SMALL;
-        } else if (!count_only) {
-          KPROF_COUNT(6, __popcll(mm) + __popcll(__ballot(is_matchB)));
-          zh_wave_sync();
-          s_map[lane] = 0;
-          zh_wave_sync();
-          if (in_chain) s_map[opre] = (uint8_t)(lane + 1u);
-          if (in_chainB) s_map[opreB] = (uint8_t)(lane + 65u);
-          zh_wave_sync();
-          const uint32_t tk = zh_wave_scan_max(s_map[lane]);  // token (window, lane) + 1 of output byte `lane`
-          const uint32_t j = (tk - 1u) & 63u;
-          const bool fromB = tk > 64u;
-          const uint32_t f1 = (A.is_lit ? 0x100u : 0u) | (((A.e >> 16) & 0xffu) << 16);
-          uint32_t g1 = (uint32_t)__shfl((int)f1, (int)j, 64);
-          uint32_t gd = (uint32_t)__shfl((int)A.distval, (int)j, 64);
-          if (useB) {
-            const uint32_t f1B = (B.is_lit ? 0x100u : 0u) | (((B.e >> 16) & 0xffu) << 16);
-            const uint32_t g1B = (uint32_t)__shfl((int)f1B, (int)j, 64);
-            const uint32_t gdB = (uint32_t)__shfl((int)B.distval, (int)j, 64);
-            if (fromB) {
-              g1 = g1B;
-              gd = gdB;
-            }
-          }
-          const bool live = lane < total;
-          uint32_t val = (g1 >> 16) & 0xffu;
-          uint32_t par = lane;  // source byte inside this round (itself: a root)
-          bool far = false;
-          uint32_t back = 0;
-          if (live && !(g1 & 0x100u)) {
-            if (gd <= lane) {
-              par = lane - gd;
-            } else {
-              back = gd - lane;  // bytes before this round's first
-              far = true;
-            }
-          }
-          if (__ballot(far)) {
-            KPROF_COUNT(8, 1);
-            own_output_visible();
-            if (far) val = ld_out(op - back);
-          }
-          if (__ballot(par != lane)) {
-            for (;;) {
-              const uint32_t pp = (uint32_t)__shfl((int)par, (int)par, 64);
-              const bool changed = pp != par;
-              par = pp;
-              if (!__ballot(changed)) break;
-            }
-            val = (uint32_t)__shfl((int)val, (int)par, 64);
-          }
-          if (live) dst[op + lane] = (uint8_t)val;
-        }
-        op += total;
-      } else {
-        // long or empty rounds (window A only): literal runs by their lanes, copies in order
-        const uint64_t op0 = op;
-        uint32_t done_lanes = 0;  // chain lanes below this bit offset are finished
-        while (mm && st == ZH_OK) {
-          const uint32_t g = (uint32_t)__ffsll((long long)mm) - 1u;
-          mm &= mm - 1;
-          const uint64_t grp = litmask & ((1ull << g) - 1ull) & (~0ull << done_lanes);
-          if (grp) {
-            const uint32_t nl = (uint32_t)__popcll(grp);
-            if (!count_only) {
-              if (op + nl > cap) { st = ZH_ERR_DST_TOO_SMALL; break; }
-              if ((grp >> lane) & 1ull) dst[op0 + opre] = (uint8_t)(e >> 16);
-            }
-            op += nl;
-          }
-          KPROF_COUNT(6, 1);
-          lz_copy(__builtin_amdgcn_readlane(lenval, g), __builtin_amdgcn_readlane(distval, g));
-          done_lanes = g + 1u;
-        }
-        if (st == ZH_OK) {
-          const uint64_t grp = done_lanes < 64u ? litmask & (~0ull << done_lanes) : 0ull;
-          if (grp) {
-            const uint32_t nl = (uint32_t)__popcll(grp);
-            if (!count_only) {
-              if (op + nl > cap) st = ZH_ERR_DST_TOO_SMALL;
-              else if ((grp >> lane) & 1ull) dst[op0 + opre] = (uint8_t)(e >> 16);
-            }
-            op += nl;
-          }
-        }
+      // ---- hand the round over ----
+      RoundDesc& d = s_desc[rk & 1u];
+      d.rec[0][lane] = (opre & 0xffffu) | (A.outlen << 16) | (in_chain ? 1u << 25 : 0u) | (A.is_lit ? 1u << 26 : 0u);
+      d.val[0][lane] = (uint16_t)A.val;
+      if (useB) {
+        d.rec[1][lane] = (opreB & 0xffffu) | (B.outlen << 16) | (in_chainB ? 1u << 25 : 0u) | (B.is_lit ? 1u << 26 : 0u);
+        d.val[1][lane] = (uint16_t)B.val;
       }
-      if (st != ZH_OK) break;
       bp += pos;
       bool block_done = false;
+      uint32_t tail = kTailNone, tail_a = 0, tail_b = 0;
       if (pos < 64u || (useB && pos < 128u)) {
         // ---- the token at bp stopped the chain: decode it alone (inflate.nim:67-102) ----
-        KPROF_COUNT(9, 1);
         // (the builtin returns int: widen through uint32_t, or the low word sign-extends)
         uint32_t sv_lo, sv_hi, se;
         if (pos < 64u) {
@@ -699,11 +791,8 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
         sv >>= used;
         const uint32_t kind = (se >> 8) & 3u;
         if (se & 0x8000u) {  // a literal with a long code
-          if (!count_only) {
-            if (op + 1 > cap) st = ZH_ERR_DST_TOO_SMALL;
-            else if (lane == 0) dst[op] = (uint8_t)(se >> 16);
-          }
-          op += 1;
+          tail = kTailLiteral;
+          tail_a = (se >> 16) & 0xffu;
         } else if (kind == kKindEob) {
           block_done = true;
         } else if (kind == kKindBad) {  // inflate.nim:202-204
@@ -727,29 +816,35 @@ __global__ __launch_bounds__(64) void zh_inflate_kernel(const uint8_t* __restric
             st = ZH_ERR_INVALID_BUFFER;
           } else {
             const uint32_t sdeb = (sde >> 4) & 15u;
-            const uint32_t dist = (sde >> 16) + ((uint32_t)sv & ((1u << sdeb) - 1u));
+            tail = kTailMatch;
+            tail_a = length;
+            tail_b = (sde >> 16) + ((uint32_t)sv & ((1u << sdeb) - 1u));
             used += sdeb;
-            KPROF_COUNT(6, 1);
-            lz_copy(length, dist);
           }
         }
         bp += used;
       }
-      KPROF_MARK(2);
       // tokens decoded from beyond the end of the input are caught here at the latest
       if (st == ZH_OK && past_end()) st = ZH_ERR_END_OF_BUFFER;
+      if (lane == 0) {
+        d.total = st == ZH_OK ? totalA + totalB : 0u;
+        d.use_b = useB ? 1u : 0u;
+        d.tail = st == ZH_OK ? tail : kTailNone;
+        d.tail_a = tail_a;
+        d.tail_b = tail_b;
+      }
+      KPROF_MARK(1);
+      __syncthreads();
+      KPROF_MARK(0);
+      KPROF_COUNT(2, 1);
+      rk++;
+      if (st == ZH_OK && s_ostatus != ZH_OK) st = s_ostatus;
       if (st != ZH_OK || block_done) break;
     }
   }
-
-  if (st == ZH_OK && op > cap && !count_only) st = ZH_ERR_DST_TOO_SMALL;
-  if (lane == 0) {
-    a.out_len[sid] = op;
-    a.status[sid] = st;
-  }
-  KPROF_MARK(4);
-  KPROF_COUNT(10, 1);
-  KPROF_FLUSH(16, 11);
+  send_tail(kTailEnd, (uint32_t)st, 0, 0);
+  KPROF_COUNT(3, 1);
+  KPROF_FLUSH(24, 4);
 }
 
 // Final check of each stream against its trailer (gzip.nim:80-88, zippy.nim:152-162).
@@ -774,7 +869,7 @@ extern "C" void zh_launch_unwrap(hipStream_t stream, const uint8_t* d_src, ZhInf
 extern "C" void zh_launch_inflate(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst,
                                   ZhInflateArgs a) {
   if (!a.nbufs) return;
-  hipLaunchKernelGGL(zh_inflate_kernel, dim3(a.nbufs), dim3(64), 0, stream, d_src, d_dst, a);
+  hipLaunchKernelGGL(zh_inflate_kernel, dim3(a.nbufs), dim3(128), 0, stream, d_src, d_dst, a);
 }
 extern "C" void zh_launch_verify(hipStream_t stream, ZhInflateArgs a, const uint32_t* buf_crc,
                                  const uint32_t* buf_adler) {
