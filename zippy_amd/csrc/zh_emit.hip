@@ -20,7 +20,7 @@
 namespace {
 __constant__ zh::LenTables c_len = zh::make_len_tables();
 __constant__ zh::DistTables c_dist = zh::make_dist_tables();
-constexpr uint32_t kStageWords = 1024;                 // 4 KiB staging window
+constexpr uint32_t kStageWords = 512;                  // 2 KiB staging window
 constexpr uint32_t kFlushBits = (kStageWords - 200) * 32;  // flush threshold: a 256-position pass adds < 6400 bits
 }  // namespace
 
