@@ -52,7 +52,9 @@ def main():
             "fetch_kib_raw_per_launch": round(fk / fc, 1) if fc else 0,
             "write_kib_raw_per_launch": round(wk / wc, 1) if wc else 0,
             "hbm_bytes_per_launch": int(fb + wb),
-            "note": "FETCH corrected by the dwordx4-stream factor; WRITE_SIZE as reported (uncalibrated)",
+            "hbm_bytes_per_launch_uncorrected": int((fk * 1024.0 / fc if fc else 0.0) + wb),
+            "note": "FETCH corrected by the dwordx4-stream factor (an upper bound for narrow gathers, whose "
+                    "requests are 64 B and counted as such); WRITE_SIZE as reported (uncalibrated)",
         }
     print(json.dumps(out, indent=1))
 
