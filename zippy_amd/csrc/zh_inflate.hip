@@ -238,16 +238,14 @@ namespace {
 constexpr uint32_t kTailNone = 0, kTailLiteral = 1, kTailMatch = 2, kTailStored = 3, kTailEnd = 4;
 
 struct RoundDesc {
-  // per lane and window: output offset (16) | output length (9) << 16 | in chain << 25 | literal << 26
+  // per lane and window: output length (9) | literal << 9 | in chain << 10 | value << 16
+  // (value: the literal byte, or the match distance)
   uint32_t rec[2][64];
-  uint16_t val[2][64];  // literal byte, or match distance
-  uint32_t total;       // bytes the chain tokens produce
-  uint32_t use_b;       // window B holds tokens too
-  uint32_t tail;        // what follows the chain (kTail*)
-  uint32_t tail_a;      // literal byte | match length | stored length | final status
-  uint32_t tail_b;      // match distance
-  uint32_t pad;
-  uint64_t tail_off;    // stored run: offset of its first byte in the compressed stream
+  uint32_t use_b;    // window B holds tokens too
+  uint32_t tail;     // what follows the chain (kTail*)
+  uint32_t tail_a;   // literal byte | match length | stored length | final status
+  uint32_t tail_b;   // match distance
+  uint64_t tail_off; // stored run: offset of its first byte in the compressed stream
 };
 
 }  // namespace
@@ -328,22 +326,30 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
       KPROF_MARK(0);
       KPROF_COUNT(2, 1);
       const RoundDesc& d = s_desc[k & 1u];
-      const uint32_t total = d.total, use_b = d.use_b, tail = d.tail, tail_a = d.tail_a, tail_b = d.tail_b;
+      const uint32_t use_b = d.use_b, tail = d.tail, tail_a = d.tail_a, tail_b = d.tail_b;
       const uint64_t tail_off = d.tail_off;
-      const uint32_t recA = d.rec[0][lane], valA = d.val[0][lane];
-      uint32_t recB = 0, valB = 0;
-      if (use_b) {
-        recB = d.rec[1][lane];
-        valB = d.val[1][lane];
-      }
+      const uint32_t recA = d.rec[0][lane];
+      const uint32_t recB = use_b ? d.rec[1][lane] : 0u;
       if (tail == kTailEnd) {
         if (st == ZH_OK) st = (int)tail_a;
         break;
       }
       if (st != ZH_OK) continue;  // failed: keep taking rounds until the decode wave stops
-      const bool in_chain = (recA >> 25) & 1u, is_lit = (recA >> 26) & 1u;
-      const bool in_chainB = (recB >> 25) & 1u, is_litB = (recB >> 26) & 1u;
-      const uint32_t opre = recA & 0xffffu, opreB = recB & 0xffffu;
+      // where every token's output goes: prefix sums of the chain's output lengths
+      const bool in_chain = (recA >> 10) & 1u, is_lit = (recA >> 9) & 1u;
+      const bool in_chainB = (recB >> 10) & 1u, is_litB = (recB >> 9) & 1u;
+      const uint32_t valA = recA >> 16, valB = recB >> 16;
+      const uint32_t lenA = in_chain ? recA & 0x1ffu : 0u, lenB = in_chainB ? recB & 0x1ffu : 0u;
+      const uint32_t inclA = zh_wave_scan(lenA);
+      const uint32_t opre = inclA - lenA;
+      const uint32_t totalA = (uint32_t)__builtin_amdgcn_readlane(inclA, 63);
+      uint32_t opreB = 0, totalB = 0;
+      if (use_b) {
+        const uint32_t inclB = zh_wave_scan(lenB);
+        opreB = totalA + inclB - lenB;
+        totalB = (uint32_t)__builtin_amdgcn_readlane(inclB, 63);
+      }
+      const uint32_t total = totalA + totalB;
       if (total - 1u < 64u) {
         const bool is_match = in_chain && !is_lit, is_matchB = in_chainB && !is_litB;
         if (__ballot((is_match && (uint64_t)valA > op + opre) ||
@@ -398,38 +404,42 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
         }
         op += total;
       } else if (total) {
-        // long rounds (window A only): literal runs by their lanes, copies in order
-        const uint64_t litmask = __ballot(in_chain && is_lit);
-        uint64_t mm = __ballot(in_chain && !is_lit);
-        const uint32_t outlen = (recA >> 16) & 0x1ffu;
+        // long rounds: per window, literal runs by their lanes and copies in order
         const uint64_t op0 = op;
-        uint32_t done_lanes = 0;  // chain lanes below this bit offset are finished
-        while (mm && st == ZH_OK) {
-          const uint32_t g = (uint32_t)__ffsll((long long)mm) - 1u;
-          mm &= mm - 1;
-          const uint64_t grp = litmask & ((1ull << g) - 1ull) & (~0ull << done_lanes);
-          if (grp) {
-            const uint32_t nl = (uint32_t)__popcll(grp);
-            if (!count_only) {
-              if (op + nl > cap) { st = ZH_ERR_DST_TOO_SMALL; break; }
-              if ((grp >> lane) & 1ull) dst[op0 + opre] = (uint8_t)valA;
+        auto long_window = [&](bool chain_w, bool lit_w, uint32_t rec_w, uint32_t opre_w) {
+          const uint64_t litmask = __ballot(chain_w && lit_w);
+          uint64_t mm = __ballot(chain_w && !lit_w);
+          uint32_t done_lanes = 0;  // chain lanes below this bit offset are finished
+          while (mm && st == ZH_OK) {
+            const uint32_t g = (uint32_t)__ffsll((long long)mm) - 1u;
+            mm &= mm - 1;
+            const uint64_t grp = litmask & ((1ull << g) - 1ull) & (~0ull << done_lanes);
+            if (grp) {
+              const uint32_t nl = (uint32_t)__popcll(grp);
+              if (!count_only) {
+                if (op + nl > cap) { st = ZH_ERR_DST_TOO_SMALL; break; }
+                if ((grp >> lane) & 1ull) dst[op0 + opre_w] = (uint8_t)(rec_w >> 16);
+              }
+              op += nl;
             }
-            op += nl;
+            const uint32_t r = __builtin_amdgcn_readlane(rec_w, g);
+            lz_copy(r & 0x1ffu, r >> 16);
+            done_lanes = g + 1u;
           }
-          lz_copy(__builtin_amdgcn_readlane(outlen, g), __builtin_amdgcn_readlane(valA, g));
-          done_lanes = g + 1u;
-        }
-        if (st == ZH_OK) {
-          const uint64_t grp = done_lanes < 64u ? litmask & (~0ull << done_lanes) : 0ull;
-          if (grp) {
-            const uint32_t nl = (uint32_t)__popcll(grp);
-            if (!count_only) {
-              if (op + nl > cap) st = ZH_ERR_DST_TOO_SMALL;
-              else if ((grp >> lane) & 1ull) dst[op0 + opre] = (uint8_t)valA;
+          if (st == ZH_OK) {
+            const uint64_t grp = done_lanes < 64u ? litmask & (~0ull << done_lanes) : 0ull;
+            if (grp) {
+              const uint32_t nl = (uint32_t)__popcll(grp);
+              if (!count_only) {
+                if (op + nl > cap) st = ZH_ERR_DST_TOO_SMALL;
+                else if ((grp >> lane) & 1ull) dst[op0 + opre_w] = (uint8_t)(rec_w >> 16);
+              }
+              op += nl;
             }
-            op += nl;
           }
-        }
+        };
+        long_window(in_chain, is_lit, recA, opre);
+        if (use_b && st == ZH_OK) long_window(in_chainB, is_litB, recB, opreB);
       }
       if (st == ZH_OK) {
         if (tail == kTailLiteral) {
@@ -538,8 +548,8 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
   // hand a round without chain tokens to the output wave
   auto send_tail = [&](uint32_t tail, uint32_t ta, uint32_t tb, uint64_t toff) {
     RoundDesc& d = s_desc[rk & 1u];
+    d.rec[0][lane] = 0;
     if (lane == 0) {
-      d.total = 0;
       d.use_b = 0;
       d.tail = tail;
       d.tail_a = ta;
@@ -688,8 +698,7 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
         chain |= 1ull << pos;
         pos += tv;
       }
-      const uint32_t posA = pos;
-      bool useB = pos >= 64u;
+      const bool useB = pos >= 64u;
       if (useB) {
         while (pos < 128u) {
           const uint32_t tv = __builtin_amdgcn_readlane(B.tbits, pos - 64u);
@@ -717,8 +726,7 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
             : [tb] "v"(A.tbits)
             : "scc");
       }
-      const uint32_t posA = pos;
-      bool useB = pos >= 64u;
+      const bool useB = pos >= 64u;
       if (useB) {
         uint32_t tv;
         asm volatile(
@@ -736,32 +744,11 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
             : "scc");
       }
 #endif
-      const bool in_chain = (chain >> lane) & 1ull;
-      const uint32_t incl = zh_wave_scan(in_chain ? A.outlen : 0u);
-      const uint32_t opre = incl - (in_chain ? A.outlen : 0u);  // output offset of this lane's A token
-      const uint32_t totalA = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
-      uint32_t opreB = 0, totalB = 0;
-      bool in_chainB = false;
-      if (useB) {
-        in_chainB = (chainB >> lane) & 1ull;
-        const uint32_t inclB = zh_wave_scan(in_chainB ? B.outlen : 0u);
-        totalB = (uint32_t)__builtin_amdgcn_readlane(inclB, 63);
-        opreB = totalA + inclB - (in_chainB ? B.outlen : 0u);
-        if (totalA + totalB > 64u || totalA == 0u) {  // window A alone this time
-          useB = false;
-          in_chainB = false;
-          totalB = 0;
-          pos = posA;
-        }
-      }
-      // ---- hand the round over ----
+      // ---- hand the round over (the output wave works out the offsets) ----
       RoundDesc& d = s_desc[rk & 1u];
-      d.rec[0][lane] = (opre & 0xffffu) | (A.outlen << 16) | (in_chain ? 1u << 25 : 0u) | (A.is_lit ? 1u << 26 : 0u);
-      d.val[0][lane] = (uint16_t)A.val;
-      if (useB) {
-        d.rec[1][lane] = (opreB & 0xffffu) | (B.outlen << 16) | (in_chainB ? 1u << 25 : 0u) | (B.is_lit ? 1u << 26 : 0u);
-        d.val[1][lane] = (uint16_t)B.val;
-      }
+      d.rec[0][lane] = A.outlen | (A.is_lit ? 1u << 9 : 0u) | ((uint32_t)((chain >> lane) & 1ull) << 10) | (A.val << 16);
+      if (useB)
+        d.rec[1][lane] = B.outlen | (B.is_lit ? 1u << 9 : 0u) | ((uint32_t)((chainB >> lane) & 1ull) << 10) | (B.val << 16);
       bp += pos;
       bool block_done = false;
       uint32_t tail = kTailNone, tail_a = 0, tail_b = 0;
@@ -827,7 +814,6 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
       // tokens decoded from beyond the end of the input are caught here at the latest
       if (st == ZH_OK && past_end()) st = ZH_ERR_END_OF_BUFFER;
       if (lane == 0) {
-        d.total = st == ZH_OK ? totalA + totalB : 0u;
         d.use_b = useB ? 1u : 0u;
         d.tail = st == ZH_OK ? tail : kTailNone;
         d.tail_a = tail_a;
