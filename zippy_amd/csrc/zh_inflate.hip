@@ -29,7 +29,7 @@ __constant__ zh::LenTables c_len = zh::make_len_tables();
 __constant__ zh::DistTables c_dist = zh::make_dist_tables();
 __constant__ uint8_t c_clcl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-constexpr uint32_t kLitBits = 10, kDistBits = 7;
+constexpr uint32_t kLitBits = 10, kDistBits = 8;
 constexpr uint32_t kInWords = 128;   // staging ring of the compressed stream (dwords, power of two)
 
 }  // namespace
