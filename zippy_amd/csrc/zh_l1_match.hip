@@ -71,8 +71,16 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
     table_size <<= 1;
     shift--;
   }
-  if (!huffman_only)
-    for (uint32_t i = lane; i < table_size / 8; i += 64) reinterpret_cast<uint4*>(s_table)[i] = make_uint4(0, 0, 0, 0);
+  // A table entry is position | tag << 15: the tag is one more bit of the hash product of the
+  // position's four bytes, so a probe whose tag differs cannot match and need not fetch the
+  // candidate's bytes (half of the non-matching gathers, which are what this kernel's memory
+  // traffic is made of).  "Empty" is the reference's zero = position 0, with position 0's tag.
+  if (!huffman_only) {
+    const uint32_t e0 = n >= 4 ? (((ld32(0) * kHashMul) >> 17) & 1u) << 15 : 0u;
+    const uint32_t fill = e0 | (e0 << 16);
+    for (uint32_t i = lane; i < table_size / 8; i += 64)
+      reinterpret_cast<uint4*>(s_table)[i] = make_uint4(fill, fill, fill, fill);
+  }
   zh_wave_sync();
   KPROF_MARK(0);
 
@@ -129,10 +137,13 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         const uint32_t pq = pos + mis, pw = pq >> 2;
         const uint32_t p0 = dw(pw), p1 = dw(pw + 1), p2 = dw(pw + 2), p3 = dw(pw + 3), p4 = dw(pw + 4);
         const uint32_t a0 = __builtin_amdgcn_alignbyte(p1, p0, pq);
-        const uint32_t h = (a0 * kHashMul) >> shift;
+        const uint32_t hp = a0 * kHashMul;
+        const uint32_t h = hp >> shift, tag = (hp >> 17) & 1u;
         // round trip 2: the table slot; every lane also ticks a counter of its (folded) hash,
         // read back together with the candidate bytes
-        const uint32_t old = __hip_atomic_load(s_table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t oldw = __hip_atomic_load(s_table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t old = oldw & 0x7fffu;
+        const bool fetch = valid && (oldw >> 15) == tag;  // equal bytes have equal tags
         const uint32_t ck = (h & 8191u) >> 2, cs = (h & 3u) * 8u;
         if (valid) atomicAdd(&s_scr[ck], 1u << cs);
         zh_wave_sync();  // (orders the counter traffic between lanes; emits nothing)
@@ -141,11 +152,18 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         const uint32_t a3 = __builtin_amdgcn_alignbyte(p4, p3, pq);
         // round trip 3: 16 bytes at the candidate the table held when the step began
         const uint32_t oq = old + mis, ow = oq >> 2;
-        const uint32_t q0 = dw(ow), q1 = dw(ow + 1), q2 = dw(ow + 2), q3 = dw(ow + 3), q4 = dw(ow + 4);
+        uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
+        if (fetch) {
+          q0 = dw(ow);
+          q1 = dw(ow + 1);
+          q2 = dw(ow + 2);
+          q3 = dw(ow + 3);
+          q4 = dw(ow + 4);
+        }
         const uint32_t cnt = valid ? (s_scr[ck] >> cs) & 255u : 0u;
         zh_wave_sync();
         if (valid) s_scr[ck] = 0;
-        const uint32_t x0 = a0 ^ __builtin_amdgcn_alignbyte(q1, q0, oq);
+        const uint32_t x0 = fetch ? a0 ^ __builtin_amdgcn_alignbyte(q1, q0, oq) : 1u;
         const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(q2, q1, oq);
         const uint32_t x2 = a2 ^ __builtin_amdgcn_alignbyte(q3, q2, oq);
         const uint32_t x3 = a3 ^ __builtin_amdgcn_alignbyte(q4, q3, oq);
@@ -413,12 +431,12 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         if (finished) break;  // nothing reads the table any more
         // ---- table inserts of the probes that really happened, in probe order ----
         const bool mine = (ins >> lane) & 1ull;
-        if (mine && !((C >> lane) & 1ull)) s_table[h] = (uint16_t)pos;
+        if (mine && !((C >> lane) & 1ull)) s_table[h] = (uint16_t)(pos | (tag << 15));
         uint64_t cc = ins & C;
         while (cc) {  // probes that share a slot write one by one (the later one wins)
           const uint32_t jx = (uint32_t)__ffsll((long long)cc) - 1u;
           cc &= cc - 1;
-          if (lane == jx) s_table[h] = (uint16_t)pos;
+          if (lane == jx) s_table[h] = (uint16_t)(pos | (tag << 15));
         }
         zh_wave_sync();
         KPROF_MARK(4);
