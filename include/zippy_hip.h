@@ -150,6 +150,50 @@ void zh_plan_set_profiling(zh_plan *plan, int on);
 int zh_plan_kernel_times(zh_plan *plan, const char **names, float *ms, int max_entries);
 
 /* ------------------------------------------------------------------ *
+ * Block-parallel form of ONE large buffer (BASELINE.json config 5).   *
+ * The reference cuts a buffer into deflate blocks of 4 MiB            *
+ * (deflate.nim:228, internal.nim:16) and calls the matcher once per   *
+ * block (deflate.nim:243-272), so no match ever reaches across a      *
+ * block start: a block can be decoded by itself once its bit position *
+ * is known.  These entry points expose that: the same encoder with    *
+ * the block size as a parameter (block_bytes: a multiple of 32768,    *
+ * 32768 .. 4194304; 4194304 reproduces zh_compress byte for byte),    *
+ * and the index of block starts that lets the decoder run one wave    *
+ * pair per block instead of one per stream.  The stream stays plain   *
+ * RFC 1951/1950/1952: zippy's uncompress() (and zh_uncompress) decode *
+ * it without the index.                                               *
+ * ------------------------------------------------------------------ */
+typedef struct zh_block_entry {
+  uint64_t bit_off; /* block's BFINAL bit, in bits from the start of the compressed buffer */
+  uint64_t out_off; /* offset of the block's first byte in the uncompressed data */
+} zh_block_entry;
+
+/* index: library-allocated (zh_free), n_entries = deflate blocks + 1; the closing entry holds
+ * the bit just past the last block and the uncompressed length.  A stored logical block longer
+ * than 65535 bytes contributes one entry per stored chunk (deflate.nim:179-205). */
+int zh_compress_blocks(zh_ctx *ctx, const void *src, size_t len, int level, int data_format,
+                       size_t block_bytes, void **dst, size_t *dst_len, zh_block_entry **index,
+                       size_t *n_entries);
+/* Decode with one decoder per index entry.  Fails with ZH_ERR_INVALID_BUFFER when a block does
+ * not produce exactly the bytes its entry promises (or reaches back before its own start);
+ * container checks and checksum as in zh_uncompress. */
+int zh_uncompress_indexed(zh_ctx *ctx, const void *src, size_t len, int data_format,
+                          const zh_block_entry *index, size_t n_entries, void **dst,
+                          size_t *dst_len);
+
+/* Device-resident forms.  zh_plan_compress_blocks = zh_plan_compress with the block size;
+ * after zh_plan_run + zh_plan_results, zh_plan_block_index returns buffer `buf`'s index
+ * (library-allocated, zh_free).  zh_plan_uncompress_indexed plans ONE stream
+ * d_src[src_off .. +src_len) -> d_dst[dst_off .. +dst_cap) with its index (host array). */
+int zh_plan_compress_blocks(zh_ctx *ctx, size_t n, const uint64_t *src_off, const uint64_t *src_len,
+                            const uint64_t *dst_off, const uint64_t *dst_cap, int level,
+                            int data_format, size_t block_bytes, zh_plan **out);
+int zh_plan_block_index(zh_plan *plan, size_t buf, zh_block_entry **index, size_t *n_entries);
+int zh_plan_uncompress_indexed(zh_ctx *ctx, uint64_t src_off, uint64_t src_len, uint64_t dst_off,
+                               uint64_t dst_cap, int data_format, const zh_block_entry *index,
+                               size_t n_entries, zh_plan **out);
+
+/* ------------------------------------------------------------------ *
  * Introspection for parity tests (not part of the drop-in surface).   *
  * ------------------------------------------------------------------ */
 /* Level-1 parse of one buffer as the u16 token stream of SURVEY.md 8a row a4

@@ -55,6 +55,10 @@ def lib():
         L.zo_free.argtypes = [ctypes.c_void_p]
         L.zo_compress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_int, ctypes.POINTER(_Buf)]
+        L.zo_compress_blocks.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(_Buf),
+                                         ctypes.POINTER(ctypes.POINTER(ctypes.c_uint64)),
+                                         ctypes.POINTER(ctypes.c_size_t)]
         L.zo_uncompress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int,
                                     ctypes.POINTER(_Buf)]
         L.zo_deflate.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int,
@@ -93,6 +97,21 @@ def compress(src, level=DefaultCompression, dataFormat=dfGzip, fname_len=0):
     buf = _Buf()
     st = lib().zo_compress(src, len(src), level, dataFormat, fname_len, ctypes.byref(buf))
     return _take(buf, st)
+
+
+def compress_blocks(src, level=DefaultCompression, dataFormat=dfGzip, block_bytes=32768, fname_len=0):
+    """Block-parallel variant (BASELINE config 5): compress() with deflate blocks of block_bytes,
+    plus the index [(bit_off, out_off), ...] of block starts (last entry closes the list)."""
+    src = bytes(src)
+    buf = _Buf()
+    idx = ctypes.POINTER(ctypes.c_uint64)()
+    n = ctypes.c_size_t(0)
+    st = lib().zo_compress_blocks(src, len(src), level, dataFormat, fname_len, block_bytes,
+                                  ctypes.byref(buf), ctypes.byref(idx), ctypes.byref(n))
+    data = _take(buf, st)
+    entries = [(idx[2 * i], idx[2 * i + 1]) for i in range(n.value)]
+    lib().zo_free(idx)
+    return data, entries
 
 
 def uncompress(src, dataFormat=dfDetect):

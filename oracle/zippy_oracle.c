@@ -714,6 +714,34 @@ int zo_huffman_codes(const uint32_t *freq, int num_freq, int min_codes, int code
 /* ------------------------------------------------------------------ */
 /* deflate.nim:179-205 addNoCompressionBlock                            */
 /* ------------------------------------------------------------------ */
+/* Block-parallel variant (BASELINE.json config 5, not in the reference): the same driver with
+ * deflate.nim:228's block size as a parameter, and a record of where every deflate block begins.
+ * Each block restarts the matcher (deflate.nim:243-272 call it per block), so a block can be
+ * decoded on its own from its bit position. */
+static _Thread_local size_t opt_block_size = MAX_BLOCK_SIZE;
+static _Thread_local struct {
+  zo_block_entry *e;
+  size_t n, cap;
+  int on, err;
+} opt_index;
+
+static void index_note(const bit_writer *b, size_t out_off) {
+  if (!opt_index.on) return;
+  if (opt_index.n == opt_index.cap) {
+    size_t cap = opt_index.cap ? opt_index.cap * 2 : 64;
+    zo_block_entry *e = (zo_block_entry *)realloc(opt_index.e, cap * sizeof(*e));
+    if (!e) {
+      opt_index.err = 1;
+      return;
+    }
+    opt_index.e = e;
+    opt_index.cap = cap;
+  }
+  opt_index.e[opt_index.n].bit_off = (uint64_t)b->pos * 8 + (uint64_t)b->bit_pos;
+  opt_index.e[opt_index.n].out_off = out_off;
+  opt_index.n++;
+}
+
 static void add_no_compression_block(bit_writer *b, const uint8_t *src, size_t block_start,
                                      size_t block_len, int final_block) {
   size_t count = (block_len + MAX_UNCOMPRESSED_BLOCK_SIZE - 1) / MAX_UNCOMPRESSED_BLOCK_SIZE;
@@ -723,6 +751,7 @@ static void add_no_compression_block(bit_writer *b, const uint8_t *src, size_t b
     size_t ustart = block_start + num * MAX_UNCOMPRESSED_BLOCK_SIZE;
     size_t ulen = block_start + block_len - ustart;
     if (ulen > MAX_UNCOMPRESSED_BLOCK_SIZE) ulen = MAX_UNCOMPRESSED_BLOCK_SIZE;
+    index_note(b, ustart);
     bw_add_bits(b, (final_block && ufinal) ? 1 : 0, 1);
     bw_add_bits(b, 0, 2);
     bw_skip_remaining_bits(b);
@@ -752,12 +781,14 @@ int zo_deflate(const uint8_t *src, size_t len, int level, zo_buf *out) {
       add_no_compression_block(&b, src, block_start, block_len, final_block);
     }
     if (b.err) return b.err;
+    index_note(&b, len);
     if (buf_reserve(out, b.pos)) return ZO_ERR_NOMEM;
     out->len = b.pos;
     return ZO_OK;
   }
 
-  size_t block_count = (len + MAX_BLOCK_SIZE - 1) / MAX_BLOCK_SIZE; /* :228 */
+  const size_t max_block = opt_block_size;
+  size_t block_count = (len + max_block - 1) / max_block; /* :228 */
   if (block_count < 1) block_count = 1;
 
   tokvec enc = {0};
@@ -766,9 +797,9 @@ int zo_deflate(const uint8_t *src, size_t len, int level, zo_buf *out) {
   int status = ZO_OK;
 
   for (size_t num = 0; num < block_count && status == ZO_OK; num++) {
-    size_t block_start = num * MAX_BLOCK_SIZE;
+    size_t block_start = num * max_block;
     size_t block_len = len - block_start;
-    if (block_len > MAX_BLOCK_SIZE) block_len = MAX_BLOCK_SIZE;
+    if (block_len > max_block) block_len = max_block;
     int final_block = num == block_count - 1;
 
     enc.len = 0;
@@ -811,6 +842,7 @@ int zo_deflate(const uint8_t *src, size_t len, int level, zo_buf *out) {
     }
 
     if (use_fixed) { /* :296-298 */
+      index_note(&b, block_start);
       bw_add_bits(&b, final_block ? 1 : 0, 1);
       bw_add_bits(&b, 1, 2);
     } else {
@@ -881,6 +913,7 @@ int zo_deflate(const uint8_t *src, size_t len, int level, zo_buf *out) {
       int hlit = n_litlen - FIRST_LENGTH_CODE_INDEX;
       int hdist = n_dist - 1;
 
+      index_note(&b, block_start);
       bw_add_bits(&b, final_block ? 1 : 0, 1); /* :376-383 */
       bw_add_bits(&b, 2, 2);
       bw_add_bits(&b, (uint32_t)hlit, 5);
@@ -963,6 +996,7 @@ int zo_deflate(const uint8_t *src, size_t len, int level, zo_buf *out) {
   free(rle);
   if (status != ZO_OK) return status;
   if (b.err) return b.err;
+  index_note(&b, len);
   bw_skip_remaining_bits(&b);
   if (buf_reserve(out, b.pos + 8)) return ZO_ERR_NOMEM;
   out->len = b.pos;
@@ -1395,6 +1429,27 @@ int zo_compress(const uint8_t *src, size_t len, int level, int data_format, int 
     default:
       return ZO_ERR_INVALID_FORMAT;
   }
+}
+
+int zo_compress_blocks(const uint8_t *src, size_t len, int level, int data_format, int fname_len,
+                       size_t block_bytes, zo_buf *out, zo_block_entry **index, size_t *n_entries) {
+  if (block_bytes < MAX_WINDOW_SIZE || block_bytes > MAX_BLOCK_SIZE || block_bytes % MAX_WINDOW_SIZE)
+    return ZO_ERR_INVALID_FORMAT;
+  if (out->len != 0) return ZO_ERR_INVALID_FORMAT; /* positions are relative to the buffer start */
+  opt_block_size = block_bytes;
+  memset(&opt_index, 0, sizeof(opt_index));
+  opt_index.on = 1;
+  int st = zo_compress(src, len, level, data_format, fname_len, out);
+  opt_block_size = MAX_BLOCK_SIZE;
+  opt_index.on = 0;
+  if (st == ZO_OK && opt_index.err) st = ZO_ERR_NOMEM;
+  if (st != ZO_OK) {
+    free(opt_index.e);
+    return st;
+  }
+  *index = opt_index.e;
+  *n_entries = opt_index.n;
+  return ZO_OK;
 }
 
 const char *zo_strerror(int status) {

@@ -79,6 +79,19 @@ void zo_free(void *p);
 int zo_compress(const uint8_t *src, size_t len, int level, int data_format,
                 int fname_len, zo_buf *out);
 
+/* Block-parallel variant (BASELINE.json config 5; no counterpart in the reference): zo_compress
+ * with deflate.nim:228's 4 MiB block size replaced by block_bytes (a multiple of 32768, <= 4 MiB)
+ * plus the index of deflate block starts.  Entry k: bit offset of block k's BFINAL bit from the
+ * start of the compressed buffer, and the offset of its first output byte; one closing entry
+ * holds the bit just past the last block and the total length.  The stream itself is an
+ * ordinary RFC 1951 stream that zo_uncompress / zlib decode. */
+typedef struct {
+  uint64_t bit_off;
+  uint64_t out_off;
+} zo_block_entry;
+int zo_compress_blocks(const uint8_t *src, size_t len, int level, int data_format, int fname_len,
+                       size_t block_bytes, zo_buf *out, zo_block_entry **index, size_t *n_entries);
+
 /* src/zippy.nim:100-165, src/zippy/gzip.nim:3-88 */
 int zo_uncompress(const uint8_t *src, size_t len, int data_format, zo_buf *out);
 

@@ -160,3 +160,44 @@ def check_error_statuses(eng):
             eng.compress(b"x", level)
     with pytest.raises(ZippyError):
         eng.compress(b"x", 1, oracle.dfDetect)
+
+
+def check_blocks(eng, src, levels, block_sizes, formats=(oracle.dfGzip,)):
+    """Block-parallel form (BASELINE config 5): bytes and index equal the oracle's at the same block
+    size, the stream round-trips through the oracle's plain uncompress() and zlib, and the indexed
+    decode returns the input."""
+    import zlib
+    for level in levels:
+        for bb in block_sizes:
+            for fmt in formats:
+                want, want_idx = oracle.compress_blocks(src, level, fmt, bb, fname_len=0)
+                got, idx = eng.compress_blocks(src, level, fmt, bb)
+                assert got == want, "level %d block %d fmt %d: bytes differ" % (level, bb, fmt)
+                assert idx == want_idx, "level %d block %d fmt %d: index differs" % (level, bb, fmt)
+                assert oracle.uncompress(got, fmt) == src
+                wbits = {oracle.dfGzip: 31, oracle.dfZlib: 15, oracle.dfDeflate: -15}[fmt]
+                assert zlib.decompress(got, wbits) == src
+                assert eng.uncompress_indexed(got, idx, fmt) == src
+                assert eng.uncompress(got, fmt) == src
+                if bb == 4194304:
+                    assert got == oracle.compress(src, level, fmt, fname_len=0)
+
+
+def check_blocks_bad_index(eng, src):
+    """An index that does not describe the stream fails the call instead of returning wrong bytes."""
+    import pytest
+    from zippy_amd.common import ZippyError
+    got, idx = eng.compress_blocks(src, 1, oracle.dfGzip, 32768)
+    assert len(idx) >= 4
+    for bad in (
+        [idx[0], (idx[1][0] + 1, idx[1][1])] + idx[2:],          # block 1 starts one bit late
+        [idx[0], (idx[1][0], idx[1][1] - 7)] + idx[2:],          # block 0 promises 7 bytes less
+        idx[:-1] + [(idx[-1][0], idx[-1][1] + 1)],               # total one byte too long
+        [idx[0], idx[2]] + idx[2:],                              # repeated entry: block skipped
+    ):
+        with pytest.raises(ZippyError):
+            eng.uncompress_indexed(got, bad, oracle.dfGzip)
+    damaged = bytearray(got)
+    damaged[len(damaged) // 2] ^= 0x10
+    with pytest.raises(ZippyError):
+        eng.uncompress_indexed(bytes(damaged), idx, oracle.dfGzip)

@@ -45,6 +45,18 @@ def test_emu_multi_block_buffer(eng):
     pc.check_tokens(eng, src, 1)
 
 
+def test_emu_block_parallel_form(eng):
+    # BASELINE config 5 in small: independent 32 KiB / 64 KiB blocks + index, all matcher families
+    src = (synth.corpus_file("alice29.txt")[:70000] + synth.gen_batch("rand", 1, 40000)[0].tobytes() +
+           b"\x00" * 30000 + synth.corpus_file("html")[:25000])
+    pc.check_blocks(eng, src, levels=(1,), block_sizes=(32768, 65536, 4194304),
+                    formats=(oracle.dfGzip, oracle.dfDeflate))
+    pc.check_blocks(eng, src[:100000], levels=(-1, 0, -2), block_sizes=(32768,), formats=(oracle.dfZlib,))
+    pc.check_blocks(eng, b"", levels=(1,), block_sizes=(32768,))
+    pc.check_blocks(eng, b"x" * 32768, levels=(1,), block_sizes=(32768,))
+    pc.check_blocks_bad_index(eng, src)
+
+
 def test_emu_roundtrip_and_random_fname(eng):
     bufs = [b.tobytes() for b in synth.gen_batch("mix", 4, 65536)]
     pc.check_roundtrip(eng, bufs, 1)

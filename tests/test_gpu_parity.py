@@ -122,6 +122,28 @@ def test_gpu_config5_single_large_buffer(eng):
     assert eng.uncompress(out) == src
 
 
+def test_gpu_config5_block_parallel_100mib(eng):
+    """BASELINE.json configs[4]: one 100 MiB+ buffer as independent 32 KiB deflate blocks; the
+    stream and its block index equal the oracle's, the indexed decode (one decoder per block)
+    and the plain decode both return the input."""
+    src = synth.gen_batch("mix", 104, 1 << 20).tobytes()
+    want, want_idx = oracle.compress_blocks(src, 1, oracle.dfGzip, 32768, fname_len=0)
+    got, idx = eng.compress_blocks(src, 1, oracle.dfGzip, 32768)
+    assert got == want and idx == want_idx
+    assert len(idx) >= 104 * 32 + 1
+    assert eng.uncompress_indexed(got, idx, oracle.dfGzip) == src
+    assert zlib.decompress(got, 31) == src
+
+
+def test_gpu_block_parallel_levels_and_bad_index(eng, golds):
+    src = golds["alice29.txt"][:150000] + synth.gen_batch("rand", 1, 70000)[0].tobytes() + golds["html"]
+    pc.check_blocks(eng, src, levels=(1, -1, 0, -2, 9), block_sizes=(32768, 131072, 4194304),
+                    formats=(oracle.dfGzip,))
+    pc.check_blocks(eng, src, levels=(1, 6), block_sizes=(65536,), formats=(oracle.dfZlib, oracle.dfDeflate))
+    pc.check_blocks(eng, b"", levels=(1,), block_sizes=(32768,))
+    pc.check_blocks_bad_index(eng, src)
+
+
 def test_gpu_property_roundtrip_kinds(eng):
     for kind in ("runs", "rand", "zero", "mix"):
         bufs = [b.tobytes() for b in synth.gen_batch(kind, 32, 200000 + 7)]

@@ -49,6 +49,21 @@ _SIGS = {
     "zh_plan_set_profiling": (None, [_c.c_void_p, _c.c_int]),
     "zh_plan_kernel_times": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_char_p),
                                         _c.POINTER(_c.c_float), _c.c_int]),
+    "zh_compress_blocks": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int,
+                                      _c.c_size_t, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
+                                      _c.POINTER(_c.POINTER(_c.c_uint64)), _c.POINTER(_c.c_size_t)]),
+    "zh_uncompress_indexed": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int,
+                                         _c.POINTER(_c.c_uint64), _c.c_size_t,
+                                         _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t)]),
+    "zh_plan_compress_blocks": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_uint64),
+                                           _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64),
+                                           _c.POINTER(_c.c_uint64), _c.c_int, _c.c_int, _c.c_size_t,
+                                           _c.POINTER(_c.c_void_p)]),
+    "zh_plan_block_index": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.POINTER(_c.POINTER(_c.c_uint64)),
+                                       _c.POINTER(_c.c_size_t)]),
+    "zh_plan_uncompress_indexed": (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_uint64,
+                                              _c.c_uint64, _c.c_int, _c.POINTER(_c.c_uint64),
+                                              _c.c_size_t, _c.POINTER(_c.c_void_p)]),
     "zh_debug_tokens": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int,
                                    _c.POINTER(_c.POINTER(_c.c_uint16)), _c.POINTER(_c.c_size_t)]),
 }
@@ -88,6 +103,16 @@ class Plan:
         sts = (_c.c_int32 * self.n)()
         self.engine._check(self.engine.lib.zh_plan_results(self._h, lens, sts))
         return list(lens), list(sts)
+
+    def block_index(self, buf=0):
+        """[(bit_off, out_off), ...] of buffer `buf` of a compress plan (zh_plan_block_index)."""
+        idx = _c.POINTER(_c.c_uint64)()
+        n = _c.c_size_t()
+        self.engine._check(self.engine.lib.zh_plan_block_index(self._h, buf, _c.byref(idx), _c.byref(n)))
+        try:
+            return [(idx[2 * i], idx[2 * i + 1]) for i in range(n.value)]
+        finally:
+            self.engine.lib.zh_free(idx)
 
     def device_lens(self):
         return self.engine.lib.zh_plan_device_lens(self._h)
@@ -189,6 +214,31 @@ class Engine:
         outs, sts = self.uncompress_batch([src], data_format)
         return self._raise_first(outs, sts)[0]
 
+    # ---- block-parallel form of one large buffer (BASELINE config 5) ----
+    def compress_blocks(self, src, level=DefaultCompression, data_format=dfGzip, block_bytes=32768):
+        """-> (compressed bytes, [(bit_off, out_off), ...])"""
+        src = bytes(src)
+        dst, dlen = _c.c_void_p(), _c.c_size_t()
+        idx, n = _c.POINTER(_c.c_uint64)(), _c.c_size_t()
+        self._check(self.lib.zh_compress_blocks(self._h, src, len(src), level, data_format, block_bytes,
+                                                _c.byref(dst), _c.byref(dlen), _c.byref(idx), _c.byref(n)))
+        try:
+            return _c.string_at(dst, dlen.value), [(idx[2 * i], idx[2 * i + 1]) for i in range(n.value)]
+        finally:
+            self.lib.zh_free(dst)
+            self.lib.zh_free(idx)
+
+    def uncompress_indexed(self, src, index, data_format=dfDetect):
+        src = bytes(src)
+        flat = _u64([v for e in index for v in e])
+        dst, dlen = _c.c_void_p(), _c.c_size_t()
+        self._check(self.lib.zh_uncompress_indexed(self._h, src, len(src), data_format, flat, len(index),
+                                                   _c.byref(dst), _c.byref(dlen)))
+        try:
+            return _c.string_at(dst, dlen.value)
+        finally:
+            self.lib.zh_free(dst)
+
     def crc32(self, src):
         src = bytes(src)
         out = _c.c_uint32()
@@ -217,6 +267,21 @@ class Engine:
                                                 _u64(dst_off), _u64(dst_cap), data_format,
                                                 _c.byref(h)))
         return Plan(self, h, n)
+
+    def plan_compress_blocks(self, src_off, src_len, dst_off, dst_cap, level, data_format, block_bytes):
+        h = _c.c_void_p()
+        n = len(src_off)
+        self._check(self.lib.zh_plan_compress_blocks(self._h, n, _u64(src_off), _u64(src_len),
+                                                     _u64(dst_off), _u64(dst_cap), level, data_format,
+                                                     block_bytes, _c.byref(h)))
+        return Plan(self, h, n)
+
+    def plan_uncompress_indexed(self, src_off, src_len, dst_off, dst_cap, index, data_format=dfDetect):
+        h = _c.c_void_p()
+        flat = _u64([v for e in index for v in e])
+        self._check(self.lib.zh_plan_uncompress_indexed(self._h, src_off, src_len, dst_off, dst_cap,
+                                                        data_format, flat, len(index), _c.byref(h)))
+        return Plan(self, h, 1)
 
     def stream(self):
         return self.lib.zh_stream(self._h)

@@ -46,6 +46,17 @@ def uncompress_batch(bufs, dataFormat=dfDetect):
     return engine().uncompress_batch(bufs, dataFormat)
 
 
+def compress_blocks(src, level=DefaultCompression, dataFormat=dfGzip, block_bytes=32768):
+    """compress() with deflate blocks of block_bytes instead of deflate.nim:228's 4 MiB, plus the
+    index of block starts; the stream still round-trips through zippy's uncompress()."""
+    return engine().compress_blocks(src, level, dataFormat, block_bytes)
+
+
+def uncompress_indexed(src, index, dataFormat=dfDetect):
+    """uncompress() of a stream whose block index is known: one decoder per block."""
+    return engine().uncompress_indexed(src, index, dataFormat)
+
+
 def crc32(src):
     return engine().crc32(src)
 

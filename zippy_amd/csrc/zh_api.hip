@@ -27,6 +27,7 @@ void zh_launch_checksum_combine(hipStream_t, const ZhBufDesc* bufs, uint32_t nbu
 void zh_launch_unwrap(hipStream_t, const uint8_t* d_src, ZhInflateArgs a);
 void zh_launch_inflate(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a);
 void zh_launch_verify(hipStream_t, ZhInflateArgs a, const uint32_t* buf_crc, const uint32_t* buf_adler);
+void zh_launch_segments_reduce(hipStream_t, ZhInflateArgs seg, ZhInflateArgs whole);
 void zh_launch_l1_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int huffman_only,
                         uint16_t* table_pool);
 uint32_t zh_l1_table_slots(void);
@@ -190,6 +191,13 @@ struct zh_plan {
   uint64_t* out_len = nullptr;
   int32_t* status = nullptr;
   const uint64_t* src_len_dev = nullptr;
+  // block index (zh_plan_block_index): host copies of the geometry
+  std::vector<ZhBufDesc> h_bufs;
+  std::vector<ZhBlockDesc> h_blocks;
+  // block-parallel decode (zh_plan_uncompress_indexed): `ia` describes the one stream, `seg` its blocks
+  bool indexed = false;
+  ZhInflateArgs seg{};
+  uint8_t* seg_arena = nullptr;
   // profiling
   bool profiling = false;
   std::vector<const char*> k_names;
@@ -231,6 +239,7 @@ extern "C" void zh_plan_destroy(zh_plan* p) {
   if (!p) return;
   hipStreamSynchronize(p->ctx->stream);
   if (p->arena) hipFree(p->arena);
+  if (p->seg_arena) hipFree(p->seg_arena);
   for (auto e : p->k_events) hipEventDestroy(e);
   delete p;
 }
@@ -240,11 +249,19 @@ static T* carve(uint8_t* base, size_t off) {
   return reinterpret_cast<T*>(base + off);
 }
 
-extern "C" int zh_plan_compress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
-                                const uint64_t* src_len, const uint64_t* dst_off,
-                                const uint64_t* dst_cap, int level, int data_format, zh_plan** out) {
+static bool valid_block_bytes(size_t bb) {
+  return bb >= ZH_FRAG_SIZE && bb <= ZH_BLOCK_SIZE && bb % ZH_FRAG_SIZE == 0;
+}
+
+extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* src_off,
+                                       const uint64_t* src_len, const uint64_t* dst_off,
+                                       const uint64_t* dst_cap, int level, int data_format,
+                                       size_t block_bytes, zh_plan** out) {
   if (!ctx || !out || (n && (!src_off || !src_len || !dst_off || !dst_cap))) return ZH_ERR_ARGUMENT;
   *out = nullptr;
+  // whole fragments per block keep lz77.nim:78's block-relative window position equal to
+  // lz77.nim:123's absolute one
+  if (!valid_block_bytes(block_bytes)) return ZH_ERR_ARGUMENT;
   if (level < -2 || level > 9) return ZH_ERR_INVALID_LEVEL;  // deflate.nim:208-209
   if (data_format != ZH_DF_GZIP && data_format != ZH_DF_ZLIB && data_format != ZH_DF_DEFLATE)
     return ZH_ERR_INVALID_FORMAT;  // zippy.nim:83-84
@@ -269,7 +286,7 @@ extern "C" int zh_plan_compress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
     b.pad = 0;
     // deflate.nim:228: blocks of <= 4 MiB; level 0 uses one run of stored chunks over the
     // whole buffer (deflate.nim:214-226)
-    const uint64_t bsize = level == 0 ? (b.src_len ? b.src_len : 1) : ZH_BLOCK_SIZE;
+    const uint64_t bsize = level == 0 ? (b.src_len ? b.src_len : 1) : block_bytes;
     uint64_t nb = (b.src_len + bsize - 1) / bsize;
     if (nb < 1) nb = 1;
     for (uint64_t j = 0; j < nb; j++) {
@@ -323,7 +340,8 @@ extern "C" int zh_plan_compress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
   const size_t o_pcrc = ar.reserve(nf * 4), o_pad = ar.reserve(nf * 4), o_plen = ar.reserve(nf * 4);
   const size_t o_bmode = ar.reserve(nb * 4), o_blit = ar.reserve(nb * 288 * 4),
                o_bdist = ar.reserve(nb * 32 * 4), o_bhdr = ar.reserve(nb * ZH_HDR_WORDS * 4),
-               o_bhb = ar.reserve(nb * 4), o_bbits = ar.reserve(nb * 8), o_bd0 = ar.reserve(nb * 8);
+               o_bhb = ar.reserve(nb * 4), o_bbits = ar.reserve(nb * 8), o_bd0 = ar.reserve(nb * 8),
+               o_bst = ar.reserve((nb + n) * 8);
   const size_t o_bcrc = ar.reserve(n * 4), o_bad = ar.reserve(n * 4), o_olen = ar.reserve(n * 8),
                o_st = ar.reserve(n * 4);
   p->head_bytes = chain ? nb * ((size_t)2 << 17) : 0;
@@ -382,6 +400,7 @@ extern "C" int zh_plan_compress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
   a.b_hdr_bits = carve<uint32_t>(base, o_bhb);
   a.b_bits = carve<uint64_t>(base, o_bbits);
   a.b_stored_d0 = carve<uint64_t>(base, o_bd0);
+  a.b_start = carve<uint64_t>(base, o_bst);
   p->buf_crc = carve<uint32_t>(base, o_bcrc);
   p->buf_adler = carve<uint32_t>(base, o_bad);
   a.out_len = p->out_len = carve<uint64_t>(base, o_olen);
@@ -390,7 +409,56 @@ extern "C" int zh_plan_compress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
   p->l1_tables = carve<uint16_t>(base, o_l1tab);
   p->chain_prev = carve<uint16_t>(base, o_cprev);
   p->chain_best = carve<uint32_t>(base, o_cbest);
+  p->h_bufs.swap(bufs);
+  p->h_blocks.swap(blocks);
   *out = p;
+  return ZH_OK;
+}
+
+extern "C" int zh_plan_compress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
+                                const uint64_t* src_len, const uint64_t* dst_off,
+                                const uint64_t* dst_cap, int level, int data_format, zh_plan** out) {
+  return zh_plan_compress_blocks(ctx, n, src_off, src_len, dst_off, dst_cap, level, data_format,
+                                 ZH_BLOCK_SIZE, out);  // deflate.nim:228
+}
+
+// Where every deflate block of buffer `buf` begins, from the layout kernel's positions.
+extern "C" int zh_plan_block_index(zh_plan* p, size_t buf, zh_block_entry** index, size_t* n_entries) {
+  if (!p || !p->is_compress || buf >= p->n || !index || !n_entries) return ZH_ERR_ARGUMENT;
+  zh_ctx* ctx = p->ctx;
+  *index = nullptr;
+  *n_entries = 0;
+  const ZhBufDesc& b = p->h_bufs[buf];
+  const size_t nb = b.nblocks, nb_all = p->h_blocks.size();
+  std::vector<uint64_t> start(nb + 1);
+  std::vector<uint32_t> mode(nb);
+  int32_t st = ZH_OK;
+  hipStream_t s = ctx->stream;
+  ZH_HIP(ctx, hipMemcpyAsync(start.data(), p->ca.b_start + b.first_block, nb * 8, hipMemcpyDeviceToHost, s));
+  ZH_HIP(ctx, hipMemcpyAsync(&start[nb], p->ca.b_start + nb_all + buf, 8, hipMemcpyDeviceToHost, s));
+  ZH_HIP(ctx, hipMemcpyAsync(mode.data(), p->ca.b_mode + b.first_block, nb * 4, hipMemcpyDeviceToHost, s));
+  ZH_HIP(ctx, hipMemcpyAsync(&st, p->status + buf, 4, hipMemcpyDeviceToHost, s));
+  ZH_HIP(ctx, hipStreamSynchronize(s));
+  if (st != ZH_OK) return st;
+  const uint64_t hdr_bits =
+      8ull * (p->fmt == ZH_DF_GZIP ? 10 + b.fname_len + 1 : p->fmt == ZH_DF_ZLIB ? 2 : 0);
+  std::vector<zh_block_entry> e;
+  for (size_t k = 0; k < nb; k++) {
+    const ZhBlockDesc& blk = p->h_blocks[b.first_block + k];
+    const uint64_t out_off = blk.src_off - b.src_off;
+    e.push_back(zh_block_entry{hdr_bits + start[k], out_off});
+    if (mode[k] == ZH_MODE_STORED) {  // further stored chunks start on byte boundaries (deflate.nim:179-205)
+      const uint64_t chunks = (blk.len + ZH_STORED_MAX - 1) / ZH_STORED_MAX;
+      const uint64_t first_len_byte = (hdr_bits + start[k] + 3 + 7) >> 3;
+      for (uint64_t c = 1; c < chunks; c++)
+        e.push_back(zh_block_entry{(first_len_byte + c * (ZH_STORED_MAX + 5ull) - 1) * 8, out_off + c * ZH_STORED_MAX});
+    }
+  }
+  e.push_back(zh_block_entry{hdr_bits + start[nb], b.src_len});
+  *index = (zh_block_entry*)malloc(e.size() * sizeof(zh_block_entry));
+  if (!*index) return ZH_ERR_NOMEM;
+  memcpy(*index, e.data(), e.size() * sizeof(zh_block_entry));
+  *n_entries = e.size();
   return ZH_OK;
 }
 
@@ -457,6 +525,66 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
   a.expect_isize = carve<uint32_t>(base, o_ei);
   a.out_len = p->out_len = carve<uint64_t>(base, o_olen);
   a.status = p->status = carve<int32_t>(base, o_st);
+  a.start_bit = nullptr;
+  a.single_block = 0;
+  *out = p;
+  return ZH_OK;
+}
+
+// One stream, one decoder per deflate block (BASELINE config 5).  `ia` keeps describing the
+// stream (container checks, checksum, result); `seg` describes its blocks as if they were streams.
+extern "C" int zh_plan_uncompress_indexed(zh_ctx* ctx, uint64_t src_off, uint64_t src_len,
+                                          uint64_t dst_off, uint64_t dst_cap, int data_format,
+                                          const zh_block_entry* index, size_t n_entries, zh_plan** out) {
+  if (!ctx || !out || !index || n_entries < 2 || n_entries > 0xfffffffeull) return ZH_ERR_ARGUMENT;
+  *out = nullptr;
+  const size_t nseg = n_entries - 1;
+  for (size_t k = 0; k < nseg; k++)
+    if (index[k + 1].out_off < index[k].out_off || index[k + 1].bit_off < index[k].bit_off ||
+        index[k].bit_off >= src_len * 8)
+      return ZH_ERR_ARGUMENT;
+  if (index[0].out_off != 0) return ZH_ERR_ARGUMENT;
+  if (index[nseg].out_off > dst_cap) return ZH_ERR_DST_TOO_SMALL;
+  zh_plan* p = nullptr;
+  const uint64_t total = index[nseg].out_off;
+  int rc = zh_plan_uncompress(ctx, 1, &src_off, &src_len, &dst_off, &total, data_format, &p);
+  if (rc) return rc;
+  std::vector<ZhBufDesc> segs(nseg);
+  std::vector<uint64_t> start(nseg);
+  for (size_t k = 0; k < nseg; k++) {
+    ZhBufDesc& b = segs[k];
+    memset(&b, 0, sizeof(b));
+    b.src_off = src_off;
+    b.src_len = src_len;
+    b.dst_off = dst_off + index[k].out_off;
+    b.dst_cap = index[k + 1].out_off - index[k].out_off;
+    start[k] = index[k].bit_off;
+  }
+  Arena ar;
+  const size_t o_bufs = ar.reserve(nseg * sizeof(ZhBufDesc)), o_start = ar.reserve(nseg * 8),
+               o_olen = ar.reserve(nseg * 8), o_st = ar.reserve(nseg * 4);
+  ar.reserve(256);
+  if (hipMalloc(&p->seg_arena, ar.size) != hipSuccess) {
+    zh_plan_destroy(p);
+    return ZH_ERR_NOMEM;
+  }
+  uint8_t* base = p->seg_arena;
+  hipMemcpyAsync(base + o_bufs, segs.data(), nseg * sizeof(ZhBufDesc), hipMemcpyHostToDevice, ctx->stream);
+  hipMemcpyAsync(base + o_start, start.data(), nseg * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    zh_plan_destroy(p);
+    return ZH_ERR_DEVICE;
+  }
+  ZhInflateArgs& g = p->seg;
+  g = p->ia;
+  g.bufs = carve<ZhBufDesc>(base, o_bufs);
+  g.src_len_dev = nullptr;
+  g.nbufs = (uint32_t)nseg;
+  g.start_bit = carve<uint64_t>(base, o_start);
+  g.single_block = 1;
+  g.out_len = carve<uint64_t>(base, o_olen);
+  g.status = carve<int32_t>(base, o_st);
+  p->indexed = true;
   *out = p;
   return ZH_OK;
 }
@@ -519,7 +647,14 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     prof_mark(p, "zh_unwrap_kernel");
     zh_launch_unwrap(s, d_src, a);
     prof_mark(p, "zh_inflate_kernel");
-    zh_launch_inflate(s, d_src, d_dst, a);
+    if (p->indexed) {
+      ZH_HIP(ctx, hipMemsetAsync(p->seg.status, 0, (size_t)p->seg.nbufs * 4, s));
+      zh_launch_inflate(s, d_src, d_dst, p->seg);
+      prof_mark(p, "zh_segments_reduce_kernel");
+      zh_launch_segments_reduce(s, p->seg, a);
+    } else {
+      zh_launch_inflate(s, d_src, d_dst, a);
+    }
     if (!a.count_only) {
       // both checksums: with dfDetect the format is only known per stream on the device
       const int want_crc = p->fmt == ZH_DF_GZIP || p->fmt == ZH_DF_DETECT;
@@ -771,6 +906,97 @@ extern "C" int zh_uncompress(zh_ctx* ctx, const void* src, size_t len, int data_
   size_t lens[1] = {len};
   int rc = zh_uncompress_batch(ctx, srcs, lens, 1, data_format, dst, dst_len, &st);
   return rc ? rc : st;
+}
+
+extern "C" int zh_compress_blocks(zh_ctx* ctx, const void* src, size_t len, int level, int data_format,
+                                  size_t block_bytes, void** dst, size_t* dst_len,
+                                  zh_block_entry** index, size_t* n_entries) {
+  if (!ctx || !dst || !dst_len || !index || !n_entries || (len && !src)) return ZH_ERR_ARGUMENT;
+  *dst = nullptr;
+  *dst_len = 0;
+  *index = nullptr;
+  *n_entries = 0;
+  if (level < -2 || level > 9) return ZH_ERR_INVALID_LEVEL;
+  if (data_format != ZH_DF_GZIP && data_format != ZH_DF_ZLIB && data_format != ZH_DF_DEFLATE)
+    return ZH_ERR_INVALID_FORMAT;
+  if (!valid_block_bytes(block_bytes)) return ZH_ERR_ARGUMENT;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+  const void* srcs[1] = {src};
+  size_t lens[1] = {len};
+  DevBuf d_src;
+  std::vector<uint64_t> soff, slen;
+  int st = upload(ctx, srcs, lens, 1, d_src, soff, slen);
+  if (st) return st;
+  const size_t nblocks = len / block_bytes + 1;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    uint64_t doff = 0;
+    uint64_t dcap = (attempt == 0 ? typical_cap(len, data_format) : zh_compress_bound(len, data_format)) +
+                    1024 * nblocks;
+    DevBuf d_dst;
+    if (hipMalloc(&d_dst.p, dcap + 256) != hipSuccess) return ZH_ERR_NOMEM;
+    PlanGuard pg;
+    st = zh_plan_compress_blocks(ctx, 1, soff.data(), slen.data(), &doff, &dcap, level, data_format,
+                                 block_bytes, &pg.p);
+    if (st) return st;
+    st = zh_plan_run(pg.p, d_src.p, d_dst.p);
+    if (st) return st;
+    uint64_t olen = 0;
+    int32_t ost = ZH_OK;
+    st = zh_plan_results(pg.p, &olen, &ost);
+    if (st) return st;
+    if (ost == ZH_ERR_DST_TOO_SMALL && attempt == 0) continue;
+    if (ost != ZH_OK) return ost;
+    st = zh_plan_block_index(pg.p, 0, index, n_entries);
+    if (st) return st;
+    *dst = malloc(olen ? olen : 1);
+    if (!*dst) {
+      free(*index);
+      *index = nullptr;
+      *n_entries = 0;
+      return ZH_ERR_NOMEM;
+    }
+    *dst_len = olen;
+    ZH_HIP(ctx, hipMemcpyAsync(*dst, d_dst.p, olen, hipMemcpyDeviceToHost, ctx->stream));
+    ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZH_OK;
+  }
+  return ZH_ERR_DST_TOO_SMALL;
+}
+
+extern "C" int zh_uncompress_indexed(zh_ctx* ctx, const void* src, size_t len, int data_format,
+                                     const zh_block_entry* index, size_t n_entries, void** dst,
+                                     size_t* dst_len) {
+  if (!ctx || !dst || !dst_len || !index || n_entries < 2 || (len && !src)) return ZH_ERR_ARGUMENT;
+  *dst = nullptr;
+  *dst_len = 0;
+  if (data_format < ZH_DF_DETECT || data_format > ZH_DF_DEFLATE) return ZH_ERR_INVALID_FORMAT;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+  const void* srcs[1] = {src};
+  size_t lens[1] = {len};
+  DevBuf d_src;
+  std::vector<uint64_t> soff, slen;
+  int st = upload(ctx, srcs, lens, 1, d_src, soff, slen);
+  if (st) return st;
+  const uint64_t total = index[n_entries - 1].out_off;
+  if (total > (uint64_t)len * 1032 + 64) return ZH_ERR_INVALID_BUFFER;  // deflate cannot expand further
+  DevBuf d_dst;
+  if (hipMalloc(&d_dst.p, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
+  PlanGuard pg;
+  st = zh_plan_uncompress_indexed(ctx, soff[0], slen[0], 0, total, data_format, index, n_entries, &pg.p);
+  if (st) return st == ZH_ERR_ARGUMENT ? ZH_ERR_INVALID_BUFFER : st;
+  st = zh_plan_run(pg.p, d_src.p, d_dst.p);
+  if (st) return st;
+  uint64_t olen = 0;
+  int32_t ost = ZH_OK;
+  st = zh_plan_results(pg.p, &olen, &ost);
+  if (st) return st;
+  if (ost != ZH_OK) return ost;
+  *dst = malloc(olen ? olen : 1);
+  if (!*dst) return ZH_ERR_NOMEM;
+  *dst_len = olen;
+  if (olen) ZH_HIP(ctx, hipMemcpyAsync(*dst, d_dst.p, olen, hipMemcpyDeviceToHost, ctx->stream));
+  ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZH_OK;
 }
 
 static int checksum_host(zh_ctx* ctx, const void* src, size_t len, int want_crc, uint32_t* out) {

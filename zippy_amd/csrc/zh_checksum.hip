@@ -163,35 +163,57 @@ __global__ __launch_bounds__(64) void zh_checksum_pieces_kernel(
 // Combine per-piece checksums of each buffer in order:
 //   crc(A||B)   = crc(A) * x^(8 len B) xor crc(B)                (zlib crc32_combine)
 //   adler(A||B) : s1 = s1A + s1B - 1 ; s2 = s2A + s2B + lenB * (s1A - 1)   (mod 65521)
-__global__ void zh_checksum_combine_kernel(const ZhBufDesc* __restrict__ bufs, uint32_t nbufs,
-                                           const uint32_t* __restrict__ piece_crc,
-                                           const uint32_t* __restrict__ piece_adler,
-                                           const uint32_t* __restrict__ piece_len, int want_crc,
-                                           int want_adler, uint32_t* __restrict__ buf_crc,
-                                           uint32_t* __restrict__ buf_adler) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nbufs) return;
+// One wave per buffer: lane l folds its contiguous share of the pieces, then the 64 partial
+// results are folded pairwise (both combinations are associative).
+__global__ __launch_bounds__(64) void zh_checksum_combine_kernel(
+    const ZhBufDesc* __restrict__ bufs, uint32_t nbufs, const uint32_t* __restrict__ piece_crc,
+    const uint32_t* __restrict__ piece_adler, const uint32_t* __restrict__ piece_len, int want_crc,
+    int want_adler, uint32_t* __restrict__ buf_crc, uint32_t* __restrict__ buf_adler) {
+  const uint32_t i = blockIdx.x;
+  const unsigned lane = threadIdx.x & 63u;
   const ZhBufDesc b = bufs[i];
+  const uint32_t share = (b.npieces + 63u) / 64u;
+  uint32_t k = lane * share, k_end = k + share;
+  if (k > b.npieces) k = b.npieces;
+  if (k_end > b.npieces) k_end = b.npieces;
   uint32_t crc = 0;
-  uint64_t s1 = 1, s2 = 0;
+  uint64_t s1 = 1, s2 = 0, total = 0;
   const uint32_t x_full = gf2_xpow8(32768);
-  for (uint32_t k = 0; k < b.npieces; k++) {
-    uint32_t p = b.first_piece + k;
-    uint32_t len = piece_len[p];
+  for (; k < k_end; k++) {
+    const uint32_t p = b.first_piece + k;
+    const uint32_t len = piece_len[p];
     if (len == 0) continue;
+    total += len;
     if (want_crc) {
-      uint32_t x = len == 32768u ? x_full : gf2_xpow8(len);
+      const uint32_t x = len == 32768u ? x_full : gf2_xpow8(len);
       crc = gf2_mul(x, crc) ^ piece_crc[p];
     }
     if (want_adler) {
-      uint32_t a = piece_adler[p];
-      uint64_t s1b = a & 0xffffu, s2b = a >> 16;
+      const uint32_t a = piece_adler[p];
+      const uint64_t s1b = a & 0xffffu, s2b = a >> 16;
       s2 = (s2 + s2b + (uint64_t)(len % 65521u) * ((s1 + 65520u) % 65521u)) % 65521u;
       s1 = (s1 + s1b + 65520u) % 65521u;
     }
   }
-  if (want_crc) buf_crc[i] = crc;
-  if (want_adler) buf_adler[i] = (uint32_t)((s2 << 16) | s1);
+  for (unsigned d = 1; d < 64; d <<= 1) {  // (this) || (lane + d)
+    const uint32_t crc_r = (uint32_t)__shfl((int)crc, (int)((lane + d) & 63u), 64);
+    const uint64_t tot_r = (uint64_t)(uint32_t)__shfl((int)(uint32_t)total, (int)((lane + d) & 63u), 64) |
+                           ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(total >> 32), (int)((lane + d) & 63u), 64) << 32);
+    const uint32_t s1_r = (uint32_t)__shfl((int)(uint32_t)s1, (int)((lane + d) & 63u), 64);
+    const uint32_t s2_r = (uint32_t)__shfl((int)(uint32_t)s2, (int)((lane + d) & 63u), 64);
+    if ((lane & (2 * d - 1)) == 0 && lane + d < 64) {
+      if (want_crc) crc = gf2_mul(gf2_xpow8(tot_r), crc) ^ crc_r;
+      if (want_adler) {
+        s2 = (s2 + s2_r + (tot_r % 65521u) * ((s1 + 65520u) % 65521u)) % 65521u;
+        s1 = (s1 + s1_r + 65520u) % 65521u;
+      }
+      total += tot_r;
+    }
+  }
+  if (lane == 0) {
+    if (want_crc) buf_crc[i] = crc;
+    if (want_adler) buf_adler[i] = (uint32_t)((s2 << 16) | s1);
+  }
 }
 
 // ---- host side ------------------------------------------------------------
@@ -240,7 +262,7 @@ extern "C" void zh_launch_checksum_combine(hipStream_t stream, const ZhBufDesc* 
                                            const uint32_t* piece_len, int want_crc, int want_adler,
                                            uint32_t* buf_crc, uint32_t* buf_adler) {
   if (!nbufs) return;
-  hipLaunchKernelGGL(zh_checksum_combine_kernel, dim3((nbufs + 63) / 64), dim3(64), 0, stream, bufs,
+  hipLaunchKernelGGL(zh_checksum_combine_kernel, dim3(nbufs), dim3(64), 0, stream, bufs,
                      nbufs, piece_crc, piece_adler, piece_len, want_crc, want_adler, buf_crc,
                      buf_adler);
 }

@@ -78,6 +78,7 @@ struct ZhCompressArgs {
   uint32_t* b_hdr_bits;
   uint64_t* b_bits;        // total bits of the block (header + payload + EOB), compressed modes
   uint64_t* b_stored_d0;   // stored mode: absolute byte of block byte 0 in d_dst
+  uint64_t* b_start;       // bit position of the block's first bit, from the start of the deflate body
   // per buffer
   uint64_t* out_len;
   int32_t* status;
@@ -105,6 +106,9 @@ struct ZhInflateArgs {
   uint32_t* expect_isize;
   uint64_t* out_len;
   int32_t* status;
+  // block-parallel decode (zh_plan_uncompress_indexed): every "stream" is one deflate block
+  const uint64_t* start_bit;     // bit position of the block in its compressed buffer, or null
+  int32_t single_block;          // stop after one block whatever BFINAL says
 };
 
 // ---- wave helpers (single-wave workgroups; lockstep execution on gfx950) ----

@@ -421,31 +421,51 @@ __global__ __launch_bounds__(64) void zh_layout_kernel(uint8_t* __restrict__ d_d
   const uint32_t hdr_len = fmt == ZH_DF_GZIP ? 10 + bd.fname_len + 1 : fmt == ZH_DF_ZLIB ? 2 : 0;
   const uint32_t trailer_len = fmt == ZH_DF_GZIP ? 8 : fmt == ZH_DF_ZLIB ? 4 : 0;
 
-  // ---- pass 1: size of the deflate body (uniform arithmetic) ----
-  uint64_t cursor = 0;  // bits, relative to the start of the deflate body
-  for (uint32_t k = 0; k < bd.nblocks; k++) {
+  // ---- where every block starts (bits from the start of the deflate body), 64 blocks at a time ----
+  auto lane64 = [](uint64_t v, uint32_t j) -> uint64_t {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)j) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)j) << 32);
+  };
+  uint64_t cursor = 0;
+  for (uint32_t k0 = 0; k0 < bd.nblocks; k0 += 64) {
+    const uint32_t k = k0 + lane;
+    const bool have = k < bd.nblocks;
     const uint32_t b = bd.first_block + k;
-    const ZhBlockDesc blk = a.blocks[b];
-    if (a.b_mode[b] == ZH_MODE_STORED) {  // deflate.nim:179-205
-      uint64_t chunks = (blk.len + ZH_STORED_MAX - 1) / ZH_STORED_MAX;
-      if (chunks < 1) chunks = 1;
-      const uint64_t first_len_byte = (cursor + 3 + 7) >> 3;
-      cursor = (first_len_byte + 4 + blk.len + 5 * (chunks - 1)) * 8;
+    const uint32_t mode = have ? a.b_mode[b] : (uint32_t)ZH_MODE_DYNAMIC;
+    const uint64_t bits = have && mode != ZH_MODE_STORED ? a.b_bits[b] : 0ull;
+    const uint64_t blen = have ? a.blocks[b].len : 0ull;
+    uint64_t start = 0;
+    if (!__ballot(have && mode == ZH_MODE_STORED)) {
+      // 64 compressed blocks sum to < 2^32 bits (64 * 4 MiB * 15 bits + headers)
+      const uint32_t incl = zh_wave_scan((uint32_t)bits);
+      start = cursor + (incl - (uint32_t)bits);
+      cursor += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     } else {
-      cursor += a.b_bits[b];
+      // a stored block pads to a byte boundary (deflate.nim:179-205): not additive, walk the batch
+      const uint32_t cnt = bd.nblocks - k0 < 64u ? bd.nblocks - k0 : 64u;
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)mode, (int)j);
+        if (lane == j) start = cursor;
+        if (mj == ZH_MODE_STORED) {
+          const uint64_t lj = lane64(blen, j);
+          uint64_t chunks = (lj + ZH_STORED_MAX - 1) / ZH_STORED_MAX;
+          if (chunks < 1) chunks = 1;
+          const uint64_t first_len_byte = (cursor + 3 + 7) >> 3;
+          cursor = (first_len_byte + 4 + lj + 5 * (chunks - 1)) * 8;
+        } else {
+          cursor += lane64(bits, j);
+        }
+      }
     }
+    if (have) a.b_start[b] = start;
   }
+  if (lane == 0) a.b_start[a.nblocks + bi] = cursor;  // end of the last block (closing index entry)
   const uint64_t body_bytes = (cursor + 7) >> 3;
   const uint64_t total_len = hdr_len + body_bytes + trailer_len;
-  if (total_len > bd.dst_cap) {
+  if (total_len > bd.dst_cap) {  // the block layout kernel skips this buffer
     if (lane == 0) {
       a.out_len[bi] = total_len;
       a.status[bi] = ZH_ERR_DST_TOO_SMALL;
-    }
-    // poison the fragments so that the emission kernel skips this buffer
-    for (uint32_t k = 0; k < bd.nblocks; k++) {
-      const ZhBlockDesc blk = a.blocks[bd.first_block + k];
-      for (uint32_t j = lane; j < blk.nfrag; j += 64) a.f_bit_start[blk.first_frag + j] = ~0ull;
     }
     return;
   }
@@ -467,54 +487,8 @@ __global__ __launch_bounds__(64) void zh_layout_kernel(uint8_t* __restrict__ d_d
     }
   }
 
-  // ---- pass 2: positions, block headers, EOB codes, stored headers ----
-  const uint64_t body_bit0 = (uint64_t)hdr_len * 8;  // relative to `out`
-  cursor = 0;
-  for (uint32_t k = 0; k < bd.nblocks; k++) {
-    const uint32_t b = bd.first_block + k;
-    const ZhBlockDesc blk = a.blocks[b];
-    const uint32_t mode = a.b_mode[b];
-    if (mode == ZH_MODE_STORED) {
-      uint64_t chunks = (blk.len + ZH_STORED_MAX - 1) / ZH_STORED_MAX;
-      if (chunks < 1) chunks = 1;
-      const uint64_t first_len_byte = (body_bit0 + cursor + 3 + 7) >> 3;  // relative to out
-      const uint64_t d0 = first_len_byte + 4;  // block byte o lands at d0 + o + 5 * (o / 65535)
-      for (uint64_t c = lane; c < chunks; c += 64) {
-        const uint32_t fin = (blk.is_final && c == chunks - 1) ? 1u : 0u;
-        const uint64_t clen = (c == chunks - 1) ? blk.len - c * ZH_STORED_MAX : ZH_STORED_MAX;
-        const uint64_t len_byte = d0 - 4 + c * (ZH_STORED_MAX + 5ull);
-        if (c == 0) or_bits(out, body_bit0 + cursor, fin, 3);  // BFINAL + BTYPE=00, then pad
-        else or_bits(out, (len_byte - 1) * 8, fin, 3);
-        or_bits(out, len_byte * 8, (uint32_t)clen | ((uint32_t)(ZH_STORED_MAX - clen) << 16), 32);
-      }
-      if (lane == 0) a.b_stored_d0[b] = bd.dst_off + d0;
-      cursor = (d0 + blk.len + 5 * (chunks - 1)) * 8 - body_bit0;
-    } else {
-      const uint32_t hbits = a.b_hdr_bits[b];
-      const uint32_t* hdr = a.b_hdr + (size_t)b * ZH_HDR_WORDS;
-      for (uint32_t w = lane; w * 32 < hbits; w += 64) {
-        const uint32_t nb = hbits - w * 32 < 32 ? hbits - w * 32 : 32;
-        or_bits(out, body_bit0 + cursor + (uint64_t)w * 32, hdr[w], nb);
-      }
-      cursor += hbits;
-      for (uint32_t base = 0; base < blk.nfrag; base += 64) {
-        const uint32_t j = base + lane;
-        const uint32_t fb = j < blk.nfrag ? a.f_bits[blk.first_frag + j] : 0u;
-        // 64-bit inclusive scan built from the 32-bit one (fragment sums fit in 32 bits:
-        // 64 fragments * 32 KiB * 15 bits < 2^32)
-        const uint32_t incl = zh_wave_scan(fb);
-        if (j < blk.nfrag)
-          a.f_bit_start[blk.first_frag + j] = (bd.dst_off + hdr_len) * 8 + cursor + (incl - fb);
-        cursor += __shfl(incl, 63, 64);
-      }
-      const uint32_t eob = a.b_litcode[(size_t)b * 288 + 256];
-      if (lane == 0) or_bits(out, body_bit0 + cursor, eob & 0xffffu, eob >> 16);  // deflate.nim:471
-      cursor += eob >> 16;
-    }
-  }
-
   // ---- trailer (after padding to a byte, deflate.nim:473) ----
-  const uint64_t tpos = hdr_len + ((cursor + 7) >> 3);
+  const uint64_t tpos = hdr_len + body_bytes;
   if (fmt == ZH_DF_GZIP) {  // zippy.nim:47-58
     const uint32_t crc = buf_crc[bi], isize = (uint32_t)(bd.src_len & 0xffffffffu);
     if (lane < 4) or_byte(out, tpos + lane, crc >> (8 * lane));
@@ -529,6 +503,58 @@ __global__ __launch_bounds__(64) void zh_layout_kernel(uint8_t* __restrict__ d_d
   }
 }
 
+// One wave per block, after zh_layout_kernel: the block's header, the bit position of each of its
+// fragments, its end-of-block code; for a stored block the chunk headers.
+__global__ __launch_bounds__(64) void zh_block_layout_kernel(uint8_t* __restrict__ d_dst, ZhCompressArgs a) {
+  const unsigned lane = zh_lane();
+  const uint32_t b = blockIdx.x;
+  const ZhBlockDesc blk = a.blocks[b];
+  const ZhBufDesc bd = a.bufs[blk.buf];
+  if (a.status[blk.buf] != ZH_OK) {  // poison the fragments so that the emission kernel skips them
+    for (uint32_t j = lane; j < blk.nfrag; j += 64) a.f_bit_start[blk.first_frag + j] = ~0ull;
+    return;
+  }
+  const int fmt = a.data_format;
+  uint8_t* out = d_dst + bd.dst_off;
+  const uint32_t hdr_len = fmt == ZH_DF_GZIP ? 10 + bd.fname_len + 1 : fmt == ZH_DF_ZLIB ? 2 : 0;
+  const uint64_t body_bit0 = (uint64_t)hdr_len * 8;  // relative to `out`
+  uint64_t cursor = a.b_start[b];
+  if (a.b_mode[b] == ZH_MODE_STORED) {
+    uint64_t chunks = (blk.len + ZH_STORED_MAX - 1) / ZH_STORED_MAX;
+    if (chunks < 1) chunks = 1;
+    const uint64_t first_len_byte = (body_bit0 + cursor + 3 + 7) >> 3;  // relative to out
+    const uint64_t d0 = first_len_byte + 4;  // block byte o lands at d0 + o + 5 * (o / 65535)
+    for (uint64_t c = lane; c < chunks; c += 64) {
+      const uint32_t fin = (blk.is_final && c == chunks - 1) ? 1u : 0u;
+      const uint64_t clen = (c == chunks - 1) ? blk.len - c * ZH_STORED_MAX : ZH_STORED_MAX;
+      const uint64_t len_byte = d0 - 4 + c * (ZH_STORED_MAX + 5ull);
+      if (c == 0) or_bits(out, body_bit0 + cursor, fin, 3);  // BFINAL + BTYPE=00, then pad
+      else or_bits(out, (len_byte - 1) * 8, fin, 3);
+      or_bits(out, len_byte * 8, (uint32_t)clen | ((uint32_t)(ZH_STORED_MAX - clen) << 16), 32);
+    }
+    if (lane == 0) a.b_stored_d0[b] = bd.dst_off + d0;
+    return;
+  }
+  const uint32_t hbits = a.b_hdr_bits[b];
+  const uint32_t* hdr = a.b_hdr + (size_t)b * ZH_HDR_WORDS;
+  for (uint32_t w = lane; w * 32 < hbits; w += 64) {
+    const uint32_t nb = hbits - w * 32 < 32 ? hbits - w * 32 : 32;
+    or_bits(out, body_bit0 + cursor + (uint64_t)w * 32, hdr[w], nb);
+  }
+  cursor += hbits;
+  for (uint32_t base = 0; base < blk.nfrag; base += 64) {
+    const uint32_t j = base + lane;
+    const uint32_t fb = j < blk.nfrag ? a.f_bits[blk.first_frag + j] : 0u;
+    // fragment sums fit in 32 bits: 64 fragments * 32 KiB * 15 bits < 2^32
+    const uint32_t incl = zh_wave_scan(fb);
+    if (j < blk.nfrag)
+      a.f_bit_start[blk.first_frag + j] = (bd.dst_off + hdr_len) * 8 + cursor + (incl - fb);
+    cursor += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  }
+  const uint32_t eob = a.b_litcode[(size_t)b * 288 + 256];
+  if (lane == 0) or_bits(out, body_bit0 + cursor, eob & 0xffffu, eob >> 16);  // deflate.nim:471
+}
+
 extern "C" void zh_launch_huffman(hipStream_t stream, ZhCompressArgs a) {
   if (!a.nblocks) return;
   hipLaunchKernelGGL(zh_huffman_kernel, dim3(a.nblocks), dim3(64), 0, stream, a);
@@ -538,4 +564,5 @@ extern "C" void zh_launch_layout(hipStream_t stream, uint8_t* d_dst, ZhCompressA
   if (!a.nbufs) return;
   hipLaunchKernelGGL(zh_layout_kernel, dim3(a.nbufs), dim3(64), 0, stream, d_dst, a, buf_crc,
                      buf_adler);
+  hipLaunchKernelGGL(zh_block_layout_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_dst, a);
 }

@@ -563,13 +563,15 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
     if (st == ZH_OK && s_ostatus != ZH_OK) st = s_ostatus;
   };
 
-  seek(((uint64_t)mis + a.body_pos[sid]) * 8);
+  // a whole stream starts at its deflate body; a block of an indexed stream at its own first bit
+  seek(a.start_bit ? (uint64_t)mis * 8 + a.start_bit[sid] : ((uint64_t)mis + a.body_pos[sid]) * 8);
+  const bool single_block = a.single_block != 0;
   bool final_block = false;
   while (!final_block && st == ZH_OK) {  // inflate.nim:273-289
     hc = 0;
     need();
     const uint32_t bfinal = take(1), btype = take(2);
-    if (bfinal) final_block = true;
+    if (bfinal || single_block) final_block = true;
 
     if (btype == 0) {  // inflate.nim:252-266 inflateNoCompression
       bp = (bp + 7u) & ~(uint64_t)7;
@@ -846,6 +848,39 @@ __global__ void zh_verify_kernel(ZhInflateArgs a, const uint32_t* __restrict__ b
   } else if (fmt == ZH_DF_ZLIB) {
     if (a.expect_sum[i] != buf_adler[i]) a.status[i] = ZH_ERR_CHECKSUM;
   }
+}
+
+// Block-parallel decode: fold the per-block results into the stream's.  Every block must have
+// produced exactly the bytes its index entry promised.
+__global__ __launch_bounds__(64) void zh_segments_reduce_kernel(ZhInflateArgs seg, ZhInflateArgs stream) {
+  __shared__ uint64_t s_total[64];
+  __shared__ uint32_t s_bad[64];
+  const unsigned lane = zh_lane();
+  uint64_t total = 0;
+  uint32_t bad = 0xffffffffu;
+  for (uint32_t i = lane; i < seg.nbufs; i += 64) {
+    const uint64_t len = seg.out_len[i];
+    total += len;
+    if ((seg.status[i] != ZH_OK || len != seg.bufs[i].dst_cap) && i < bad) bad = i;
+  }
+  s_total[lane] = total;
+  s_bad[lane] = bad;
+  zh_wave_sync();
+  if (lane == 0 && stream.status[0] == ZH_OK) {
+    for (uint32_t l = 1; l < 64; l++) {
+      total += s_total[l];
+      if (s_bad[l] < bad) bad = s_bad[l];
+    }
+    stream.out_len[0] = total;
+    if (bad != 0xffffffffu) {
+      const int32_t st = seg.status[bad];
+      stream.status[0] = (st == ZH_OK || st == ZH_ERR_DST_TOO_SMALL) ? (int32_t)ZH_ERR_INVALID_BUFFER : st;
+    }
+  }
+}
+
+extern "C" void zh_launch_segments_reduce(hipStream_t stream, ZhInflateArgs seg, ZhInflateArgs whole) {
+  hipLaunchKernelGGL(zh_segments_reduce_kernel, dim3(1), dim3(64), 0, stream, seg, whole);
 }
 
 extern "C" void zh_launch_unwrap(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a) {
