@@ -58,7 +58,19 @@ enum {
   ZH_ERR_NOMEM = 19,             /* host or device allocation failed */
   ZH_ERR_DEVICE = 20,            /* no usable GPU / HIP runtime error (zh_last_error) */
   ZH_ERR_DST_TOO_SMALL = 21,     /* device API: output slot capacity exceeded */
-  ZH_ERR_ARGUMENT = 22           /* NULL pointer, bad plan, ... */
+  ZH_ERR_ARGUMENT = 22,          /* NULL pointer, bad plan, ... */
+  /* archive layer (zh_zip_*): the ZippyError raise sites of ziparchives.nim */
+  ZH_ERR_ARCHIVE_EOF = 23,        /* internal.nim:197-198 failArchiveEOF */
+  ZH_ERR_ZIP_FILE_HEADER = 24,    /* ziparchives.nim:58-59 */
+  ZH_ERR_ZIP_METHOD = 25,         /* ziparchives.nim:87-88,296-297 */
+  ZH_ERR_ZIP_NO_RECORD = 26,      /* ziparchives.nim:43-52,89-90 */
+  ZH_ERR_ZIP_CRC = 27,            /* ziparchives.nim:91-92 */
+  ZH_ERR_ZIP_UNSUPPORTED = 28,    /* ziparchives.nim:214-218,248-255 disk / record numbers */
+  ZH_ERR_ZIP_CENTRAL_HEADER = 29, /* ziparchives.nim:224-225,279-280 */
+  ZH_ERR_ZIP_DISK_NUMBER = 30,    /* ziparchives.nim:299-300 */
+  ZH_ERR_ZIP_DUPLICATE = 31,      /* ziparchives.nim:314-315 */
+  ZH_ERR_ZIP_CENTRAL_SIZE = 32,   /* ziparchives.nim:343-344 */
+  ZH_ERR_ZIP_NAME = 33            /* ziparchives.nim:506-511 empty / absolute / over-long path */
 };
 
 /* Engine context: one GPU, one HIP stream, reusable scratch. Thread-compatible
@@ -113,6 +125,21 @@ int zh_uncompress(zh_ctx *ctx, const void *src, size_t len, int data_format, voi
 int zh_crc32(zh_ctx *ctx, const void *src, size_t len, uint32_t *out);
 int zh_adler32(zh_ctx *ctx, const void *src, size_t len, uint32_t *out);
 
+/* n checksums in one launch pair: crc32* applied to every buffer (crc.nim:53-72). */
+int zh_crc32_batch(zh_ctx *ctx, const void *const *srcs, const size_t *lens, size_t n, uint32_t *out);
+
+/* zh_compress_batch that also returns crc32(srcs[i]) -- what createZipArchive needs per entry
+ * (ziparchives.nim:526-530: crc32(contents); compress(contents, BestSpeed, dfDeflate)). */
+int zh_compress_batch_crc32(zh_ctx *ctx, const void *const *srcs, const size_t *lens, size_t n,
+                            int level, int data_format, void **dsts, size_t *dst_lens,
+                            int32_t *statuses, uint32_t *crcs);
+/* zh_uncompress_batch for callers that know the output sizes up front (ZIP central directory,
+ * ziparchives.nim:85-93; gzip.nim:72-76 trustSize): size_hints[i] replaces the sizing pass of
+ * zlib/raw streams (a wrong hint only costs a retry), crcs[i] (optional) = crc32 of output i. */
+int zh_uncompress_batch_sized(zh_ctx *ctx, const void *const *srcs, const size_t *lens, size_t n,
+                              int data_format, const uint64_t *size_hints, void **dsts,
+                              size_t *dst_lens, int32_t *statuses, uint32_t *crcs);
+
 void zh_free(void *p);
 
 /* ------------------------------------------------------------------ *
@@ -143,6 +170,11 @@ const int32_t *zh_plan_device_statuses(zh_plan *plan);
  * offsets/capacities), e.g. after a compress plan produced them on device. */
 int zh_plan_set_src_lens_device(zh_plan *plan, const uint64_t *d_lens);
 void zh_plan_destroy(zh_plan *plan);
+
+/* CRC-32 of the uncompressed side of every buffer (sources of a compress plan, outputs of an
+ * uncompress plan) whatever the container: request before zh_plan_run, read after it. */
+int zh_plan_request_crc32(zh_plan *plan, int on);
+int zh_plan_crc32(zh_plan *plan, uint32_t *crcs);
 
 /* Per-kernel timing of the LAST zh_plan_run when profiling is on (HIP events on
  * the context's stream around every launch).  names[i] are static strings. */
@@ -192,6 +224,43 @@ int zh_plan_block_index(zh_plan *plan, size_t buf, zh_block_entry **index, size_
 int zh_plan_uncompress_indexed(zh_ctx *ctx, uint64_t src_off, uint64_t src_len, uint64_t dst_off,
                                uint64_t dst_cap, int data_format, const zh_block_entry *index,
                                size_t n_entries, zh_plan **out);
+
+/* ------------------------------------------------------------------ *
+ * ZIP archives as batch clients of the codec. *
+ * Record parsing / assembly of src/zippy/ziparchives.nim on the host, *
+ * every entry's deflate stream and CRC-32 in ONE GPU batch.  The file *
+ * system side of extractAll (ziparchives.nim:374-453) stays with the  *
+ * caller.                                                             *
+ * ------------------------------------------------------------------ */
+typedef struct zh_zip_reader zh_zip_reader;
+typedef struct zh_zip_entry {
+  const char *path;           /* UTF-8, not NUL-terminated; CP437 names converted (ziparchives.nim:108-160) */
+  size_t path_len;
+  int is_directory;           /* ziparchives.nim:352-359 */
+  uint64_t header_offset;     /* of the local file header in the image */
+  uint64_t compressed_size, uncompressed_size;
+  uint32_t crc32;
+  uint32_t unix_mode;         /* external attributes >> 16 (parseFilePermissions' input) */
+} zh_zip_entry;
+
+/* openZipArchive(zipPath) -- ziparchives.nim:183-372 -- on a memory image, which stays borrowed
+ * until zh_zip_close.  Entries keep central-directory order. */
+int zh_zip_open(const void *archive, size_t len, zh_zip_reader **out);
+void zh_zip_close(zh_zip_reader *reader);
+size_t zh_zip_num_entries(const zh_zip_reader *reader);
+int zh_zip_entry_at(const zh_zip_reader *reader, size_t i, zh_zip_entry *out);
+int zh_zip_find(const zh_zip_reader *reader, const char *path, size_t path_len, size_t *index);
+/* extractFile(reader, path) -- ziparchives.nim:39-93 -- for n records at once; statuses[k] is
+ * the outcome of record indices[k], dsts[k] library-allocated (zh_free). */
+int zh_zip_extract_batch(zh_ctx *ctx, const zh_zip_reader *reader, const size_t *indices, size_t n,
+                         void **dsts, size_t *dst_lens, int32_t *statuses);
+/* createZipArchive(entries: OrderedTable[string, string]) -- ziparchives.nim:455-634.  Entries in
+ * insertion order (the archive lists them last to first, as the reference does); dos_time /
+ * dos_date = msdos(getTime()) (ziparchives.nim:475-493), taken from the caller so that the
+ * call is a pure function. */
+int zh_zip_create(zh_ctx *ctx, const char *const *paths, const size_t *path_lens,
+                  const void *const *contents, const size_t *content_lens, size_t n,
+                  uint16_t dos_time, uint16_t dos_date, void **archive, size_t *archive_len);
 
 /* ------------------------------------------------------------------ *
  * Introspection for parity tests (not part of the drop-in surface).   *

@@ -3,6 +3,7 @@ zippy_amd/libzippy_hip.so) and tests/test_emu_parity.py (the same kernel sources
 under the CPU emulator).  `eng` is a zippy_amd._binding.Engine; the oracle
 (oracle/) is the checker.  Mirrors the reference's own tests."""
 import hashlib
+import os
 import random
 import zlib
 
@@ -201,3 +202,91 @@ def check_blocks_bad_index(eng, src):
     damaged[len(damaged) // 2] ^= 0x10
     with pytest.raises(ZippyError):
         eng.uncompress_indexed(bytes(damaged), idx, oracle.dfGzip)
+
+
+# ---- ZIP archives (reference tests: tests/test_ziparchives_read.nim,
+# tests/test_ziparchives_write.nim) ----
+ZIP_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ziparchives")
+
+
+def zip_fixture(name):
+    with open(os.path.join(ZIP_DIR, name), "rb") as fh:
+        return fh.read()
+
+
+def check_zip_extract(eng, image):
+    """Every record of the archive, extracted in one batch, equals the oracle's extractFile."""
+    from oracle import zip_oracle
+    want = zip_oracle.open_archive(image)
+    reader = eng.open_zip(image)
+    assert [e["path"].encode("utf-8", "surrogateescape") for e in reader.entries] == list(want.records)
+    for e in reader.entries:
+        w = want.records[e["path"].encode("utf-8", "surrogateescape")]
+        for key in ("is_directory", "header_offset", "crc32", "compressed_size", "uncompressed_size", "unix_mode"):
+            assert e[key] == w[key], (e["path"], key)
+    files = [i for i, e in enumerate(reader.entries) if not e["is_directory"]]
+    outs, sts = reader.extract_batch(files)
+    assert all(s == 0 for s in sts)
+    for i, out in zip(files, outs):
+        assert out == zip_oracle.extract_file(want, reader.entries[i]["path"]), reader.entries[i]["path"]
+    dirs = [i for i, e in enumerate(reader.entries) if e["is_directory"]]
+    if dirs:
+        _, sts = reader.extract_batch(dirs[:3])
+        assert all(s == 26 for s in sts)  # "No file record found", ziparchives.nim:89-90
+    assert reader.walk_files() == [p.decode("utf-8", "surrogateescape") for p, r in want.records.items()
+                                   if not r["is_directory"]]
+    reader.close()
+    return len(files)
+
+
+def check_zip_create(eng, entries, dos_time=0x6000, dos_date=0x5a21):
+    """createZipArchive: same bytes as the oracle, readable by Python's zipfile, and back."""
+    import io
+    import zipfile
+    from oracle import zip_oracle
+    got = eng.create_zip(entries, dos_time, dos_date)
+    assert got == zip_oracle.create_archive(entries, dos_time, dos_date)
+    zf = zipfile.ZipFile(io.BytesIO(got))
+    assert zf.testzip() is None
+    pairs = list(entries.items()) if hasattr(entries, "items") else list(entries)
+    assert zf.namelist() == [p for p, _ in reversed(pairs)]
+    for path, contents in pairs:
+        assert zf.read(path) == bytes(contents)
+    reader = eng.open_zip(got)
+    outs, sts = reader.extract_batch(list(range(len(pairs))))
+    assert all(s == 0 for s in sts)
+    assert outs == [bytes(c) for _, c in reversed(pairs)]
+    reader.close()
+    return got
+
+
+def check_zip_errors(eng):
+    import pytest
+    from zippy_amd.common import ZippyError
+    from oracle import zip_oracle
+    either = (ZippyError, oracle.ZippyError)
+    good = eng.create_zip([("a.txt", b"hello " * 50), ("dir/b.bin", bytes(range(256)) * 8), ("empty", b"")])
+    # damaged payload -> that record fails its CRC (or decode), neighbours survive
+    bad = bytearray(good)
+    reader = eng.open_zip(good)
+    target = reader.entries[1]  # "dir/b.bin"... entries are listed last to first
+    reader.close()
+    bad[target["header_offset"] + 30 + len(target["path"]) + 20 + 5] ^= 0x40
+    reader = eng.open_zip(bytes(bad))
+    outs, sts = reader.extract_batch([0, 1, 2])
+    assert sts[1] != 0 and sts[0] == 0 and sts[2] == 0
+    with pytest.raises(either):
+        zip_oracle.extract_file(zip_oracle.open_archive(bytes(bad)), target["path"])
+    reader.close()
+    for blob in (b"", b"PK\x05\x06", good[:-30], good[:len(good) // 2]):
+        with pytest.raises(ZippyError):
+            eng.open_zip(blob)
+        with pytest.raises(either):
+            zip_oracle.open_archive(blob)
+    for entries in ([("", b"x")], [("/abs", b"x")], [("n" * 70000, b"x")]):
+        with pytest.raises(ZippyError):
+            eng.create_zip(entries)
+        with pytest.raises(either):
+            zip_oracle.create_archive(entries)
+    with pytest.raises(ZippyError):
+        eng.open_zip(good).extract_file("nope.txt")

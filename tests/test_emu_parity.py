@@ -57,6 +57,17 @@ def test_emu_block_parallel_form(eng):
     pc.check_blocks_bad_index(eng, src)
 
 
+def test_emu_zip_archives(eng):
+    # tests/test_ziparchives_read.nim / _write.nim through the batch clients
+    assert pc.check_zip_extract(eng, pc.zip_fixture("cat.jpg")) == 3
+    image = pc.zip_fixture("Bagnon-10.2.31.zip")
+    assert pc.check_zip_extract(eng, image) > 100
+    pc.check_zip_create(eng, [("README.txt", b"Hello, World!")])
+    pc.check_zip_create(eng, {"a/b.txt": synth.corpus_file("alice29.txt")[:40000], "empty": b"",
+                              "caf\u00e9.bin": bytes(range(256)) * 40})
+    pc.check_zip_errors(eng)
+
+
 def test_emu_roundtrip_and_random_fname(eng):
     bufs = [b.tobytes() for b in synth.gen_batch("mix", 4, 65536)]
     pc.check_roundtrip(eng, bufs, 1)

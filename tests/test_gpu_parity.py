@@ -144,6 +144,24 @@ def test_gpu_block_parallel_levels_and_bad_index(eng, golds):
     pc.check_blocks_bad_index(eng, src)
 
 
+def test_gpu_zip_archives(eng, golds):
+    """the reference's archive fixtures through the batch clients, and
+    createZipArchive of a few hundred entries in one compress batch."""
+    assert pc.check_zip_extract(eng, pc.zip_fixture("cat.jpg")) == 3
+    assert pc.check_zip_extract(eng, pc.zip_fixture("Bagnon-10.2.31.zip")) > 100
+    pc.check_zip_create(eng, [("README.txt", b"Hello, World!")])
+    entries = {}
+    rng = random.Random(7)
+    names = sorted(golds)
+    for i in range(300):
+        src = golds[names[i % len(names)]]
+        lo = rng.randrange(0, max(1, len(src) - 1))
+        entries["d%d/f%03d.bin" % (i % 7, i)] = src[lo:lo + rng.randrange(0, 200000)]
+    entries["whole/kppkn.gtb"] = golds["kppkn.gtb"]
+    pc.check_zip_create(eng, entries)
+    pc.check_zip_errors(eng)
+
+
 def test_gpu_property_roundtrip_kinds(eng):
     for kind in ("runs", "rand", "zero", "mix"):
         bufs = [b.tobytes() for b in synth.gen_batch(kind, 32, 200000 + 7)]

@@ -64,6 +64,30 @@ _SIGS = {
     "zh_plan_uncompress_indexed": (_c.c_int, [_c.c_void_p, _c.c_uint64, _c.c_uint64, _c.c_uint64,
                                               _c.c_uint64, _c.c_int, _c.POINTER(_c.c_uint64),
                                               _c.c_size_t, _c.POINTER(_c.c_void_p)]),
+    "zh_crc32_batch": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t), _c.c_size_t,
+                                  _c.POINTER(_c.c_uint32)]),
+    "zh_compress_batch_crc32": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
+                                           _c.c_size_t, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p),
+                                           _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_int32),
+                                           _c.POINTER(_c.c_uint32)]),
+    "zh_uncompress_batch_sized": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
+                                             _c.c_size_t, _c.c_int, _c.POINTER(_c.c_uint64),
+                                             _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
+                                             _c.POINTER(_c.c_int32), _c.POINTER(_c.c_uint32)]),
+    "zh_plan_request_crc32": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "zh_plan_crc32": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint32)]),
+    "zh_zip_open": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_void_p)]),
+    "zh_zip_close": (None, [_c.c_void_p]),
+    "zh_zip_num_entries": (_c.c_size_t, [_c.c_void_p]),
+    "zh_zip_entry_at": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "zh_zip_find": (_c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_size_t, _c.POINTER(_c.c_size_t)]),
+    "zh_zip_extract_batch": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_size_t), _c.c_size_t,
+                                        _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
+                                        _c.POINTER(_c.c_int32)]),
+    "zh_zip_create": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_char_p), _c.POINTER(_c.c_size_t),
+                                 _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t), _c.c_size_t,
+                                 _c.c_uint16, _c.c_uint16, _c.POINTER(_c.c_void_p),
+                                 _c.POINTER(_c.c_size_t)]),
     "zh_debug_tokens": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int,
                                    _c.POINTER(_c.POINTER(_c.c_uint16)), _c.POINTER(_c.c_size_t)]),
 }
@@ -132,6 +156,76 @@ class Plan:
     def close(self):
         if self._h:
             self.engine.lib.zh_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ZipEntry(_c.Structure):
+    _fields_ = [("path", _c.c_void_p), ("path_len", _c.c_size_t), ("is_directory", _c.c_int),
+                ("header_offset", _c.c_uint64), ("compressed_size", _c.c_uint64),
+                ("uncompressed_size", _c.c_uint64), ("crc32", _c.c_uint32), ("unix_mode", _c.c_uint32)]
+
+
+class ZipReader:
+    """zh_zip_reader over a bytes image: the ZipArchiveReader of ziparchives.nim:27-29."""
+
+    def __init__(self, engine, image):
+        self.engine = engine
+        self._image = bytes(image)  # borrowed by the library until close
+        h = _c.c_void_p()
+        engine._check(engine.lib.zh_zip_open(self._image, len(self._image), _c.byref(h)))
+        self._h = h
+        self.entries = []
+        for i in range(engine.lib.zh_zip_num_entries(h)):
+            e = ZipEntry()
+            engine._check(engine.lib.zh_zip_entry_at(h, i, _c.byref(e)))
+            self.entries.append({
+                "path": _c.string_at(e.path, e.path_len).decode("utf-8", "surrogateescape"),
+                "is_directory": bool(e.is_directory), "header_offset": e.header_offset,
+                "compressed_size": e.compressed_size, "uncompressed_size": e.uncompressed_size,
+                "crc32": e.crc32, "unix_mode": e.unix_mode})
+
+    def walk_files(self):
+        return [e["path"] for e in self.entries if not e["is_directory"]]
+
+    def find(self, path):
+        raw = path.encode("utf-8", "surrogateescape")
+        idx = _c.c_size_t()
+        self.engine._check(self.engine.lib.zh_zip_find(self._h, raw, len(raw), _c.byref(idx)))
+        return idx.value
+
+    def extract_batch(self, indices):
+        """-> (list of bytes | None, statuses) for the records at `indices`, one GPU batch."""
+        n = len(indices)
+        idx = (_c.c_size_t * n)(*indices)
+        dsts = (_c.c_void_p * n)()
+        lens = (_c.c_size_t * n)()
+        sts = (_c.c_int32 * n)()
+        rc = self.engine.lib.zh_zip_extract_batch(self.engine._h, self._h, idx, n, dsts, lens, sts)
+        outs = []
+        try:
+            for i in range(n):
+                outs.append(_c.string_at(dsts[i], lens[i]) if dsts[i] and sts[i] == 0 else None)
+        finally:
+            for i in range(n):
+                if dsts[i]:
+                    self.engine.lib.zh_free(dsts[i])
+        self.engine._check(rc)
+        return outs, list(sts)
+
+    def extract_file(self, path):
+        outs, sts = self.extract_batch([self.find(path)])
+        self.engine._check(sts[0])
+        return outs[0]
+
+    def close(self):
+        if self._h:
+            self.engine.lib.zh_zip_close(self._h)
             self._h = None
 
     def __del__(self):
@@ -213,6 +307,37 @@ class Engine:
     def uncompress(self, src, data_format=dfDetect):
         outs, sts = self.uncompress_batch([src], data_format)
         return self._raise_first(outs, sts)[0]
+
+    # ---- ZIP archives (ziparchives.nim) ----
+    def open_zip(self, image):
+        return ZipReader(self, image)
+
+    def create_zip(self, entries, dos_time=0, dos_date=0):
+        """entries: ordered (path, contents) pairs -> archive bytes (createZipArchive)."""
+        entries = list(entries.items()) if hasattr(entries, "items") else list(entries)
+        n = len(entries)
+        names = [p.encode("utf-8", "surrogateescape") if isinstance(p, str) else bytes(p) for p, _ in entries]
+        blobs = [bytes(c) for _, c in entries]
+        c_names = (_c.c_char_p * n)(*names)
+        c_nlens = (_c.c_size_t * n)(*[len(x) for x in names])
+        c_blobs = (_c.c_void_p * n)(*[_c.cast(_c.c_char_p(b), _c.c_void_p) for b in blobs])
+        c_blens = (_c.c_size_t * n)(*[len(b) for b in blobs])
+        dst, dlen = _c.c_void_p(), _c.c_size_t()
+        self._check(self.lib.zh_zip_create(self._h, c_names, c_nlens, c_blobs, c_blens, n, dos_time, dos_date,
+                                           _c.byref(dst), _c.byref(dlen)))
+        try:
+            return _c.string_at(dst, dlen.value)
+        finally:
+            self.lib.zh_free(dst)
+
+    def crc32_batch(self, bufs):
+        n = len(bufs)
+        keep = [bytes(b) for b in bufs]
+        srcs = (_c.c_void_p * n)(*[_c.cast(_c.c_char_p(k), _c.c_void_p) for k in keep])
+        lens = (_c.c_size_t * n)(*[len(k) for k in keep])
+        out = (_c.c_uint32 * n)()
+        self._check(self.lib.zh_crc32_batch(self._h, srcs, lens, n, out))
+        return list(out)
 
     # ---- block-parallel form of one large buffer (BASELINE config 5) ----
     def compress_blocks(self, src, level=DefaultCompression, data_format=dfGzip, block_bytes=32768):

@@ -57,6 +57,17 @@ def uncompress_indexed(src, index, dataFormat=dfDetect):
     return engine().uncompress_indexed(src, index, dataFormat)
 
 
+def openZipArchive(image):
+    """ziparchives.nim:183 openZipArchive on the bytes of an archive -> reader with walk_files(),
+    extract_file(path), extract_batch(indices)."""
+    return engine().open_zip(image)
+
+
+def createZipArchive(entries, dos_time=0, dos_date=0):
+    """ziparchives.nim:625-634 createZipArchive(OrderedTable): entries = ordered mapping / pairs."""
+    return engine().create_zip(entries, dos_time, dos_date)
+
+
 def crc32(src):
     return engine().crc32(src)
 

@@ -92,6 +92,17 @@ extern "C" const char* zh_strerror(int status) {
     case ZH_ERR_DEVICE: return "GPU/HIP error";
     case ZH_ERR_DST_TOO_SMALL: return "Output slot too small";
     case ZH_ERR_ARGUMENT: return "Invalid argument";
+    case ZH_ERR_ARCHIVE_EOF: return "Unexpected EOF, invalid archive?";
+    case ZH_ERR_ZIP_FILE_HEADER: return "Invalid file header";
+    case ZH_ERR_ZIP_METHOD: return "Unsupported archive, compression method";
+    case ZH_ERR_ZIP_NO_RECORD: return "No file record found";
+    case ZH_ERR_ZIP_CRC: return "Verifying crc32 failed";
+    case ZH_ERR_ZIP_UNSUPPORTED: return "Unsupported archive, disk or record number";
+    case ZH_ERR_ZIP_CENTRAL_HEADER: return "Invalid central directory file header";
+    case ZH_ERR_ZIP_DISK_NUMBER: return "Invalid file disk number";
+    case ZH_ERR_ZIP_DUPLICATE: return "Unsupported archive, duplicate entry";
+    case ZH_ERR_ZIP_CENTRAL_SIZE: return "Invalid central directory size";
+    case ZH_ERR_ZIP_NAME: return "Invalid file name (empty, absolute or longer than uint16.high)";
     default: return "Unknown status";
   }
 }
@@ -195,6 +206,7 @@ struct zh_plan {
   std::vector<ZhBufDesc> h_bufs;
   std::vector<ZhBlockDesc> h_blocks;
   // block-parallel decode (zh_plan_uncompress_indexed): `ia` describes the one stream, `seg` its blocks
+  bool force_crc = false;  // CRC-32 of the uncompressed side whatever the container (ZIP entries)
   bool indexed = false;
   ZhInflateArgs seg{};
   uint8_t* seg_arena = nullptr;
@@ -607,7 +619,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
   if (!p->n) return ZH_OK;
   if (p->is_compress) {
     const ZhCompressArgs& a = p->ca;
-    const int want_crc = p->fmt == ZH_DF_GZIP, want_adler = p->fmt == ZH_DF_ZLIB;
+    const int want_crc = p->fmt == ZH_DF_GZIP || p->force_crc, want_adler = p->fmt == ZH_DF_ZLIB;
     // every shared output word is OR-ed into place, so the slots start out zeroed
     prof_mark(p, "memset_dst");
     ZH_HIP(ctx, hipMemsetAsync(d_dst + p->dst_lo, 0, p->dst_hi - p->dst_lo, s));
@@ -657,7 +669,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     }
     if (!a.count_only) {
       // both checksums: with dfDetect the format is only known per stream on the device
-      const int want_crc = p->fmt == ZH_DF_GZIP || p->fmt == ZH_DF_DETECT;
+      const int want_crc = p->fmt == ZH_DF_GZIP || p->fmt == ZH_DF_DETECT || p->force_crc;
       const int want_adler = p->fmt == ZH_DF_ZLIB || p->fmt == ZH_DF_DETECT;
       if (want_crc || want_adler) {
         prof_mark(p, "zh_checksum_pieces_kernel");
@@ -681,6 +693,18 @@ extern "C" int zh_plan_results(zh_plan* p, uint64_t* out_lens, int32_t* statuses
   zh_ctx* ctx = p->ctx;
   if (out_lens) ZH_HIP(ctx, hipMemcpyAsync(out_lens, p->out_len, p->n * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (statuses) ZH_HIP(ctx, hipMemcpyAsync(statuses, p->status, p->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZH_OK;
+}
+extern "C" int zh_plan_request_crc32(zh_plan* p, int on) {
+  if (!p) return ZH_ERR_ARGUMENT;
+  p->force_crc = on != 0;
+  return ZH_OK;
+}
+extern "C" int zh_plan_crc32(zh_plan* p, uint32_t* crcs) {
+  if (!p || !crcs || !p->buf_crc) return ZH_ERR_ARGUMENT;
+  zh_ctx* ctx = p->ctx;
+  ZH_HIP(ctx, hipMemcpyAsync(crcs, p->buf_crc, p->n * 4, hipMemcpyDeviceToHost, ctx->stream));
   ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZH_OK;
 }
@@ -721,9 +745,9 @@ int upload(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n, D
 }
 }  // namespace
 
-extern "C" int zh_compress_batch(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
-                                 int level, int data_format, void** dsts, size_t* dst_lens,
-                                 int32_t* statuses) {
+static int compress_batch_impl(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
+                               int level, int data_format, void** dsts, size_t* dst_lens,
+                               int32_t* statuses, uint32_t* crcs) {
   if (!ctx || (n && (!srcs || !lens || !dsts || !dst_lens || !statuses))) return ZH_ERR_ARGUMENT;
   for (size_t i = 0; i < n; i++) {
     dsts[i] = nullptr;
@@ -759,12 +783,14 @@ extern "C" int zh_compress_batch(zh_ctx* ctx, const void* const* srcs, const siz
     st = zh_plan_compress(ctx, n, soff.data(), slen.data(), doff.data(), dcap.data(), level,
                           data_format, &pg.p);
     if (st) return st;
+    if (crcs) zh_plan_request_crc32(pg.p, 1);
     st = zh_plan_run(pg.p, d_src.p, d_dst.p);
     if (st) return st;
     std::vector<uint64_t> olen(n);
     std::vector<int32_t> ost(n);
     st = zh_plan_results(pg.p, olen.data(), ost.data());
     if (st) return st;
+    if (crcs && (st = zh_plan_crc32(pg.p, crcs))) return st;
     bool retry = false;
     for (size_t i = 0; i < n; i++)
       if (ost[i] == ZH_ERR_DST_TOO_SMALL) retry = true;
@@ -786,6 +812,18 @@ extern "C" int zh_compress_batch(zh_ctx* ctx, const void* const* srcs, const siz
   return ZH_OK;
 }
 
+extern "C" int zh_compress_batch(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
+                                 int level, int data_format, void** dsts, size_t* dst_lens,
+                                 int32_t* statuses) {
+  return compress_batch_impl(ctx, srcs, lens, n, level, data_format, dsts, dst_lens, statuses, nullptr);
+}
+extern "C" int zh_compress_batch_crc32(zh_ctx* ctx, const void* const* srcs, const size_t* lens,
+                                       size_t n, int level, int data_format, void** dsts,
+                                       size_t* dst_lens, int32_t* statuses, uint32_t* crcs) {
+  if (!crcs && n) return ZH_ERR_ARGUMENT;
+  return compress_batch_impl(ctx, srcs, lens, n, level, data_format, dsts, dst_lens, statuses, crcs);
+}
+
 // Which container will the device see?  (zippy.nim:108-125, sizing only)
 static int host_detect(const uint8_t* s, size_t len, int fmt) {
   if (fmt != ZH_DF_DETECT) return fmt;
@@ -795,9 +833,12 @@ static int host_detect(const uint8_t* s, size_t len, int fmt) {
   return ZH_DF_DETECT;
 }
 
-extern "C" int zh_uncompress_batch(zh_ctx* ctx, const void* const* srcs, const size_t* lens,
-                                   size_t n, int data_format, void** dsts, size_t* dst_lens,
-                                   int32_t* statuses) {
+// size_hints: expected output sizes (ZIP central directory, gzip.nim:72-76 trustSize): they
+// replace the sizing pass of streams that carry no size; a stream that outgrows its hint falls
+// back to the deflate expansion bound.  crcs: CRC-32 of every output (whatever the container).
+static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
+                                 int data_format, const uint64_t* size_hints, void** dsts,
+                                 size_t* dst_lens, int32_t* statuses, uint32_t* crcs) {
   if (!ctx || (n && (!srcs || !lens || !dsts || !dst_lens || !statuses))) return ZH_ERR_ARGUMENT;
   for (size_t i = 0; i < n; i++) {
     dsts[i] = nullptr;
@@ -829,8 +870,12 @@ extern "C" int zh_uncompress_batch(zh_ctx* ctx, const void* const* srcs, const s
       const uint64_t max_out = (uint64_t)lens[i] * 1032 + 64;  // deflate cannot expand further
       cap[i] = std::min(isize, max_out);
     } else if (f == ZH_DF_ZLIB || f == ZH_DF_DEFLATE) {
-      need_count[i] = 1;
-      any_count = true;
+      if (size_hints) {
+        cap[i] = std::min<uint64_t>(size_hints[i], (uint64_t)lens[i] * 1032 + 64);
+      } else {
+        need_count[i] = 1;
+        any_count = true;
+      }
     }
   }
   std::vector<uint64_t> zero_off(n, 0);
@@ -850,12 +895,15 @@ extern "C" int zh_uncompress_batch(zh_ctx* ctx, const void* const* srcs, const s
     st = zh_plan_uncompress(ctx, n, soff.data(), slen.data(), doff.data(), dcap.data(), data_format, &pg.p);
     if (st) return st;
     plan_set_count_only(pg.p, pass == 0);
+    if (crcs && pass != 0) zh_plan_request_crc32(pg.p, 1);
     st = zh_plan_run(pg.p, d_src.p, d_dst.p);
     if (st) return st;
     std::vector<uint64_t> olen(n);
     std::vector<int32_t> ost(n);
+    std::vector<uint32_t> ocrc(crcs ? n : 0);
     st = zh_plan_results(pg.p, olen.data(), ost.data());
     if (st) return st;
+    if (crcs && pass != 0 && (st = zh_plan_crc32(pg.p, ocrc.data()))) return st;
     if (pass == 0) {
       for (size_t i = 0; i < n; i++)
         if (need_count[i]) cap[i] = olen[i];
@@ -879,6 +927,7 @@ extern "C" int zh_uncompress_batch(zh_ctx* ctx, const void* const* srcs, const s
         continue;
       }
       dst_lens[i] = olen[i];
+      if (crcs) crcs[i] = ocrc[i];
       if (olen[i]) ZH_HIP(ctx, hipMemcpyAsync(dsts[i], d_dst.p + doff[i], olen[i], hipMemcpyDeviceToHost, ctx->stream));
     }
     ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -889,6 +938,18 @@ extern "C" int zh_uncompress_batch(zh_ctx* ctx, const void* const* srcs, const s
   for (size_t i = 0; i < n; i++)
     if (statuses[i] == ZH_ERR_DST_TOO_SMALL) statuses[i] = ZH_ERR_CHECKSUM;
   return ZH_OK;
+}
+
+extern "C" int zh_uncompress_batch(zh_ctx* ctx, const void* const* srcs, const size_t* lens,
+                                   size_t n, int data_format, void** dsts, size_t* dst_lens,
+                                   int32_t* statuses) {
+  return uncompress_batch_impl(ctx, srcs, lens, n, data_format, nullptr, dsts, dst_lens, statuses, nullptr);
+}
+extern "C" int zh_uncompress_batch_sized(zh_ctx* ctx, const void* const* srcs, const size_t* lens,
+                                         size_t n, int data_format, const uint64_t* size_hints,
+                                         void** dsts, size_t* dst_lens, int32_t* statuses,
+                                         uint32_t* crcs) {
+  return uncompress_batch_impl(ctx, srcs, lens, n, data_format, size_hints, dsts, dst_lens, statuses, crcs);
 }
 
 extern "C" int zh_compress(zh_ctx* ctx, const void* src, size_t len, int level, int data_format,
@@ -999,49 +1060,66 @@ extern "C" int zh_uncompress_indexed(zh_ctx* ctx, const void* src, size_t len, i
   return ZH_OK;
 }
 
-static int checksum_host(zh_ctx* ctx, const void* src, size_t len, int want_crc, uint32_t* out) {
-  if (!ctx || !out || (len && !src)) return ZH_ERR_ARGUMENT;
+// CRC-32 / Adler-32 of n host buffers in one launch pair (pieces of <= 32 KiB, then a fold per buffer).
+static int checksum_host(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
+                         int want_crc, uint32_t* out) {
+  if (!ctx || (n && (!srcs || !lens || !out))) return ZH_ERR_ARGUMENT;
+  for (size_t i = 0; i < n; i++)
+    if (lens[i] && !srcs[i]) return ZH_ERR_ARGUMENT;
+  if (!n) return ZH_OK;
   ZH_HIP(ctx, hipSetDevice(ctx->device));
-  const void* srcs[1] = {src};
-  size_t lens[1] = {len};
   DevBuf d;
   std::vector<uint64_t> off, l64;
-  int st = upload(ctx, srcs, lens, 1, d, off, l64);
+  int st = upload(ctx, srcs, lens, n, d, off, l64);
   if (st) return st;
   std::vector<ZhPieceDesc> pieces;
-  for (uint64_t o = 0; o < len; o += ZH_FRAG_SIZE)
-    pieces.push_back(ZhPieceDesc{o, (uint32_t)std::min<uint64_t>(len - o, ZH_FRAG_SIZE), 0, o});
-  ZhBufDesc b;
-  memset(&b, 0, sizeof(b));
-  b.src_len = len;
-  b.npieces = (uint32_t)pieces.size();
+  std::vector<ZhBufDesc> bufs(n);
+  for (size_t i = 0; i < n; i++) {
+    ZhBufDesc& b = bufs[i];
+    memset(&b, 0, sizeof(b));
+    b.src_off = off[i];
+    b.src_len = lens[i];
+    b.first_piece = (uint32_t)pieces.size();
+    for (uint64_t o = 0; o < lens[i]; o += ZH_FRAG_SIZE)
+      pieces.push_back(ZhPieceDesc{off[i] + o, (uint32_t)std::min<uint64_t>(lens[i] - o, ZH_FRAG_SIZE), (uint32_t)i, o});
+    b.npieces = (uint32_t)pieces.size() - b.first_piece;
+  }
   const size_t np = pieces.size();
+  if (np >= 0xffffffffull) return ZH_ERR_ARGUMENT;
+  Arena ar;
+  const size_t o_b = ar.reserve(n * sizeof(ZhBufDesc)), o_p = ar.reserve(np * sizeof(ZhPieceDesc)),
+               o_pc = ar.reserve(np * 4), o_pl = ar.reserve(np * 4), o_pa = ar.reserve(np * 4),
+               o_oc = ar.reserve(n * 4), o_oa = ar.reserve(n * 4);
+  ar.reserve(256);
   DevBuf scratch;
-  const size_t bytes = sizeof(ZhBufDesc) + 256 + np * sizeof(ZhPieceDesc) + 256 + np * 12 + 256 + 64;
-  if (hipMalloc(&scratch.p, bytes) != hipSuccess) return ZH_ERR_NOMEM;
-  ZhBufDesc* d_b = (ZhBufDesc*)scratch.p;
-  ZhPieceDesc* d_p = (ZhPieceDesc*)(scratch.p + 256);
-  uint32_t* d_pc = (uint32_t*)(scratch.p + 512 + ((np * sizeof(ZhPieceDesc) + 255) & ~(size_t)255));
-  uint32_t* d_pl = d_pc + np;
-  uint32_t* d_pa = d_pl + np;
-  uint32_t* d_out = d_pa + np;
+  if (hipMalloc(&scratch.p, ar.size) != hipSuccess) return ZH_ERR_NOMEM;
+  uint8_t* base = scratch.p;
   hipStream_t s = ctx->stream;
-  ZH_HIP(ctx, hipMemcpyAsync(d_b, &b, sizeof(b), hipMemcpyHostToDevice, s));
-  if (np) ZH_HIP(ctx, hipMemcpyAsync(d_p, pieces.data(), np * sizeof(ZhPieceDesc), hipMemcpyHostToDevice, s));
-  zh_launch_checksum_pieces(s, ctx->cktabs, d.p, d_p, (uint32_t)np, nullptr, want_crc, !want_crc,
-                            d_pc, d_pa, d_pl);
-  zh_launch_checksum_combine(s, d_b, 1, d_pc, d_pa, d_pl, want_crc, !want_crc, d_out, d_out + 1);
-  uint32_t res[2] = {0, 0};
-  ZH_HIP(ctx, hipMemcpyAsync(res, d_out, 8, hipMemcpyDeviceToHost, s));
+  ZH_HIP(ctx, hipMemcpyAsync(base + o_b, bufs.data(), n * sizeof(ZhBufDesc), hipMemcpyHostToDevice, s));
+  if (np) ZH_HIP(ctx, hipMemcpyAsync(base + o_p, pieces.data(), np * sizeof(ZhPieceDesc), hipMemcpyHostToDevice, s));
+  zh_launch_checksum_pieces(s, ctx->cktabs, d.p, carve<ZhPieceDesc>(base, o_p), (uint32_t)np, nullptr, want_crc,
+                            !want_crc, carve<uint32_t>(base, o_pc), carve<uint32_t>(base, o_pa),
+                            carve<uint32_t>(base, o_pl));
+  zh_launch_checksum_combine(s, carve<ZhBufDesc>(base, o_b), (uint32_t)n, carve<uint32_t>(base, o_pc),
+                             carve<uint32_t>(base, o_pa), carve<uint32_t>(base, o_pl), want_crc, !want_crc,
+                             carve<uint32_t>(base, o_oc), carve<uint32_t>(base, o_oa));
+  ZH_HIP(ctx, hipMemcpyAsync(out, base + (want_crc ? o_oc : o_oa), n * 4, hipMemcpyDeviceToHost, s));
   ZH_HIP(ctx, hipStreamSynchronize(s));
-  *out = want_crc ? res[0] : res[1];
   return ZH_OK;
 }
+extern "C" int zh_crc32_batch(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
+                              uint32_t* out) {
+  return checksum_host(ctx, srcs, lens, n, 1, out);
+}
 extern "C" int zh_crc32(zh_ctx* ctx, const void* src, size_t len, uint32_t* out) {
-  return checksum_host(ctx, src, len, 1, out);
+  const void* srcs[1] = {src};
+  size_t lens[1] = {len};
+  return checksum_host(ctx, srcs, lens, 1, 1, out);
 }
 extern "C" int zh_adler32(zh_ctx* ctx, const void* src, size_t len, uint32_t* out) {
-  return checksum_host(ctx, src, len, 0, out);
+  const void* srcs[1] = {src};
+  size_t lens[1] = {len};
+  return checksum_host(ctx, srcs, lens, 1, 0, out);
 }
 
 // ---------------------------------------------------------------------------
