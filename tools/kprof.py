@@ -15,8 +15,8 @@ sys.path.insert(0, ROOT)
 
 L1 = ["stage-in", "step: vector part", "step: fast walk", "step: slow walk", "step: table inserts",
       "stats phase", "#steps", "#fast steps", "#events fast", "#events slow", "#match extensions",
-      "#waves", "#slow: run continues", "#slow: 32 lanes no event", "#slow: shared slot",
-      "#slow: end of step"]
+      "#waves", "#slow: all lanes miss", "#slow: (unused)", "#slow: shared-slot lane",
+      "#slow: plain hit"]
 INF_O = ["waiting for a round", "working", "#rounds", "#waves"]
 INF_D = ["waiting for the output wave", "working", "#rounds", "#waves"]
 

@@ -27,16 +27,23 @@ namespace {
 __constant__ zh::LenTables c_len = zh::make_len_tables();
 __constant__ zh::DistTables c_dist = zh::make_dist_tables();
 constexpr uint32_t kHashMul = 0x1e35a7bdu;  // snappy.nim:70-71
+// byte-wide per-step slot counters, four to a dword, keyed by the low hash bits (also the size
+// of the coverage bitmap that reuses the array: 1024 words = 32768 bits)
+constexpr uint32_t kCntWords = 1024;
+
 }  // namespace
 
 __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restrict__ d_src,
                                                          ZhCompressArgs a, int huffman_only,
                                                          uint16_t* __restrict__ table_pool) {
   __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
-  // parse: 8192 byte-wide counters (4 per dword) of the probes per table slot in one step,
+  // parse: 4096 byte-wide counters (4 per dword) of the probes per table slot in one step,
   // all zero between steps; afterwards the first 4 KiB are the coverage bitmap (bit p set:
   // byte p lies inside a match)
-  __shared__ uint32_t s_scr[2048];
+  __shared__ uint32_t s_scr[kCntWords];
+  // one bit per table slot: written while parsing this fragment.  A slot that was not holds the
+  // reference's initial zero, which needs no load -- and the pooled table needs no clearing.
+  __shared__ uint32_t s_bits[512];
   __shared__ uint32_t s_nmatch;
   uint32_t* const s_cover = s_scr;
 
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
     return __builtin_amdgcn_alignbyte(dw(i + 1), dw(i), q);
   };
   for (uint32_t i = lane; i < ZH_HIST_STRIDE; i += 64) s_hist[i] = 0;
-  for (uint32_t i = lane; i < 2048; i += 64) s_scr[i] = 0;
+  for (uint32_t i = lane; i < kCntWords; i += 64) s_scr[i] = 0;
 
   uint32_t table_size = 256, shift = 24;  // snappy.nim:24-29
   while (table_size < 16384u && table_size < n) {
@@ -74,13 +81,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   // A table entry is position | tag << 15: the tag is one more bit of the hash product of the
   // position's four bytes, so a probe whose tag differs cannot match and need not fetch the
   // candidate's bytes (half of the non-matching gathers, which are what this kernel's memory
-  // traffic is made of).  "Empty" is the reference's zero = position 0, with position 0's tag.
-  if (!huffman_only) {
-    const uint32_t e0 = n >= 4 ? (((ld32(0) * kHashMul) >> 17) & 1u) << 15 : 0u;
-    const uint32_t fill = e0 | (e0 << 16);
-    for (uint32_t i = lane; i < table_size / 8; i += 64)
-      reinterpret_cast<uint4*>(s_table)[i] = make_uint4(fill, fill, fill, fill);
-  }
+  // traffic is made of).  "Empty" is the reference's zero = position 0, with position 0's tag (e0).
+  const uint32_t e0 = (!huffman_only && n >= 4) ? (((ld32(0) * kHashMul) >> 17) & 1u) << 15 : 0u;
+  for (uint32_t i = lane; i < 512; i += 64) s_bits[i] = 0;
   zh_wave_sync();
   KPROF_MARK(0);
 
@@ -141,10 +144,12 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         const uint32_t h = hp >> shift, tag = (hp >> 17) & 1u;
         // round trip 2: the table slot; every lane also ticks a counter of its (folded) hash,
         // read back together with the candidate bytes
-        const uint32_t oldw = __hip_atomic_load(s_table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t oldw = e0;
+        if (valid && ((s_bits[h >> 5] >> (h & 31u)) & 1u))
+          oldw = __hip_atomic_load(s_table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t old = oldw & 0x7fffu;
         const bool fetch = valid && (oldw >> 15) == tag;  // equal bytes have equal tags
-        const uint32_t ck = (h & 8191u) >> 2, cs = (h & 3u) * 8u;
+        const uint32_t ck = (h & (kCntWords * 4u - 1u)) >> 2, cs = (h & 3u) * 8u;
         if (valid) atomicAdd(&s_scr[ck], 1u << cs);
         zh_wave_sync();  // (orders the counter traffic between lanes; emits nothing)
         const uint32_t a1 = __builtin_amdgcn_alignbyte(p2, p1, pq);
@@ -179,8 +184,21 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         const uint64_t V = __ballot(valid);  // a prefix of the lanes (pos + step is monotone)
         const uint64_t H = __ballot(valid && x0 == 0);
         // lanes that may share their table slot with another lane of this step (a superset:
-        // the counters see 13 of the 14 hash bits); the general walk below sorts them out exactly
+        // the counters see 12 of the 14 hash bits); the general walk below sorts them out exactly
         const uint64_t C = __ballot(cnt > 1u);
+        // Cw: the flagged lanes that really have an earlier lane with their hash in this step --
+        // only those can have a candidate other than `old` (the first lane of a group, and lanes
+        // flagged by the folded counter alone, walk like any other lane)
+        uint64_t Cw = C;
+        if (C && __popcll(C) <= 16) {
+          Cw = 0;
+          for (uint64_t cm = C; cm; cm &= cm - 1) {
+            const uint32_t g = (uint32_t)__ffsll((long long)cm) - 1u;
+            const uint32_t hg = __builtin_amdgcn_readlane(h, g);
+            const bool same_h = valid && h == hg;
+            if (__ballot(same_h) & ((1ull << g) - 1ull)) Cw |= 1ull << g;
+          }
+        }
         const uint32_t t = V == ~0ull ? 64u : (uint32_t)__ffsll((long long)~V) - 1u;  // first probe past ip_limit
 
         KPROF_MARK(1);
@@ -203,9 +221,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         // in the next step (only from lanes >= 32, so that it cannot reach its 32nd probe here).
         uint32_t hop = 0x8000u;
         if (dense) {
-          const uint64_t ev = (H | C) >> lane;
+          const uint64_t ev = (H | Cw) >> lane;
           const uint32_t d = ev ? (uint32_t)__ffsll((long long)ev) - 1u : 64u;
-          const uint32_t info = eqlen | ((uint32_t)((C >> lane) & 1ull) << 5);
+          const uint32_t info = eqlen | ((uint32_t)((Cw >> lane) & 1ull) << 5);
           const uint32_t gi = (uint32_t)__shfl((int)info, (int)((lane + d) & 63u), 64);
           if (d < 32u && gi < 16u) hop = (lane + d) | 0x40u | ((lane + d + gi) << 8);
           else if (!ev && lane >= 32u) hop = 63u | (64u << 8);
@@ -318,9 +336,10 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
             const uint32_t last_dense = dense ? i + (31u - K) : 63u;  // lane of probe #31 of the run
             uint32_t lim = last_dense < 63u ? last_dense : 63u;
             if (t - 1u < lim) lim = t - 1u;
-            const uint64_t E = (H | C) & (~0ull << i);
+            const uint64_t E = (H | Cw) & (~0ull << i);
             g = E ? (uint32_t)__ffsll((long long)E) - 1u : 64u;
             if (g > lim) {  // lanes i..lim all miss
+              KPROF_COUNT(12, 1);
               ins |= (~0ull << i) & (~0ull >> (63u - lim));
               if (dense && lim == last_dense) {  // probe #32 on: the sparse schedule takes over
                 K = 32;
@@ -344,16 +363,30 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
           }
           // ---- probe lane g: its candidate is the last same-hash insert before it ----
           uint32_t cand, flen;
-          bool hit, cand_in_step = false;
-          if ((C >> g) & 1ull) {
+          bool hit;
+          if ((Cw >> g) & 1ull) {
+            KPROF_COUNT(14, 1);
             const uint32_t hg = __builtin_amdgcn_readlane(h, g);
             const uint64_t same = __ballot(h == hg) & ins;  // ins holds only lanes probed before g
             if (same) {
               const uint32_t k = 63u - (uint32_t)__clzll((long long)same);
               cand = __builtin_amdgcn_readlane(pos, k);
               hit = __builtin_amdgcn_readlane(a0, k) == __builtin_amdgcn_readlane(a0, g);
-              flen = 4;  // only the first four bytes are known to match
-              cand_in_step = true;
+              flen = 4;
+              if (hit) {  // both lanes hold their 16 bytes: the common prefix without a memory trip
+                const uint32_t y1 = (uint32_t)__builtin_amdgcn_readlane(a1, k) ^ (uint32_t)__builtin_amdgcn_readlane(a1, g);
+                if (y1) {
+                  flen = 4u + (((uint32_t)__ffs((int)y1) - 1u) >> 3);
+                } else {
+                  const uint32_t y2 = (uint32_t)__builtin_amdgcn_readlane(a2, k) ^ (uint32_t)__builtin_amdgcn_readlane(a2, g);
+                  if (y2) {
+                    flen = 8u + (((uint32_t)__ffs((int)y2) - 1u) >> 3);
+                  } else {
+                    const uint32_t y3 = (uint32_t)__builtin_amdgcn_readlane(a3, k) ^ (uint32_t)__builtin_amdgcn_readlane(a3, g);
+                    flen = y3 ? 12u + (((uint32_t)__ffs((int)y3) - 1u) >> 3) : 16u;
+                  }
+                }
+              }
             } else {
               cand = __builtin_amdgcn_readlane(old, g);
               hit = (H >> g) & 1ull;
@@ -390,7 +423,8 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
           const uint32_t mp = __builtin_amdgcn_readlane(pos, g);
           const uint32_t limit = n < mp + 258u ? n : mp + 258u;
           uint32_t matched;
-          if (flen < 16u && !cand_in_step) {
+          if (flen < 16u) {
+            KPROF_COUNT(15, 1);
             matched = flen;
           } else {
             // 4 + determineMatchLength(cand + 4, mp + 4, limit), internal.nim:251-270:
@@ -431,6 +465,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         if (finished) break;  // nothing reads the table any more
         // ---- table inserts of the probes that really happened, in probe order ----
         const bool mine = (ins >> lane) & 1ull;
+        if (mine) atomicOr(&s_bits[h >> 5], 1u << (h & 31u));
         if (mine && !((C >> lane) & 1ull)) s_table[h] = (uint16_t)(pos | (tag << 15));
         uint64_t cc = ins & C;
         while (cc) {  // probes that share a slot write one by one (the later one wins)
@@ -497,12 +532,12 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   }  // next fragment of this wave
 }
 
-// waves that share the table pool: 16 per CU on 256 CUs (ZH_L1_SLOTS: tuning override)
+// waves that share the table pool: 20 per CU on 256 CUs, LDS 7.4 KiB each (ZH_L1_SLOTS: tuning override)
 extern "C" uint32_t zh_l1_table_slots(void) {
   static const uint32_t slots = [] {
     const char* e = getenv("ZH_L1_SLOTS");
     const long v = e ? atol(e) : 0;
-    return v >= 64 && v <= 16384 ? (uint32_t)v : 4096u;
+    return v >= 64 && v <= 16384 ? (uint32_t)v : 5120u;
   }();
   return slots;
 }
