@@ -20,6 +20,7 @@
 namespace {
 __constant__ zh::LenTables c_len = zh::make_len_tables();
 __constant__ zh::DistTables c_dist = zh::make_dist_tables();
+constexpr uint32_t kChunk = 8192;                      // positions per match-bitmap chunk (32 passes)
 constexpr uint32_t kStageWords = 512;                  // 2 KiB staging window
 constexpr uint32_t kFlushBits = (kStageWords - 200) * 32;  // flush threshold: a 256-position pass adds < 6400 bits
 }  // namespace
@@ -28,8 +29,10 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
                                                      uint8_t* __restrict__ d_dst, ZhCompressArgs a) {
   __shared__ uint32_t s_lit[288];
   __shared__ uint32_t s_dist[32];
-  __shared__ uint32_t s_start[ZH_FRAG_SIZE / 32];  // bit p: a match starts at p
-  __shared__ uint32_t s_cover[ZH_FRAG_SIZE / 32];  // bit p: p is inside a match (not its start)
+  // match bitmaps of the current 8 KiB chunk of the fragment (whole-fragment bitmaps would cost
+  // 8 KiB of LDS and a third of the waves per CU)
+  __shared__ uint32_t s_start[kChunk / 32];  // bit p - c0: a match starts at p
+  __shared__ uint32_t s_cover[kChunk / 32];  // bit p - c0: p is inside a match (not its start)
   __shared__ uint32_t s_stage[kStageWords + 4];
 
   const unsigned lane = zh_lane();
@@ -59,10 +62,6 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   // ---- code tables and match bitmaps into LDS ----
   for (uint32_t i = lane; i < 288; i += 64) s_lit[i] = a.b_litcode[(size_t)b * 288 + i];
   if (lane < 32) s_dist[lane] = a.b_distcode[(size_t)b * 32 + lane];
-  for (uint32_t i = lane; i < ZH_FRAG_SIZE / 32; i += 64) {
-    s_start[i] = 0;
-    s_cover[i] = 0;
-  }
   for (uint32_t i = lane; i < kStageWords + 4; i += 64) s_stage[i] = 0;
   zh_wave_sync();
 
@@ -71,27 +70,48 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   const uint16_t* m_off = a.m_off + (size_t)f * ZH_MAX_MATCHES_PER_FRAG;
   const uint32_t nmatch = a.f_nmatch[f];
   const uint32_t spill = a.f_spill[f];  // bytes covered by a match begun in the previous fragment
-  for (uint32_t m = lane; m < nmatch + 1; m += 64) {
-    uint32_t p, e;  // cover [p, e)
-    if (m < nmatch) {
-      const uint32_t s = m_pos[m];
-      atomicOr(&s_start[s >> 5], 1u << (s & 31u));
-      p = s + 1;
-      e = s + m_len[m];
-      if (e > n) e = n;  // chain levels: a match may run into the next fragment
-    } else {
-      p = 0;
-      e = spill;
+  uint32_t mnext = 0;                   // first match that starts at or behind the current chunk
+  // cover [p, e) clipped to the chunk [c0, c1), as bits relative to c0
+  auto cover = [&](uint32_t p, uint32_t e, uint32_t c0, uint32_t c1) {
+    if (p < c0) p = c0;
+    if (e > c1) e = c1;
+    if (p >= e) return;
+    p -= c0;
+    e -= c0;
+    for (uint32_t w = p >> 5; w <= (e - 1) >> 5; w++) {
+      const uint32_t lo = w == (p >> 5) ? (p & 31u) : 0u;
+      const uint32_t hi = w == ((e - 1) >> 5) ? ((e - 1) & 31u) : 31u;
+      atomicOr(&s_cover[w], (0xffffffffu >> (31u - hi)) & (0xffffffffu << lo));
     }
-    if (p < e) {
-      for (uint32_t w = p >> 5; w <= (e - 1) >> 5; w++) {
-        const uint32_t lo = w == (p >> 5) ? (p & 31u) : 0u;
-        const uint32_t hi = w == ((e - 1) >> 5) ? ((e - 1) & 31u) : 31u;
-        atomicOr(&s_cover[w], (0xffffffffu >> (31u - hi)) & (0xffffffffu << lo));
+  };
+  auto build_chunk = [&](uint32_t c0) {
+    const uint32_t c1 = c0 + kChunk < n ? c0 + kChunk : n;
+    zh_wave_sync();
+    for (uint32_t i = lane; i < kChunk / 32; i += 64) {
+      s_start[i] = 0;
+      s_cover[i] = 0;
+    }
+    zh_wave_sync();
+    // what reaches in from before the chunk: the previous match (matches do not overlap), or
+    // for the first chunk the match begun in the previous fragment
+    if (lane == 0) {
+      if (mnext) cover(m_pos[mnext - 1] + 1u, (uint32_t)m_pos[mnext - 1] + m_len[mnext - 1], c0, c1);
+      else cover(0, spill, c0, c1);
+    }
+    for (;;) {
+      const uint32_t m = mnext + lane;
+      const uint32_t s = m < nmatch ? m_pos[m] : 0xffffffffu;
+      const bool here = s < c1;
+      if (here) {
+        atomicOr(&s_start[(s - c0) >> 5], 1u << ((s - c0) & 31u));
+        cover(s + 1u, s + m_len[m], c0, c1);  // (chain levels: a match may run past the fragment)
       }
+      const uint32_t cnt = (uint32_t)__popcll(__ballot(here));
+      mnext += cnt;
+      if (cnt < 64u) break;
     }
-  }
-  zh_wave_sync();
+    zh_wave_sync();
+  };
 
   // ---- emission ----
   const uint64_t bit0 = a.f_bit_start[f];              // absolute bit position in d_dst
@@ -108,9 +128,10 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   auto dw = [&](uint32_t i) -> uint32_t { return asrc[i < last_dw ? i : last_dw]; };
 
   for (uint32_t base = 0; base < n; base += 256) {
+    if ((base & (kChunk - 1u)) == 0) build_chunk(base);
     const uint32_t p0 = base + 4u * lane;  // this lane's four positions p0 .. p0+3
     const bool in = p0 < n;
-    const uint32_t bw = in ? p0 >> 5 : 0u, bs = p0 & 31u;  // p0 is a multiple of 4: one bitmap word
+    const uint32_t bw = in ? (p0 & (kChunk - 1u)) >> 5 : 0u, bs = p0 & 31u;  // p0 is a multiple of 4: one bitmap word
     const uint32_t st4 = in ? (s_start[bw] >> bs) & 15u : 0u;
     uint32_t skip4 = in ? (s_cover[bw] >> bs) & 15u : 15u;
     if (in && n - p0 < 4u) skip4 |= 15u << (n - p0);  // positions past the fragment
