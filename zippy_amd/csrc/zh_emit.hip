@@ -20,7 +20,7 @@
 namespace {
 __constant__ zh::LenTables c_len = zh::make_len_tables();
 __constant__ zh::DistTables c_dist = zh::make_dist_tables();
-constexpr uint32_t kChunk = 8192;                      // positions per match-bitmap chunk (32 passes)
+constexpr uint32_t kChunk = 4096;                      // positions per match-bitmap chunk (16 passes)
 constexpr uint32_t kStageWords = 512;                  // 2 KiB staging window
 constexpr uint32_t kFlushBits = (kStageWords - 200) * 32;  // flush threshold: a 256-position pass adds < 6400 bits
 }  // namespace
@@ -29,8 +29,8 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
                                                      uint8_t* __restrict__ d_dst, ZhCompressArgs a) {
   __shared__ uint32_t s_lit[288];
   __shared__ uint32_t s_dist[32];
-  // match bitmaps of the current 8 KiB chunk of the fragment (whole-fragment bitmaps would cost
-  // 8 KiB of LDS and a third of the waves per CU)
+  // match bitmaps of the current 4 KiB chunk of the fragment (whole-fragment bitmaps would cost
+  // 8 KiB of LDS and leave 13 waves per CU instead of 32)
   __shared__ uint32_t s_start[kChunk / 32];  // bit p - c0: a match starts at p
   __shared__ uint32_t s_cover[kChunk / 32];  // bit p - c0: p is inside a match (not its start)
   __shared__ uint32_t s_stage[kStageWords + 4];
