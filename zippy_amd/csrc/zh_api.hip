@@ -32,9 +32,9 @@ void zh_launch_l1_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int
                         uint16_t* table_pool);
 uint32_t zh_l1_table_slots(void);
 void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint16_t* head_scratch,
-                          uint16_t* prevw);
+                          uint64_t* prevw);
 void zh_launch_chain_search(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
-                            int max_chain, const uint16_t* prevw, uint32_t* best);
+                            int max_chain, const uint64_t* prevw, uint32_t* best);
 void zh_launch_chain_select(hipStream_t, ZhCompressArgs a, const uint32_t* best);
 void zh_launch_frag_stats(hipStream_t, const uint8_t* d_src, ZhCompressArgs a);
 void zh_launch_huffman(hipStream_t, ZhCompressArgs a);
@@ -196,7 +196,7 @@ struct zh_plan {
   uint16_t* head_scratch = nullptr;  // chain levels: `head` per block, previous-position links and
   size_t head_bytes = 0;             // best match per position (zh_chain_match.hip)
   uint16_t* l1_tables = nullptr;  // BestSpeed: pool of per-wave hash tables (zh_l1_match.hip)
-  uint16_t* chain_prev = nullptr;
+  uint64_t* chain_prev = nullptr;
   uint32_t* chain_best = nullptr;
   uint64_t dst_lo = 0, dst_hi = 0;  // byte range of d_dst covered by the slots
   uint64_t* out_len = nullptr;
@@ -359,7 +359,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   p->head_bytes = chain ? nb * ((size_t)2 << 17) : 0;
   const size_t o_head = ar.reserve(p->head_bytes);
   const size_t o_l1tab = ar.reserve(level == 1 ? (size_t)zh_l1_table_slots() * 32768 : 0);
-  const size_t o_cprev = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 2 : 0);
+  const size_t o_cprev = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 8 : 0);
   const size_t o_cbest = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 4 : 0);
   ar.reserve(256);
 
@@ -419,7 +419,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   a.status = p->status = carve<int32_t>(base, o_st);
   p->head_scratch = carve<uint16_t>(base, o_head);
   p->l1_tables = carve<uint16_t>(base, o_l1tab);
-  p->chain_prev = carve<uint16_t>(base, o_cprev);
+  p->chain_prev = carve<uint64_t>(base, o_cprev);
   p->chain_best = carve<uint32_t>(base, o_cbest);
   p->h_bufs.swap(bufs);
   p->h_blocks.swap(blocks);

@@ -47,7 +47,7 @@ __device__ inline uint32_t load32u(const uint8_t* p) {
 __global__ __launch_bounds__(64) void zh_chain_prev_kernel(const uint8_t* __restrict__ d_src,
                                                            ZhCompressArgs a,
                                                            uint16_t* __restrict__ head_scratch,
-                                                           uint16_t* __restrict__ prevw) {
+                                                           uint64_t* __restrict__ prevw) {
   __shared__ uint32_t s_cnt[1024];  // byte-wide counters of the group's hashes (12 bits)
   const unsigned lane = zh_lane();
   const uint32_t b = blockIdx.x;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void zh_chain_prev_kernel(const uint8_t* __rest
   const uint8_t* src = d_src + bd.src_off;
   const uint32_t block_len = (uint32_t)bd.len;
   uint16_t* head = head_scratch + ((size_t)b << kHashBits);  // zeroed by the host before launch
-  uint16_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
   const uint32_t nins = block_len > 4u ? block_len - 4u : 0u;  // positions with pos + 4 < block end
   for (uint32_t i = lane; i < 1024; i += 64) s_cnt[i] = 0;
   zh_wave_sync();
@@ -85,7 +85,14 @@ __global__ __launch_bounds__(64) void zh_chain_prev_kernel(const uint8_t* __rest
       cc &= ~same;
     }
     if (valid) {
-      pw[P] = (uint16_t)old;
+      // the link and the position's first six bytes in one word: the search reads both with one gather
+      uint64_t six = 0;
+      if (P + 8u <= block_len) {
+        six = load64u(src + P) & 0xffffffffffffull;
+      } else {
+        for (uint32_t k = 0; k < 6u && P + k < block_len; k++) six |= (uint64_t)src[P + k] << (8u * k);
+      }
+      pw[P] = (uint64_t)(old & 0xffffu) | (six << 16);
       if (last) __hip_atomic_store(head + h, (uint16_t)(P & 32767u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     zh_wave_sync();
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(64) void zh_chain_prev_kernel(const uint8_t* __rest
 __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __restrict__ d_src,
                                                               ZhCompressArgs a, int good, int nice,
                                                               int max_chain,
-                                                              const uint16_t* __restrict__ prevw,
+                                                              const uint64_t* __restrict__ prevw,
                                                               uint32_t* __restrict__ best) {
   const uint32_t f = blockIdx.x / (ZH_FRAG_SIZE / 256u);
   const uint32_t local = (blockIdx.x % (ZH_FRAG_SIZE / 256u)) * 256u + threadIdx.x;
@@ -106,12 +113,16 @@ __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __r
   const uint8_t* src = d_src + bd.src_off;
   const uint32_t block_len = (uint32_t)bd.len;
   const uint32_t pos = (f - bd.first_frag) * ZH_FRAG_SIZE + local;  // block-relative
-  const uint16_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  const uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
   uint32_t result = 0;
   if (pos + 4u < block_len) {
     const uint32_t window_pos = pos & 32767u;
     const uint32_t limit = block_len < pos + 258u ? block_len : pos + 258u;
-    uint32_t hash_pos = pw[pos];
+    uint32_t hash_pos = (uint32_t)pw[pos] & 0xffffu;
+    // the position's own first bytes: every candidate is compared against them, first through the
+    // six bytes that travel with the candidate's chain link (one gather decides most candidates)
+    const bool wide = pos + 8u <= limit;
+    const uint64_t own6 = wide ? load64u(src + pos) & 0xffffffffffffull : 0ull;
     int tries = max_chain;
     int prev_offset = 0, longest_offset = 0, longest_len = 0;
     while (tries > 0 && hash_pos != 0) {
@@ -121,11 +132,19 @@ __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __r
       if (offset <= 0 || offset < prev_offset) break;
       prev_offset = offset;
       // determineMatchLength(src, pos - offset, pos, limit), internal.nim:251-270
+      const uint64_t entry = pw[pos - (uint32_t)offset];  // chain[hashPos] | the candidate's six bytes << 16
       const uint8_t* s1 = src + (pos - (uint32_t)offset);
       uint32_t s2 = pos;
       int match_len = 0;
       bool done = false;
-      while (s2 + 8u <= limit) {
+      if (wide) {
+        const uint64_t x6 = (entry >> 16) ^ own6;
+        if (x6 != 0) {
+          match_len = (int)((uint32_t)__builtin_ctzll(x6) >> 3);
+          done = true;
+        }
+      }
+      while (!done && s2 + 8u <= limit) {
         const uint64_t x = load64u(src + s2) ^ load64u(s1 + match_len);
         if (x != 0) {
           match_len += (int)((uint32_t)__builtin_ctzll(x) >> 3);
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __r
         longest_offset = offset;
       }
       // chain[hashPos]: the value stored when the position in that window slot was inserted
-      const uint32_t nxt = pw[pos - (uint32_t)offset];
+      const uint32_t nxt = (uint32_t)entry & 0xffffu;
       if (longest_len >= nice || hash_pos == nxt) break;
       hash_pos = nxt;
     }
@@ -270,13 +289,13 @@ __global__ __launch_bounds__(64) void zh_frag_stats_kernel(const uint8_t* __rest
 }
 
 extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
-                                     uint16_t* head_scratch, uint16_t* prevw) {
+                                     uint16_t* head_scratch, uint64_t* prevw) {
   if (!a.nblocks) return;
   hipLaunchKernelGGL(zh_chain_prev_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a, head_scratch,
                      prevw);
 }
 extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
-                                       int good, int nice, int max_chain, const uint16_t* prevw,
+                                       int good, int nice, int max_chain, const uint64_t* prevw,
                                        uint32_t* best) {
   if (!a.nfrags) return;
   hipLaunchKernelGGL(zh_chain_search_kernel, dim3(a.nfrags * (ZH_FRAG_SIZE / 256u)), dim3(256), 0, stream,
