@@ -325,6 +325,10 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
       __syncthreads();  // round k is in s_desc[k & 1]
       KPROF_MARK(0);
       KPROF_COUNT(2, 1);
+      // wave-uniform by construction; saying so keeps them in scalar registers and the control
+      // flow below on scalar branches
+      op = zh_bcast64(op);
+      st = (int)zh_bcast((uint32_t)st);
       const RoundDesc& d = s_desc[k & 1u];
       const uint32_t use_b = d.use_b, tail = d.tail, tail_a = d.tail_a, tail_b = d.tail_b;
       const uint64_t tail_off = d.tail_off;
@@ -340,15 +344,13 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
       const bool in_chainB = (recB >> 10) & 1u, is_litB = (recB >> 9) & 1u;
       const uint32_t valA = recA >> 16, valB = recB >> 16;
       const uint32_t lenA = in_chain ? recA & 0x1ffu : 0u, lenB = in_chainB ? recB & 0x1ffu : 0u;
-      const uint32_t inclA = zh_wave_scan(lenA);
-      const uint32_t opre = inclA - lenA;
-      const uint32_t totalA = (uint32_t)__builtin_amdgcn_readlane(inclA, 63);
-      uint32_t opreB = 0, totalB = 0;
-      if (use_b) {
-        const uint32_t inclB = zh_wave_scan(lenB);
-        opreB = totalA + inclB - lenB;
-        totalB = (uint32_t)__builtin_amdgcn_readlane(inclB, 63);
-      }
+      // one scan for both windows: A's lengths in the low half, B's in the high half (a window's
+      // sum is at most 64 * 258)
+      const uint32_t incl = zh_wave_scan(lenA | (lenB << 16));
+      const uint32_t sums = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+      const uint32_t totalA = sums & 0xffffu, totalB = sums >> 16;
+      const uint32_t opre = (incl & 0xffffu) - lenA;
+      const uint32_t opreB = totalA + (incl >> 16) - lenB;
       const uint32_t total = totalA + totalB;
       if (total - 1u < 64u) {
         const bool is_match = in_chain && !is_lit, is_matchB = in_chainB && !is_litB;
