@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Host-buffer API (what the Nim shim binds) end to end: buffers start and end in host memory, so
+the rate includes allocation, H2D, kernels, D2H and the per-output malloc/copy.  DESIGN.md section 5
+quotes it next to the device-resident headline.
+
+    python tools/bench_host_api.py [--buffers 1024] [--size 1048576] [--reps 3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--buffers", type=int, default=1024)
+    ap.add_argument("--size", type=int, default=1 << 20)
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    import torch  # noqa: F401  (initialises the HIP runtime the library shares)
+    from zippy_amd import api, synth
+    bufs = [b.tobytes() for b in synth.gen_batch("mix", args.buffers, args.size)]
+    total = args.buffers * args.size / 2.0**30
+    api.engine().set_gzip_fname_len(0)
+    outs, sts = api.compress_batch(bufs[:8], 1, api.dfGzip)  # warm-up (context, code objects)
+    tc = tu = 1e9
+    for _ in range(args.reps):
+        t = time.perf_counter()
+        outs, sts = api.compress_batch(bufs, 1, api.dfGzip)
+        tc = min(tc, time.perf_counter() - t)
+        assert all(s == 0 for s in sts)
+        t = time.perf_counter()
+        back, sts = api.uncompress_batch(outs, api.dfGzip)
+        tu = min(tu, time.perf_counter() - t)
+        assert all(s == 0 for s in sts)
+    assert back == bufs
+    print(json.dumps({
+        "workload": "%d x %d B host buffers through zh_compress_batch / zh_uncompress_batch (level 1, gzip)" %
+                    (args.buffers, args.size),
+        "compress_GiBps": round(total / tc, 3), "uncompress_GiBps": round(total / tu, 3),
+        "both_GiBps": round(total / (tc + tu), 3),
+        "note": "includes the Python ctypes marshalling of the test mirror (bytes objects in and out)"}))
+
+
+if __name__ == "__main__":
+    main()
