@@ -70,7 +70,10 @@ enum {
   ZH_ERR_ZIP_DISK_NUMBER = 30,    /* ziparchives.nim:299-300 */
   ZH_ERR_ZIP_DUPLICATE = 31,      /* ziparchives.nim:314-315 */
   ZH_ERR_ZIP_CENTRAL_SIZE = 32,   /* ziparchives.nim:343-344 */
-  ZH_ERR_ZIP_NAME = 33            /* ziparchives.nim:506-511 empty / absolute / over-long path */
+  ZH_ERR_ZIP_NAME = 33,           /* ziparchives.nim:506-511 empty / absolute / over-long path */
+  ZH_ERR_TAR_HEADER_TYPE = 34,    /* tarballs.nim:119 */
+  ZH_ERR_UNSAFE_PATH = 35,        /* internal.nim:294-302 verifyPathIsSafeToExtract */
+  ZH_ERR_TAR_NUMBER = 36          /* tarballs.nim:17-23 (octal field that is not octal) */
 };
 
 /* Engine context: one GPU, one HIP stream, reusable scratch. Thread-compatible
@@ -261,6 +264,32 @@ int zh_zip_extract_batch(zh_ctx *ctx, const zh_zip_reader *reader, const size_t 
 int zh_zip_create(zh_ctx *ctx, const char *const *paths, const size_t *path_lens,
                   const void *const *contents, const size_t *content_lens, size_t n,
                   uint16_t dos_time, uint16_t dos_date, void **archive, size_t *archive_len);
+
+/* ------------------------------------------------------------------ *
+ * Tarballs: extractAll of src/zippy/tarballs.nim *
+ * without its file-system half.  A .tar.gz is ONE foreign gzip member *
+ * -- one decoder, no parallelism to offer; the GPU still does the     *
+ * inflate + CRC-32, with ISIZE as the output size (trustSize).        *
+ * ------------------------------------------------------------------ */
+typedef struct zh_tar_reader zh_tar_reader;
+typedef struct zh_tar_entry {
+  const char *path;      /* prefix / name, or the preceding 'L' block's long name */
+  size_t path_len;
+  const char *linkname;  /* symlinks (typeflag '2') */
+  size_t linkname_len;
+  char typeflag;         /* '0' or '\0' file, '5' directory, '2' symlink */
+  uint32_t mode;
+  int64_t mtime;
+  uint64_t offset, size; /* the entry's bytes inside zh_tar_data() */
+} zh_tar_entry;
+
+/* image: the bytes of a .tar.gz (decoded here; ctx required) or of a .tar (borrowed until close;
+ * ctx may be NULL).  Header walk and checks: tarballs.nim:61-124. */
+int zh_tar_open(zh_ctx *ctx, const void *image, size_t len, zh_tar_reader **out);
+void zh_tar_close(zh_tar_reader *reader);
+size_t zh_tar_num_entries(const zh_tar_reader *reader);
+int zh_tar_entry_at(const zh_tar_reader *reader, size_t i, zh_tar_entry *out);
+const void *zh_tar_data(const zh_tar_reader *reader, size_t *len);
 
 /* ------------------------------------------------------------------ *
  * Introspection for parity tests (not part of the drop-in surface).   *

@@ -290,3 +290,72 @@ def check_zip_errors(eng):
             zip_oracle.create_archive(entries)
     with pytest.raises(ZippyError):
         eng.open_zip(good).extract_file("nope.txt")
+
+
+# ---- tarballs (reference test: tests/test_tarballs_read.nim) ----
+def tar_fixture():
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tarballs",
+                           "libressl-3.4.2.tar.gz"), "rb") as fh:
+        return fh.read()
+
+
+def check_tarball(eng, image):
+    from oracle import tar_oracle
+    data, want = tar_oracle.open_tarball(image)
+    reader = eng.open_tar(image)
+    assert reader.data == data
+    assert reader.entries == want
+    reader.close()
+    return len(want)
+
+
+def make_tar_gz(files, long_name=None):
+    """A small .tar.gz with Python's tarfile (GNU format: a long name becomes an 'L' block)."""
+    import io
+    import tarfile
+    buf = io.BytesIO()
+    with tarfile.open(fileobj=buf, mode="w:gz", format=tarfile.GNU_FORMAT) as tf:
+        for name, contents in files:
+            if contents is None:
+                info = tarfile.TarInfo(name)
+                info.type = tarfile.DIRTYPE
+                info.mode = 0o755
+                tf.addfile(info)
+            else:
+                info = tarfile.TarInfo(name)
+                info.size = len(contents)
+                info.mode = 0o644
+                info.mtime = 1234567890
+                tf.addfile(info, io.BytesIO(contents))
+        if long_name:
+            info = tarfile.TarInfo(long_name)
+            info.size = 3
+            tf.addfile(info, io.BytesIO(b"abc"))
+        link = tarfile.TarInfo("link")
+        link.type = tarfile.SYMTYPE
+        link.linkname = "a.txt"
+        tf.addfile(link)
+    return buf.getvalue()
+
+
+def check_tar_errors(eng):
+    import gzip
+    import pytest
+    from zippy_amd.common import ZippyError
+    from oracle import tar_oracle
+    either = (ZippyError, oracle.ZippyError)
+    good = gzip.decompress(make_tar_gz([("a.txt", b"hello")]))
+    for bad in (good[:515],                                        # cut inside the first file
+                good[:156] + b"Z" + good[157:],                    # vendor type: skipped, not an error
+                good[:156] + b"7" + good[157:],                    # unsupported type
+                b"../evil".ljust(100, b"\0") + good[100:],         # unsafe path
+                good[:124] + b"0000000009\0" + good[135:]):        # "9" is not octal
+        expect_ok = bad[156:157] == b"Z"
+        for fn in (lambda b: eng.open_tar(b), tar_oracle.open_tarball):
+            if expect_ok:
+                fn(bad)
+            else:
+                with pytest.raises(either):
+                    fn(bad)
+    with pytest.raises(either):
+        eng.open_tar(b"\x1f\x8b" + b"\0" * 30)

@@ -68,6 +68,15 @@ def test_emu_zip_archives(eng):
     pc.check_zip_errors(eng)
 
 
+def test_emu_tarballs(eng):
+    # tests/test_tarballs_read.nim in small (the 20 MB fixture itself runs on the GPU)
+    files = [("a.txt", b"hello"), ("d", None), ("d/b.bin", synth.corpus_file("html")[:30000])]
+    assert pc.check_tarball(eng, pc.make_tar_gz(files, "d/" + "y" * 140 + ".txt")) == 5
+    import gzip
+    assert pc.check_tarball(eng, gzip.decompress(pc.make_tar_gz(files))) == 4  # a plain .tar
+    pc.check_tar_errors(eng)
+
+
 def test_emu_roundtrip_and_random_fname(eng):
     bufs = [b.tobytes() for b in synth.gen_batch("mix", 4, 65536)]
     pc.check_roundtrip(eng, bufs, 1)

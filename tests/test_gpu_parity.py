@@ -162,6 +162,14 @@ def test_gpu_zip_archives(eng, golds):
     pc.check_zip_errors(eng)
 
 
+def test_gpu_tarballs(eng):
+    """the reference's tarball fixture (one foreign 3.9 MB gzip member, 20 MB of
+    tar) decoded on the device, header walk equal to the oracle's."""
+    assert pc.check_tarball(eng, pc.tar_fixture()) > 1000
+    assert pc.check_tarball(eng, pc.make_tar_gz([("a.txt", b"hello"), ("d", None)], "d/" + "y" * 140)) == 4
+    pc.check_tar_errors(eng)
+
+
 def test_gpu_property_roundtrip_kinds(eng):
     for kind in ("runs", "rand", "zero", "mix"):
         bufs = [b.tobytes() for b in synth.gen_batch(kind, 32, 200000 + 7)]

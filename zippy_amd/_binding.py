@@ -88,6 +88,11 @@ _SIGS = {
                                  _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t), _c.c_size_t,
                                  _c.c_uint16, _c.c_uint16, _c.POINTER(_c.c_void_p),
                                  _c.POINTER(_c.c_size_t)]),
+    "zh_tar_open": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_void_p)]),
+    "zh_tar_close": (None, [_c.c_void_p]),
+    "zh_tar_num_entries": (_c.c_size_t, [_c.c_void_p]),
+    "zh_tar_entry_at": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "zh_tar_data": (_c.c_void_p, [_c.c_void_p, _c.POINTER(_c.c_size_t)]),
     "zh_debug_tokens": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int,
                                    _c.POINTER(_c.POINTER(_c.c_uint16)), _c.POINTER(_c.c_size_t)]),
 }
@@ -235,6 +240,48 @@ class ZipReader:
             pass
 
 
+class TarEntry(_c.Structure):
+    _fields_ = [("path", _c.c_void_p), ("path_len", _c.c_size_t), ("linkname", _c.c_void_p),
+                ("linkname_len", _c.c_size_t), ("typeflag", _c.c_char), ("mode", _c.c_uint32),
+                ("mtime", _c.c_int64), ("offset", _c.c_uint64), ("size", _c.c_uint64)]
+
+
+class TarReader:
+    """zh_tar_reader: the entries of a .tar.gz / .tar image (tarballs.nim:61-124)."""
+
+    def __init__(self, engine, image):
+        self.engine = engine
+        self._image = bytes(image)  # an uncompressed tarball stays borrowed until close
+        h = _c.c_void_p()
+        engine._check(engine.lib.zh_tar_open(engine._h, self._image, len(self._image), _c.byref(h)))
+        self._h = h
+        n = _c.c_size_t()
+        base = engine.lib.zh_tar_data(h, _c.byref(n))
+        self.data = _c.string_at(base, n.value) if n.value else b""
+        self.entries = []
+        for i in range(engine.lib.zh_tar_num_entries(h)):
+            e = TarEntry()
+            engine._check(engine.lib.zh_tar_entry_at(h, i, _c.byref(e)))
+            self.entries.append({
+                "path": _c.string_at(e.path, e.path_len), "linkname": _c.string_at(e.linkname, e.linkname_len),
+                "typeflag": e.typeflag, "mode": e.mode, "mtime": e.mtime, "offset": e.offset, "size": e.size})
+
+    def contents(self, i):
+        e = self.entries[i]
+        return self.data[e["offset"]:e["offset"] + e["size"]]
+
+    def close(self):
+        if self._h:
+            self.engine.lib.zh_tar_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     def __init__(self, lib_path, device=-1, stream=None):
         self.lib = load_library(lib_path)
@@ -329,6 +376,9 @@ class Engine:
             return _c.string_at(dst, dlen.value)
         finally:
             self.lib.zh_free(dst)
+
+    def open_tar(self, image):
+        return TarReader(self, image)
 
     def crc32_batch(self, bufs):
         n = len(bufs)

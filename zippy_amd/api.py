@@ -68,6 +68,11 @@ def createZipArchive(entries, dos_time=0, dos_date=0):
     return engine().create_zip(entries, dos_time, dos_date)
 
 
+def openTarball(image):
+    """tarballs.nim:26-124 on the bytes of a .tar.gz / .tar -> reader with .entries, .contents(i)."""
+    return engine().open_tar(image)
+
+
 def crc32(src):
     return engine().crc32(src)
 

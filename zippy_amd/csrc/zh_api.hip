@@ -103,6 +103,9 @@ extern "C" const char* zh_strerror(int status) {
     case ZH_ERR_ZIP_DUPLICATE: return "Unsupported archive, duplicate entry";
     case ZH_ERR_ZIP_CENTRAL_SIZE: return "Invalid central directory size";
     case ZH_ERR_ZIP_NAME: return "Invalid file name (empty, absolute or longer than uint16.high)";
+    case ZH_ERR_TAR_HEADER_TYPE: return "Unsupported header type";
+    case ZH_ERR_UNSAFE_PATH: return "Path not allowed (absolute or containing ../)";
+    case ZH_ERR_TAR_NUMBER: return "Invalid octal number in tar header";
     default: return "Unknown status";
   }
 }
