@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -729,6 +730,19 @@ struct PlanGuard {
   ~PlanGuard() { zh_plan_destroy(p); }
 };
 
+// ZH_TRACE=1: wall-clock of the host-buffer calls' phases on stderr (tuning aid; syncs the stream)
+struct Trace {
+  bool on = getenv("ZH_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void mark(zh_ctx* ctx, const char* what) {
+    if (!on) return;
+    hipStreamSynchronize(ctx->stream);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[zh] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+
 // Pack host buffers into one device allocation (256-byte aligned slices).
 int upload(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n, DevBuf& dev,
            std::vector<uint64_t>& off, std::vector<uint64_t>& len64) {
@@ -769,8 +783,10 @@ static int compress_batch_impl(zh_ctx* ctx, const void* const* srcs, const size_
   ZH_HIP(ctx, hipSetDevice(ctx->device));
   DevBuf d_src;
   std::vector<uint64_t> soff, slen;
+  Trace tr;
   int st = upload(ctx, srcs, lens, n, d_src, soff, slen);
   if (st) return st;
+  tr.mark(ctx, "compress: upload");
 
   for (int attempt = 0; attempt < 2; attempt++) {
     std::vector<uint64_t> doff(n), dcap(n);
@@ -786,6 +802,7 @@ static int compress_batch_impl(zh_ctx* ctx, const void* const* srcs, const size_
     st = zh_plan_compress(ctx, n, soff.data(), slen.data(), doff.data(), dcap.data(), level,
                           data_format, &pg.p);
     if (st) return st;
+    tr.mark(ctx, "compress: alloc + plan");
     if (crcs) zh_plan_request_crc32(pg.p, 1);
     st = zh_plan_run(pg.p, d_src.p, d_dst.p);
     if (st) return st;
@@ -793,6 +810,7 @@ static int compress_batch_impl(zh_ctx* ctx, const void* const* srcs, const size_
     std::vector<int32_t> ost(n);
     st = zh_plan_results(pg.p, olen.data(), ost.data());
     if (st) return st;
+    tr.mark(ctx, "compress: kernels");
     if (crcs && (st = zh_plan_crc32(pg.p, crcs))) return st;
     bool retry = false;
     for (size_t i = 0; i < n; i++)
@@ -810,6 +828,7 @@ static int compress_batch_impl(zh_ctx* ctx, const void* const* srcs, const size_
       ZH_HIP(ctx, hipMemcpyAsync(dsts[i], d_dst.p + doff[i], olen[i], hipMemcpyDeviceToHost, ctx->stream));
     }
     ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    tr.mark(ctx, "compress: download");
     break;
   }
   return ZH_OK;
@@ -856,8 +875,10 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
   ZH_HIP(ctx, hipSetDevice(ctx->device));
   DevBuf d_src;
   std::vector<uint64_t> soff, slen;
+  Trace tr;
   int st = upload(ctx, srcs, lens, n, d_src, soff, slen);
   if (st) return st;
+  tr.mark(ctx, "uncompress: upload");
 
   // Output sizes: gzip members carry ISIZE (gzip.nim:64-66, trusted only as a
   // capacity hint and verified afterwards); zlib / raw streams get a sizing pass.
@@ -897,6 +918,7 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
     PlanGuard pg;
     st = zh_plan_uncompress(ctx, n, soff.data(), slen.data(), doff.data(), dcap.data(), data_format, &pg.p);
     if (st) return st;
+    tr.mark(ctx, "uncompress: alloc + plan");
     plan_set_count_only(pg.p, pass == 0);
     if (crcs && pass != 0) zh_plan_request_crc32(pg.p, 1);
     st = zh_plan_run(pg.p, d_src.p, d_dst.p);
@@ -907,6 +929,7 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
     st = zh_plan_results(pg.p, olen.data(), ost.data());
     if (st) return st;
     if (crcs && pass != 0 && (st = zh_plan_crc32(pg.p, ocrc.data()))) return st;
+    tr.mark(ctx, "uncompress: kernels");
     if (pass == 0) {
       for (size_t i = 0; i < n; i++)
         if (need_count[i]) cap[i] = olen[i];
@@ -934,6 +957,7 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
       if (olen[i]) ZH_HIP(ctx, hipMemcpyAsync(dsts[i], d_dst.p + doff[i], olen[i], hipMemcpyDeviceToHost, ctx->stream));
     }
     ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    tr.mark(ctx, "uncompress: download");
     if (!again) break;
     for (size_t i = 0; i < n; i++)
       if (statuses[i] != ZH_ERR_DST_TOO_SMALL) cap[i] = 0;  // only the wrapped members run again
