@@ -30,6 +30,9 @@ __constant__ zh::DistTables c_dist = zh::make_dist_tables();
 __constant__ uint8_t c_clcl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 constexpr uint32_t kLitBits = 10, kDistBits = 8;
+// second-level tables behind the litlen root table for codes longer than kLitBits (a complete
+// 286-symbol code of maximum length 15 needs at most 308 entries with a 10-bit root)
+constexpr uint32_t kLitSub = 320;
 constexpr uint32_t kInWords = 128;   // staging ring of the compressed stream (dwords, power of two)
 
 }  // namespace
@@ -118,6 +121,9 @@ __global__ void zh_unwrap_kernel(const uint8_t* __restrict__ d_src, ZhInflateArg
 //   bits 0-3   code length in bits (0 = not in this table: take the slow path)
 //   bits 4-7   number of extra bits that follow the code
 //   bits 8-9   kind: 0 literal, 1 length (or any distance), 2 end of block, 3 invalid symbol
+//   bit  10    link: the code is longer than the root table; bits 0-3 = index bits of its
+//              second-level table, bits 16-31 = where that table starts (entries of a
+//              second-level table carry the code's full length)
 //   bit  15    set for literals (single-bit test on the hot path)
 //   bits 16-31 literal byte / base length / base distance
 // ---------------------------------------------------------------------------
@@ -151,7 +157,7 @@ __device__ __forceinline__ uint32_t cl_entry(uint32_t sym, uint32_t len) { retur
 // 2 code-length alphabet).  Returns ZH_OK or ZH_ERR_INVALID_BUFFER (over-subscribed;
 // incomplete codes are accepted like the reference).
 __device__ int build_table(const uint8_t* lens, uint32_t n, uint32_t* lut, uint32_t lut_bits,
-                           int kind, HuffTab* tab, uint16_t* values, uint32_t* s_cnt) {
+                           int kind, HuffTab* tab, uint16_t* values, uint32_t* s_cnt, uint32_t sub_cap = 0) {
   const unsigned lane = zh_lane();
   zh_wave_sync();
   if (lane < 16) s_cnt[lane] = 0;
@@ -209,6 +215,45 @@ __device__ int build_table(const uint8_t* lens, uint32_t n, uint32_t* lut, uint3
     }
   }
   zh_wave_sync();
+  // Codes longer than the root table: one second-level table per root prefix, like zlib's
+  // inflate_table.  Canonical codes are sorted, so the codes below one prefix are consecutive in
+  // `values` order; once per block and a few hundred steps at most, so one lane does it.  Patterns
+  // no code claims stay 0 (= "decode alone on the canonical path", which also finds the errors).
+  if (sub_cap && lane == 0) {
+    const uint32_t R = lut_bits;
+    auto len_of = [&](uint32_t t, uint32_t l) -> uint32_t {  // code length of canonical index t (l: a lower bound)
+      while (l < 15u && t >= (uint32_t)tab->first_symbol[l] + s_cnt[l]) l++;
+      return l;
+    };
+    auto code_of = [&](uint32_t t, uint32_t l) -> uint32_t { return (uint32_t)tab->first_code[l] + (t - tab->first_symbol[l]); };
+    uint32_t next = 1u << R;
+    uint32_t t = tab->first_symbol[R + 1u], tl = R + 1u;
+    while (t < k) {
+      tl = len_of(t, tl);
+      const uint32_t p = code_of(t, tl) >> (tl - R);
+      uint32_t j = t, jl = tl;  // last code below prefix p (lengths do not decrease)
+      while (j + 1u < k) {
+        const uint32_t l2 = len_of(j + 1u, jl);
+        if ((code_of(j + 1u, l2) >> (l2 - R)) != p) break;
+        j++;
+        jl = l2;
+      }
+      const uint32_t sb = jl - R, size = 1u << sb;
+      if (next + size > (1u << R) + sub_cap) break;  // no room: the rest keeps taking the slow path
+      for (uint32_t q = 0; q < size; q++) lut[next + q] = 0;
+      uint32_t ul = tl;
+      for (uint32_t u = t; u <= j; u++) {
+        ul = len_of(u, ul);
+        const uint32_t low = code_of(u, ul) & ((1u << (ul - R)) - 1u);
+        const uint32_t entry = kind == 0 ? litlen_entry(values[u], ul) : dist_entry(values[u], ul);
+        for (uint32_t q = __brev(low) >> (32u - (ul - R)); q < size; q += 1u << (ul - R)) lut[next + q] = entry;
+      }
+      lut[__brev(p) >> (32u - R)] = sb | 0x400u | (next << 16);
+      next += size;
+      t = j + 1u;
+    }
+  }
+  zh_wave_sync();
   return ZH_OK;
 }
 
@@ -253,7 +298,7 @@ struct RoundDesc {
 __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __restrict__ d_src,
                                                          uint8_t* __restrict__ d_dst,
                                                          ZhInflateArgs a) {
-  __shared__ uint32_t s_lit[1u << kLitBits];
+  __shared__ uint32_t s_lit[(1u << kLitBits) + kLitSub];
   __shared__ uint32_t s_dst[1u << kDistBits];  // also hosts the 7-bit code-length table
   __shared__ uint32_t s_in[kInWords];          // staging ring of the compressed stream
   __shared__ uint8_t s_map[64];                // output byte -> token lane of the current round
@@ -650,7 +695,7 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
     }
     {
       const uint32_t dist_at = btype == 1 ? 288u : hlit;
-      st = build_table(s_lens, hlit, s_lit, kLitBits, 0, &s_tab_lit, s_val_lit, s_cnt);
+      st = build_table(s_lens, hlit, s_lit, kLitBits, 0, &s_tab_lit, s_val_lit, s_cnt, kLitSub);
       if (st != ZH_OK) break;
       st = build_table(s_lens + dist_at, hdist, s_dst, kDistBits, 1, &s_tab_dist, s_val_dist, s_cnt);
       if (st != ZH_OK) break;
@@ -674,7 +719,8 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
         t.v_lo = v_lo;
         t.v_hi = v_hi;
         const uint64_t v = (uint64_t)v_lo | ((uint64_t)v_hi << 32);
-        const uint32_t e = s_lit[v_lo & ((1u << kLitBits) - 1u)];
+        uint32_t e = s_lit[v_lo & ((1u << kLitBits) - 1u)];
+        if (e & 0x400u) e = s_lit[(e >> 16) + ((v_lo >> kLitBits) & ((1u << (e & 15u)) - 1u))];  // a longer code
         const uint32_t L = e & 15u, eb = (e >> 4) & 15u;
         t.e = e;
         t.is_lit = (e & 0x8000u) != 0;
