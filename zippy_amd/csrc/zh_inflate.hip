@@ -327,7 +327,7 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
 
   if (!decoder) {
     // =========================== OUTPUT wave ===========================
-    KPROF_DECL(4);  // output wave: 0 waiting for a round, 1 working; 2 rounds; 3 waves
+    KPROF_DECL(8);  // output wave: 0 waiting for a round, 1 working; 2 rounds; 3 waves; 4 long rounds; 5 far rounds; 6 doubling turns; 7 tail matches
     uint64_t op = 0;  // bytes produced
     int st = ZH_OK;
     // match sources are read back past this CU's L1 (which may hold a stale copy of a line the
@@ -435,11 +435,13 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
             }
           }
           if (__ballot(far)) {
+            KPROF_COUNT(5, 1);
             own_output_visible();
             if (far) val = ld_out(op - back);
           }
           if (__ballot(par != lane)) {
             for (;;) {
+              KPROF_COUNT(6, 1);
               const uint32_t pp = (uint32_t)__shfl((int)par, (int)par, 64);
               const bool changed = pp != par;
               par = pp;
@@ -452,6 +454,7 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
         op += total;
       } else if (total) {
         // long rounds: per window, literal runs by their lanes and copies in order
+        KPROF_COUNT(4, 1);
         const uint64_t op0 = op;
         auto long_window = [&](bool chain_w, bool lit_w, uint32_t rec_w, uint32_t opre_w) {
           const uint64_t litmask = __ballot(chain_w && lit_w);
@@ -496,6 +499,7 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
           }
           op += 1;
         } else if (tail == kTailMatch) {
+          KPROF_COUNT(7, 1);
           lz_copy(tail_a, tail_b);
         } else if (tail == kTailStored) {  // inflate.nim:252-266: tail_a raw bytes
           if (!count_only) {
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
       a.status[sid] = st;
     }
     KPROF_COUNT(3, 1);
-    KPROF_FLUSH(16, 4);
+    KPROF_FLUSH(16, 8);
     return;
   }
 
