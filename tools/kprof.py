@@ -18,7 +18,8 @@ L1 = ["stage-in", "step: vector part", "step: fast walk", "step: slow walk", "st
       "#waves", "#slow: all lanes miss", "#slow: (unused)", "#slow: shared-slot lane",
       "#slow: plain hit"]
 INF_O = ["waiting for a round", "working", "#rounds", "#waves", "#long rounds", "#far rounds", "#doubling turns", "#tail matches"]
-INF_D = ["waiting for the output wave", "working", "#rounds", "#waves"]
+INF_D = ["waiting for the output wave", "other work", "#rounds", "#waves", "vector decode", "chain walks", "staging",
+         "#(unused)"]
 
 
 def show(title, names, vals):
@@ -72,7 +73,7 @@ def main():
     print("kernel ms:", {k: round(v, 3) for k, v in cplan.kernel_times() + uplan.kernel_times()})
     show("zh_l1_match_kernel", L1, list(slots[0:16]))
     show("zh_inflate_kernel: output wave", INF_O, list(slots[16:24]))
-    show("zh_inflate_kernel: decode wave", INF_D, list(slots[24:28]))
+    show("zh_inflate_kernel: decode wave", INF_D, list(slots[24:32]))
 
 
 if __name__ == "__main__":

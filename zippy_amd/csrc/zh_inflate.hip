@@ -593,7 +593,7 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
     return zh_bcast(values[id]);
   };
 
-  KPROF_DECL(4);  // decode wave: 0 waiting for the output wave, 1 working; 2 rounds; 3 waves
+  KPROF_DECL(8);  // decode wave: 0 waiting for the output wave, 1 other work; 2 rounds; 3 waves; 4 vector decode; 5 chain walks; 6 staging
   uint32_t rk = 0;  // rounds handed over so far
   int st = ZH_OK;
   // hand a round without chain tokens to the output wave
@@ -706,11 +706,16 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
     }
 
     for (;;) {  // inflate.nim:173-250, one round = up to 128 bit positions
+      KPROF_MARK(1);
       ensure();
+      KPROF_MARK(6);
       // ---- every lane decodes the tokens that would start at bits bp + lane (window A)
       // and bp + 64 + lane (window B): two independent dependency chains per lane; B is
       // used when A's chain runs into it cleanly and both together make at most 64 bytes ----
       const uint32_t wi = (uint32_t)((bp + lane) >> 5), sh = ((uint32_t)bp + lane) & 31u;
+      // (the output wave's status travels with these reads: a round's delay in noticing a failure
+      // costs nothing, the exposed LDS round trip of a read behind the barrier did)
+      const int32_t ostatus = s_ostatus;
       const uint32_t d0 = s_in[wi & (kInWords - 1u)], d1 = s_in[(wi + 1u) & (kInWords - 1u)],
                      d2 = s_in[(wi + 2u) & (kInWords - 1u)], d3 = s_in[(wi + 3u) & (kInWords - 1u)],
                      d4 = s_in[(wi + 4u) & (kInWords - 1u)];
@@ -745,6 +750,10 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
       // ---- the chain of real token starts ----
       uint64_t chain = 0, chainB = 0;
       uint32_t pos = 0;
+#ifdef ZH_KPROF
+      asm volatile("" ::"v"(A.tbits), "v"(B.tbits));  // (timers: the decode is done here)
+#endif
+      KPROF_MARK(4);
 #ifdef ZH_EMU
       while (pos < 64u) {
         const uint32_t tv = __builtin_amdgcn_readlane(A.tbits, pos);
@@ -762,42 +771,48 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
         }
       }
 #else
-      // the same two loops, seven instructions and one taken branch per symbol (hipcc's
-      // structured form of them is twice that); lane select and s_bitset use pos[5:0]
+      // the same two loops, five instructions and one taken branch per symbol: a token that
+      // cannot be decoded here has length 0x8000, which ends the loop like the end of the window
+      // does; its lane's bit is taken back afterwards (lane select and s_bitset use pos[5:0])
       {
         uint32_t tv;
         asm volatile(
             "1:\n\t"
             "v_readlane_b32 %[tv], %[tb], %[pos]\n\t"
-            "s_bitcmp1_b32 %[tv], 15\n\t"
-            "s_cbranch_scc1 2f\n\t"
             "s_bitset1_b64 %[ch], %[pos]\n\t"
             "s_add_u32 %[pos], %[pos], %[tv]\n\t"
             "s_cmp_lt_u32 %[pos], 64\n\t"
             "s_cbranch_scc1 1b\n\t"
+            "s_bitcmp0_b32 %[pos], 15\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "s_and_b32 %[pos], %[pos], 0x7fff\n\t"
+            "s_bitset0_b64 %[ch], %[pos]\n\t"
             "2:"
             : [tv] "=&s"(tv), [pos] "+s"(pos), [ch] "+s"(chain)
             : [tb] "v"(A.tbits)
             : "scc");
       }
-      const bool useB = pos >= 64u;
+      const bool useB = pos >= 64u;  // (a chain that stopped in window A left pos below 64)
       if (useB) {
         uint32_t tv;
         asm volatile(
             "1:\n\t"
             "v_readlane_b32 %[tv], %[tb], %[pos]\n\t"
-            "s_bitcmp1_b32 %[tv], 15\n\t"
-            "s_cbranch_scc1 2f\n\t"
             "s_bitset1_b64 %[ch], %[pos]\n\t"
             "s_add_u32 %[pos], %[pos], %[tv]\n\t"
             "s_cmp_lt_u32 %[pos], 0x80\n\t"
             "s_cbranch_scc1 1b\n\t"
+            "s_bitcmp0_b32 %[pos], 15\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "s_and_b32 %[pos], %[pos], 0x7fff\n\t"
+            "s_bitset0_b64 %[ch], %[pos]\n\t"
             "2:"
             : [tv] "=&s"(tv), [pos] "+s"(pos), [ch] "+s"(chainB)
             : [tb] "v"(B.tbits)
             : "scc");
       }
 #endif
+      KPROF_MARK(5);
       // ---- hand the round over (the output wave works out the offsets) ----
       RoundDesc& d = s_desc[rk & 1u];
       d.rec[0][lane] = A.outlen | (A.is_lit ? 1u << 9 : 0u) | ((uint32_t)((chain >> lane) & 1ull) << 10) | (A.val << 16);
@@ -878,13 +893,13 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
       KPROF_MARK(0);
       KPROF_COUNT(2, 1);
       rk++;
-      if (st == ZH_OK && s_ostatus != ZH_OK) st = s_ostatus;
+      if (st == ZH_OK && ostatus != ZH_OK) st = ostatus;
       if (st != ZH_OK || block_done) break;
     }
   }
   send_tail(kTailEnd, (uint32_t)st, 0, 0);
   KPROF_COUNT(3, 1);
-  KPROF_FLUSH(24, 4);
+  KPROF_FLUSH(24, 8);
 }
 
 // Final check of each stream against its trailer (gzip.nim:80-88, zippy.nim:152-162).
