@@ -225,8 +225,15 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
           const uint32_t d = ev ? (uint32_t)__ffsll((long long)ev) - 1u : 64u;
           const uint32_t info = eqlen | ((uint32_t)((Cw >> lane) & 1ull) << 5);
           const uint32_t gi = (uint32_t)__shfl((int)info, (int)((lane + d) & 63u), 64);
-          if (d < 32u && gi < 16u) hop = (lane + d) | 0x40u | ((lane + d + gi) << 8);
-          else if (!ev && lane >= 32u) hop = 63u | (64u << 8);
+          if (d < 32u && gi < 16u) {
+            // (the walk's bookkeeping, worked out here once per lane instead of once per hop:
+            // bits 16-21 = number of probes d + 1, bits 22-27 = the lane of ip-1 behind the match
+            // if it is in this step, else the match lane again)
+            const uint32_t g0 = lane + d, nx = g0 + gi;
+            hop = g0 | 0x40u | (nx << 8) | ((d + 1u) << 16) | ((nx <= 64u ? nx - 1u : g0) << 22);
+          } else if (!ev && lane >= 32u) {
+            hop = 63u | (64u << 8);
+          }
         }
         const uint32_t tt = ip_limit > W0 ? ip_limit - W0 : 0u;  // dense: first lane past ip_limit
         for (;;) {
@@ -247,40 +254,34 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
               do {
                 tv = __builtin_amdgcn_readlane(hop, cur);
                 if ((tv & 0x8040u) != 0x40u) break;  // not a match hop
-                const uint32_t g = tv & 63u, nxt = tv >> 8;
+                const uint32_t g = tv & 63u, nxt = (tv >> 8) & 127u;
                 sel |= 1ull << g;
                 ins |= (~0ull << cur) & (~0ull >> (63u - g));  // probes cur..g (table[h] = ip)
                 ins |= 1ull << (nxt <= 64u ? nxt - 1u : g);     // ip-1 behind the match (snappy.nim:126)
                 cur = nxt;
               } while (cur < lim);
 #else
-              // the same loop in 19 instructions with one taken branch per match
+              // the same loop in 12 instructions with one taken branch per match
               uint32_t t0, g, nxt;
-              uint64_t m1, m2;
+              uint64_t m1;
               asm volatile(
                   "1:\n\t"
                   "v_readlane_b32 %[tv], %[hop], %[cur]\n\t"
-                  "s_and_b32 %[t0], %[tv], 0x8040\n\t"
-                  "s_cmp_eq_u32 %[t0], 64\n\t"
+                  "s_bitcmp1_b32 %[tv], 6\n\t"
                   "s_cbranch_scc0 2f\n\t"
                   "s_and_b32 %[g], %[tv], 63\n\t"
-                  "s_lshr_b32 %[nxt], %[tv], 8\n\t"
                   "s_bitset1_b64 %[sel], %[g]\n\t"
-                  "s_lshl_b64 %[m1], -1, %[cur]\n\t"
-                  "s_sub_u32 %[t0], 63, %[g]\n\t"
-                  "s_lshr_b64 %[m2], -1, %[t0]\n\t"
-                  "s_and_b64 %[m1], %[m1], %[m2]\n\t"
+                  "s_bfe_u32 %[t0], %[tv], 0x60010\n\t"
+                  "s_bfm_b64 %[m1], %[t0], %[cur]\n\t"
                   "s_or_b64 %[ins], %[ins], %[m1]\n\t"
-                  "s_sub_u32 %[t0], %[nxt], 1\n\t"
-                  "s_cmp_lt_u32 %[t0], 64\n\t"
-                  "s_cselect_b32 %[t0], %[t0], %[g]\n\t"
+                  "s_bfe_u32 %[t0], %[tv], 0x60016\n\t"
                   "s_bitset1_b64 %[ins], %[t0]\n\t"
-                  "s_mov_b32 %[cur], %[nxt]\n\t"
+                  "s_bfe_u32 %[cur], %[tv], 0x70008\n\t"
                   "s_cmp_lt_u32 %[cur], %[lim]\n\t"
                   "s_cbranch_scc1 1b\n\t"
                   "2:"
                   : [tv] "=&s"(tv), [cur] "+s"(cur), [sel] "+s"(sel), [ins] "+s"(ins), [t0] "=&s"(t0),
-                    [g] "=&s"(g), [nxt] "=&s"(nxt), [m1] "=&s"(m1), [m2] "=&s"(m2)
+                    [g] "=&s"(g), [nxt] "=&s"(nxt), [m1] "=&s"(m1)
                   : [hop] "v"(hop), [lim] "s"(lim)
                   : "scc");
 #endif
