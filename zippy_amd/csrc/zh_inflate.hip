@@ -723,21 +723,32 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
         uint32_t v_lo, v_hi, e, tbits, outlen, val;  // val: literal byte or match distance
         bool is_lit;
       };
+      // `flag` in the lanes whose bit is set in the wave-uniform mask (one select on the mask
+      // instead of a 64-bit shift per lane)
+      auto lane_flag = [&](uint64_t mask, uint32_t flag) -> uint32_t {
+#ifdef ZH_EMU
+        return (mask >> lane) & 1ull ? flag : 0u;
+#else
+        uint32_t r;
+        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(flag), "s"(mask));
+        return r;
+#endif
+      };
       auto decode_tok = [&](uint32_t v_lo, uint32_t v_hi) -> Tok {
         Tok t;
         t.v_lo = v_lo;
         t.v_hi = v_hi;
-        const uint64_t v = (uint64_t)v_lo | ((uint64_t)v_hi << 32);
         uint32_t e = s_lit[v_lo & ((1u << kLitBits) - 1u)];
         if (e & 0x400u) e = s_lit[(e >> 16) + ((v_lo >> kLitBits) & ((1u << (e & 15u)) - 1u))];  // a longer code
         const uint32_t L = e & 15u, eb = (e >> 4) & 15u;
         t.e = e;
         t.is_lit = (e & 0x8000u) != 0;
         const uint32_t lenval = (e >> 16) + ((v_lo >> L) & ((1u << eb) - 1u));
-        const uint32_t o2 = L + eb;  // <= 15
-        const uint32_t de = s_dst[(uint32_t)(v >> o2) & ((1u << kDistBits) - 1u)];
+        // (32-bit funnel shifts: L + eb <= 20 and, with a distance code from the 8-bit table, o3 <= 28)
+        const uint32_t o2 = L + eb;
+        const uint32_t de = s_dst[zh_alignbit(v_hi, v_lo, o2) & ((1u << kDistBits) - 1u)];
         const uint32_t o3 = o2 + (de & 15u), deb = (de >> 4) & 15u;
-        t.val = t.is_lit ? (e >> 16) & 0xffu : (de >> 16) + ((uint32_t)(v >> o3) & ((1u << deb) - 1u));
+        t.val = t.is_lit ? (e >> 16) & 0xffu : (de >> 16) + (zh_alignbit(v_hi, v_lo, o3) & ((1u << deb) - 1u));
         if (t.is_lit) t.tbits = L;  // bits of the whole token; 0x8000: not decodable here
         else if (e != 0 && ((e >> 8) & 3u) == kKindBase && de != 0 && ((de >> 8) & 3u) == kKindBase) t.tbits = o3 + deb;
         else t.tbits = 0x8000u;
@@ -815,9 +826,9 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
       KPROF_MARK(5);
       // ---- hand the round over (the output wave works out the offsets) ----
       RoundDesc& d = s_desc[rk & 1u];
-      d.rec[0][lane] = A.outlen | (A.is_lit ? 1u << 9 : 0u) | ((uint32_t)((chain >> lane) & 1ull) << 10) | (A.val << 16);
+      d.rec[0][lane] = A.outlen | (A.is_lit ? 1u << 9 : 0u) | lane_flag(chain, 1u << 10) | (A.val << 16);
       if (useB)
-        d.rec[1][lane] = B.outlen | (B.is_lit ? 1u << 9 : 0u) | ((uint32_t)((chainB >> lane) & 1ull) << 10) | (B.val << 16);
+        d.rec[1][lane] = B.outlen | (B.is_lit ? 1u << 9 : 0u) | lane_flag(chainB, 1u << 10) | (B.val << 16);
       bp += pos;
       bool block_done = false;
       uint32_t tail = kTailNone, tail_a = 0, tail_b = 0;
