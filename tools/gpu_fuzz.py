@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""GPU-box stress (not part of pytest): the same input families as tools/emu_fuzz_l1.py through the
+real library, several seeds -- BestSpeed bytes against the oracle, round trips, foreign (zlib
+levels 1..9, raw/zlib/gzip) streams, and damaged streams whose accept/reject decision and bytes
+must equal the oracle's.   python tools/gpu_fuzz.py [first_seed] [n_seeds]"""
+import os
+import random
+import sys
+import zlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle  # noqa: E402
+from zippy_amd import api, synth  # noqa: E402
+
+
+def inputs(seed):
+    rnd = random.Random(seed)
+    bufs = []
+    for kind in ("runs", "rand", "zero", "mix"):
+        bufs += [b.tobytes() for b in synth.gen_batch(kind, 2, 120000, first_index=seed * 7)]
+    for per in (1, 2, 3, 5, 8, 13, 32, 33, 64, 65, 257, 300):
+        pat = rnd.randbytes(per)
+        b = bytearray()
+        while len(b) < 70000:
+            b += pat * rnd.randrange(1, 40)
+            if rnd.random() < 0.3:
+                b += rnd.randbytes(rnd.randrange(1, 50))
+        bufs.append(bytes(b[:70000]))
+    for alpha in (2, 4, 16, 200):
+        bufs.append(bytes(rnd.randrange(alpha) for _ in range(60000)))
+    text = synth.corpus_file(rnd.choice(["alice29.txt", "html", "urls.10K", "kppkn.gtb", "geo.protodata"]))
+    b = bytearray()
+    while len(b) < 300000:
+        o = rnd.randrange(max(1, len(text) - 4000))
+        b += text[o:o + rnd.randrange(10, 4000)]
+        b += rnd.randbytes(rnd.choice((0, 1, 5, 20, 31, 32, 33, 40, 64, 100, 500)))
+    bufs.append(bytes(b))
+    bufs += [text[100:100 + k] for k in range(0, 40)]
+    return bufs, rnd
+
+
+def main(first, count):
+    eng = api.engine()
+    eng.set_gzip_fname_len(0)
+    bad = 0
+    for seed in range(first, first + count):
+        bufs, rnd = inputs(seed)
+        outs, sts = eng.compress_batch(bufs, 1, oracle.dfGzip)
+        for i, (src, out, st) in enumerate(zip(bufs, outs, sts)):
+            if st != 0 or out != oracle.compress(src, 1, oracle.dfGzip, fname_len=0):
+                bad += 1
+                print("COMPRESS MISMATCH seed", seed, "case", i, len(src), st)
+        back, sts = eng.uncompress_batch(outs)
+        bad += sum(1 for s, b, st in zip(bufs, back, sts) if st != 0 or b != s)
+        # a few buffers at other levels
+        for level in (-1, 9, -2, 0):
+            pick = [bufs[i] for i in rnd.sample(range(len(bufs)), 4)]
+            o2, s2 = eng.compress_batch(pick, level, oracle.dfZlib)
+            for src, out, st in zip(pick, o2, s2):
+                if st != 0 or out != oracle.compress(src, level, oracle.dfZlib):
+                    bad += 1
+                    print("LEVEL MISMATCH seed", seed, level, len(src))
+        # foreign encoders: every zlib level and container
+        streams, golds = [], []
+        for src in bufs[:40]:
+            lvl = rnd.randrange(1, 10)
+            wb = rnd.choice((31, 15, -15))
+            c = zlib.compressobj(lvl, zlib.DEFLATED, wb, rnd.choice((1, 8, 9)), rnd.choice((0, 1, 2, 3)))
+            streams.append((c.compress(src) + c.flush(), wb))
+            golds.append(src)
+        for wb, fmt in ((31, oracle.dfGzip), (15, oracle.dfZlib), (-15, oracle.dfDeflate)):
+            sel = [(s, g) for (s, w), g in zip(streams, golds) if w == wb]
+            if not sel:
+                continue
+            got, sts = eng.uncompress_batch([s for s, _ in sel], fmt)
+            for (s, g), o, st in zip(sel, got, sts):
+                if st != 0 or o != g:
+                    bad += 1
+                    print("FOREIGN MISMATCH seed", seed, wb, len(g), st)
+        # damaged streams: same decision (and bytes) as the oracle
+        dmg = []
+        for s, wb in streams:
+            if wb != 31 or len(s) < 40:
+                continue
+            m = bytearray(s)
+            for _ in range(rnd.randrange(1, 4)):
+                m[rnd.randrange(12, len(m) - 8)] ^= 1 << rnd.randrange(8)
+            dmg.append(bytes(m))
+            if rnd.random() < 0.3:
+                dmg.append(s[:rnd.randrange(20, len(s))])
+        got, sts = eng.uncompress_batch(dmg, oracle.dfGzip)
+        for blob, o, st in zip(dmg, got, sts):
+            try:
+                want, wst = oracle.uncompress(blob, oracle.dfGzip), 0
+            except oracle.ZippyError as e:
+                want, wst = None, e.status
+            if (st == 0) != (wst == 0) or (st == 0 and o != want):
+                bad += 1
+                print("DAMAGED MISMATCH seed", seed, len(blob), st, wst)
+        print("seed", seed, "ok so far" if not bad else "BAD %d" % bad, flush=True)
+    print("gpu_fuzz: seeds %d..%d bad %d" % (first, first + count - 1, bad))
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 4) else 0)
