@@ -94,7 +94,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (zippy_amd has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torchrun the collective path is used even with one rank (exercises it on a 1-GPU box)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -144,7 +146,7 @@ def main():
     kernel_ms = {}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     t_comp = t_unc = 0.0
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -160,10 +162,10 @@ def main():
         for name, ms in cplan.kernel_times() + uplan.kernel_times():
             kernel_ms.setdefault(name, []).append(ms)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -217,7 +219,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sample, args.level, cores)
         out["host_gen_s"] = round(t_gen, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
