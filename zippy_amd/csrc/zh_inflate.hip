@@ -526,6 +526,8 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
   }
 
   // =========================== DECODE wave ===========================
+  // (it is the critical one of the pair at equal priority -- the output wave waits a fifth of
+  // the time -- so its decode + chain walk take first pick of the SIMD's issue slots, below)
   // input: the stream is addressed in bits from the 4-byte aligned base below `src`; 64 dwords
   // at a time go through a 512-byte LDS ring (bitstreams.nim:22-49's refill)
   const uint64_t end = mis + src_len;  // first byte offset (from asrc) past the stream
@@ -707,6 +709,9 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
 
     for (;;) {  // inflate.nim:173-250, one round = up to 128 bit positions
       KPROF_MARK(1);
+#ifndef ZH_EMU
+      __builtin_amdgcn_s_setprio(1);
+#endif
       ensure();
       KPROF_MARK(6);
       // ---- every lane decodes the tokens that would start at bits bp + lane (window A)
@@ -824,6 +829,9 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
       }
 #endif
       KPROF_MARK(5);
+#ifndef ZH_EMU
+      __builtin_amdgcn_s_setprio(0);
+#endif
       // ---- hand the round over (the output wave works out the offsets) ----
       RoundDesc& d = s_desc[rk & 1u];
       d.rec[0][lane] = A.outlen | (A.is_lit ? 1u << 9 : 0u) | lane_flag(chain, 1u << 10) | (A.val << 16);
