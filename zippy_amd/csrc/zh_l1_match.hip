@@ -203,6 +203,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
 
         KPROF_MARK(1);
         KPROF_COUNT(6, 1);
+#ifndef ZH_EMU
+        __builtin_amdgcn_s_setprio(1);  // the walk is a dependent scalar chain: first pick of the issue slots
+#endif
         // ---- the walk: wave-uniform replay of the reference's decisions ----
         uint64_t ins = post ? 1ull : 0ull;  // lanes whose position was inserted, in probe order
         uint32_t i = post ? 1u : 0u;        // next lane to probe
@@ -463,6 +466,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
           reprobe = true;
         }
         KPROF_MARK(3);
+#ifndef ZH_EMU
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (finished) break;  // nothing reads the table any more
         // ---- table inserts of the probes that really happened, in probe order ----
         const bool mine = (ins >> lane) & 1ull;
