@@ -33,12 +33,11 @@ __constant__ uint8_t c_clcl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4
 constexpr int kMaxSyms = 288;
 
 struct HuffWork {
-  uint32_t nfreq[2 * kMaxSyms];   // node frequency (leaves then internal nodes)
+  uint64_t hkey[kMaxSyms];         // the heap: node frequency << 16 | node (one LDS read per comparison)
   uint16_t left[2 * kMaxSyms];
   uint16_t right[2 * kMaxSyms];
   uint16_t depth[2 * kMaxSyms];
   int16_t symbol[kMaxSyms];        // leaf -> symbol
-  uint16_t heap[kMaxSyms];
   uint16_t order[kMaxSyms];        // leaves, sorted by depth when limiting
   uint16_t stack[2 * kMaxSyms + 4];
   int32_t histogram[2 * kMaxSyms];
@@ -46,41 +45,48 @@ struct HuffWork {
 
 __device__ inline uint32_t rev16(uint32_t v) { return __brev(v) >> 16; }
 
-// ---- Nim std/heapqueue (CPython heapq) on node indices, `<` on frequency ----
+// ---- Nim std/heapqueue (CPython heapq) on nodes, `<` on frequency only ----
 __device__ inline void heap_sift_to_root(HuffWork& w, int startpos, int pos) {
-  const uint16_t newitem = w.heap[pos];
-  const uint32_t f = w.nfreq[newitem];
+  const uint64_t newitem = w.hkey[pos];
+  const uint64_t f = newitem >> 16;
   while (pos > startpos) {
     const int parentpos = (pos - 1) >> 1;
-    const uint16_t parent = w.heap[parentpos];
-    if (f < w.nfreq[parent]) {
-      w.heap[pos] = parent;
+    const uint64_t parent = w.hkey[parentpos];
+    if (f < (parent >> 16)) {
+      w.hkey[pos] = parent;
       pos = parentpos;
     } else {
       break;
     }
   }
-  w.heap[pos] = newitem;
+  w.hkey[pos] = newitem;
 }
 __device__ inline void heap_sink_to_bottom(HuffWork& w, int len, int pos) {
   const int startpos = pos;
-  const uint16_t newitem = w.heap[pos];
+  const uint64_t newitem = w.hkey[pos];
   int childpos = 2 * pos + 1;
   while (childpos < len) {
     const int rightpos = childpos + 1;
-    if (rightpos < len && !(w.nfreq[w.heap[childpos]] < w.nfreq[w.heap[rightpos]])) childpos = rightpos;
-    w.heap[pos] = w.heap[childpos];
+    uint64_t c = w.hkey[childpos];
+    if (rightpos < len) {
+      const uint64_t r = w.hkey[rightpos];
+      if (!((c >> 16) < (r >> 16))) {
+        childpos = rightpos;
+        c = r;
+      }
+    }
+    w.hkey[pos] = c;
     pos = childpos;
     childpos = 2 * pos + 1;
   }
-  w.heap[pos] = newitem;
+  w.hkey[pos] = newitem;
   heap_sift_to_root(w, startpos, pos);
 }
-__device__ inline int heap_pop(HuffWork& w, int& len) {
-  const uint16_t last = w.heap[--len];
+__device__ inline uint64_t heap_pop(HuffWork& w, int& len) {
+  const uint64_t last = w.hkey[--len];
   if (len > 0) {
-    const uint16_t result = w.heap[0];
-    w.heap[0] = last;
+    const uint64_t result = w.hkey[0];
+    w.hkey[0] = last;
     heap_sink_to_bottom(w, len, 0);
     return result;
   }
@@ -112,27 +118,22 @@ __device__ int huffman_codes(const uint32_t* freq, int num_freq, int min_codes, 
         break;
       }
   } else {
-    int n = 0;
+    int n = 0, hlen = 0;
     for (int s = 0; s < num_freq; s++)
-      if (freq[s] > 0) {
-        w.nfreq[n] = freq[s];
+      if (freq[s] > 0) {  // :54-55 push the leaves, in symbol order
         w.symbol[n] = (int16_t)s;
         w.order[n] = (uint16_t)n;
+        w.hkey[hlen++] = ((uint64_t)freq[s] << 16) | (uint64_t)n;
+        heap_sift_to_root(w, 0, hlen - 1);
         n++;
       }
-    int hlen = 0;
-    for (int i = 0; i < n; i++) {  // :54-55 push all leaves
-      w.heap[hlen++] = (uint16_t)i;
-      heap_sift_to_root(w, 0, hlen - 1);
-    }
     int total = n;
     while (hlen >= 2) {  // :57-63
-      const int l = heap_pop(w, hlen);
-      const int r = heap_pop(w, hlen);
-      w.left[total] = (uint16_t)l;
-      w.right[total] = (uint16_t)r;
-      w.nfreq[total] = w.nfreq[l] + w.nfreq[r];
-      w.heap[hlen++] = (uint16_t)total;
+      const uint64_t l = heap_pop(w, hlen);
+      const uint64_t r = heap_pop(w, hlen);
+      w.left[total] = (uint16_t)(l & 0xffffu);
+      w.right[total] = (uint16_t)(r & 0xffffu);
+      w.hkey[hlen++] = (((l >> 16) + (r >> 16)) << 16) | (uint64_t)total;
       heap_sift_to_root(w, 0, hlen - 1);
       total++;
     }
