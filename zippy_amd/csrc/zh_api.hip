@@ -143,7 +143,7 @@ extern "C" int zh_create(int device, void* stream, zh_ctx** out) {
 
 extern "C" void zh_destroy(zh_ctx* ctx) {
   if (!ctx) return;
-  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 extern "C" const char* zh_last_error(zh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
@@ -226,10 +226,16 @@ static void prof_mark(zh_plan* p, const char* name) {
   size_t i = p->k_names.size();
   if (p->k_events.size() <= i) {
     hipEvent_t e;
-    hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) {  // no timing rather than a failed run
+      p->profiling = false;
+      return;
+    }
     p->k_events.push_back(e);
   }
-  hipEventRecord(p->k_events[i], p->ctx->stream);
+  if (hipEventRecord(p->k_events[i], p->ctx->stream) != hipSuccess) {
+    p->profiling = false;
+    return;
+  }
   p->k_names.push_back(name);
 }
 
@@ -239,11 +245,11 @@ extern "C" void zh_plan_set_profiling(zh_plan* plan, int on) {
 
 extern "C" int zh_plan_kernel_times(zh_plan* p, const char** names, float* ms, int max_entries) {
   if (!p || !p->profiling || p->k_names.size() < 2) return 0;
-  hipStreamSynchronize(p->ctx->stream);
+  if (hipStreamSynchronize(p->ctx->stream) != hipSuccess) return 0;
   int cnt = 0;
   for (size_t i = 0; i + 1 < p->k_names.size() && cnt < max_entries; i++) {
     float t = 0;
-    hipEventElapsedTime(&t, p->k_events[i], p->k_events[i + 1]);
+    if (hipEventElapsedTime(&t, p->k_events[i], p->k_events[i + 1]) != hipSuccess) break;
     names[cnt] = p->k_names[i];  // the marker recorded BEFORE a launch carries its name
     ms[cnt] = t;
     cnt++;
@@ -253,10 +259,11 @@ extern "C" int zh_plan_kernel_times(zh_plan* p, const char** names, float* ms, i
 
 extern "C" void zh_plan_destroy(zh_plan* p) {
   if (!p) return;
-  hipStreamSynchronize(p->ctx->stream);
-  if (p->arena) hipFree(p->arena);
-  if (p->seg_arena) hipFree(p->seg_arena);
-  for (auto e : p->k_events) hipEventDestroy(e);
+  // (nothing useful can be done about a failure while tearing down)
+  (void)hipStreamSynchronize(p->ctx->stream);
+  if (p->arena) (void)hipFree(p->arena);
+  if (p->seg_arena) (void)hipFree(p->seg_arena);
+  for (auto e : p->k_events) (void)hipEventDestroy(e);
   delete p;
 }
 
@@ -374,16 +381,25 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   }
   uint8_t* base = p->arena;
   hipStream_t s = ctx->stream;
-  hipMemcpyAsync(base + o_bufs, bufs.data(), n * sizeof(ZhBufDesc), hipMemcpyHostToDevice, s);
-  hipMemcpyAsync(base + o_blocks, blocks.data(), nb * sizeof(ZhBlockDesc), hipMemcpyHostToDevice, s);
-  hipMemcpyAsync(base + o_frags, frags.data(), nf * sizeof(ZhFragDesc), hipMemcpyHostToDevice, s);
-  hipMemcpyAsync(base + o_pieces, pieces.data(), nf * sizeof(ZhPieceDesc), hipMemcpyHostToDevice, s);
-  hipMemsetAsync(base + o_fnm, 0, nf * 4, s);
-  hipMemsetAsync(base + o_fsp, 0, nf * 4, s);
-  hipMemsetAsync(base + o_fhist, 0, nf * ZH_HIST_STRIDE * 2, s);
-  hipMemsetAsync(base + o_fnl, 0, nf * 4, s);
-  hipMemsetAsync(base + o_fex, 0, nf * 4, s);
-  ZH_HIP(ctx, hipStreamSynchronize(s));  // host vectors go out of scope
+  hipError_t up = hipSuccess;
+  auto chk = [&](hipError_t e) {
+    if (up == hipSuccess) up = e;
+  };
+  chk(hipMemcpyAsync(base + o_bufs, bufs.data(), n * sizeof(ZhBufDesc), hipMemcpyHostToDevice, s));
+  chk(hipMemcpyAsync(base + o_blocks, blocks.data(), nb * sizeof(ZhBlockDesc), hipMemcpyHostToDevice, s));
+  chk(hipMemcpyAsync(base + o_frags, frags.data(), nf * sizeof(ZhFragDesc), hipMemcpyHostToDevice, s));
+  chk(hipMemcpyAsync(base + o_pieces, pieces.data(), nf * sizeof(ZhPieceDesc), hipMemcpyHostToDevice, s));
+  chk(hipMemsetAsync(base + o_fnm, 0, nf * 4, s));
+  chk(hipMemsetAsync(base + o_fsp, 0, nf * 4, s));
+  chk(hipMemsetAsync(base + o_fhist, 0, nf * ZH_HIST_STRIDE * 2, s));
+  chk(hipMemsetAsync(base + o_fnl, 0, nf * 4, s));
+  chk(hipMemsetAsync(base + o_fex, 0, nf * 4, s));
+  chk(hipStreamSynchronize(s));  // host vectors go out of scope
+  if (up != hipSuccess) {
+    ctx->last_error = std::string("plan upload: ") + hipGetErrorString(up);
+    zh_plan_destroy(p);
+    return ZH_ERR_DEVICE;
+  }
 
   ZhCompressArgs& a = p->ca;
   a.bufs = p->d_bufs = carve<ZhBufDesc>(base, o_bufs);
@@ -518,9 +534,15 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
     return ZH_ERR_NOMEM;
   }
   uint8_t* base = p->arena;
-  hipMemcpyAsync(base + o_bufs, bufs.data(), n * sizeof(ZhBufDesc), hipMemcpyHostToDevice, ctx->stream);
-  hipMemcpyAsync(base + o_pieces, pieces.data(), np * sizeof(ZhPieceDesc), hipMemcpyHostToDevice, ctx->stream);
-  ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipError_t up = hipMemcpyAsync(base + o_bufs, bufs.data(), n * sizeof(ZhBufDesc), hipMemcpyHostToDevice, ctx->stream);
+  if (up == hipSuccess)
+    up = hipMemcpyAsync(base + o_pieces, pieces.data(), np * sizeof(ZhPieceDesc), hipMemcpyHostToDevice, ctx->stream);
+  if (up == hipSuccess) up = hipStreamSynchronize(ctx->stream);
+  if (up != hipSuccess) {
+    ctx->last_error = std::string("plan upload: ") + hipGetErrorString(up);
+    zh_plan_destroy(p);
+    return ZH_ERR_DEVICE;
+  }
   p->d_bufs = carve<ZhBufDesc>(base, o_bufs);
   p->d_pieces = carve<ZhPieceDesc>(base, o_pieces);
   p->npieces = (uint32_t)np;
@@ -585,9 +607,11 @@ extern "C" int zh_plan_uncompress_indexed(zh_ctx* ctx, uint64_t src_off, uint64_
     return ZH_ERR_NOMEM;
   }
   uint8_t* base = p->seg_arena;
-  hipMemcpyAsync(base + o_bufs, segs.data(), nseg * sizeof(ZhBufDesc), hipMemcpyHostToDevice, ctx->stream);
-  hipMemcpyAsync(base + o_start, start.data(), nseg * 8, hipMemcpyHostToDevice, ctx->stream);
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+  hipError_t up = hipMemcpyAsync(base + o_bufs, segs.data(), nseg * sizeof(ZhBufDesc), hipMemcpyHostToDevice, ctx->stream);
+  if (up == hipSuccess) up = hipMemcpyAsync(base + o_start, start.data(), nseg * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (up == hipSuccess) up = hipStreamSynchronize(ctx->stream);
+  if (up != hipSuccess) {
+    ctx->last_error = std::string("plan upload: ") + hipGetErrorString(up);
     zh_plan_destroy(p);
     return ZH_ERR_DEVICE;
   }
@@ -722,7 +746,7 @@ namespace {
 struct DevBuf {
   uint8_t* p = nullptr;
   ~DevBuf() {
-    if (p) hipFree(p);
+    if (p) (void)hipFree(p);
   }
 };
 struct PlanGuard {
@@ -736,7 +760,7 @@ struct Trace {
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
   void mark(zh_ctx* ctx, const char* what) {
     if (!on) return;
-    hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
     const auto now = std::chrono::steady_clock::now();
     fprintf(stderr, "[zh] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
     t = now;

@@ -240,8 +240,12 @@ extern "C" const void* zh_checksum_tables(int device) {
     delete h;
     return nullptr;
   }
-  hipMemcpy(d, h, sizeof(ChecksumTables), hipMemcpyHostToDevice);
+  const hipError_t e = hipMemcpy(d, h, sizeof(ChecksumTables), hipMemcpyHostToDevice);
   delete h;
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return nullptr;
+  }
   g_tabs_dev[device] = d;
   return d;
 }

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   __shared__ uint8_t s_cl_all[ZH_HIST_STRIDE];
   __shared__ uint8_t s_rle[704];
   __shared__ uint32_t s_hdr[ZH_HDR_WORDS];
-  __shared__ uint32_t s_mode, s_nlitlen, s_ndist, s_hdr_bits;
+  __shared__ uint32_t s_mode, s_hdr_bits;
 
   const unsigned lane = zh_lane();
   const uint32_t b = blockIdx.x;
@@ -299,16 +299,12 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
         s_codes[i] = (uint16_t)(rev16(c) >> (16 - l));
       }
       for (int i = 0; i < 30; i++) s_codes[288 + i] = (uint16_t)(rev16((uint32_t)i) >> 11);
-      s_nlitlen = 288;
-      s_ndist = 30;
       hdr_add(h, bd.is_final ? 1 : 0, 1);  // deflate.nim:296-298
       hdr_add(h, 1, 2);
     } else if (mode == ZH_MODE_DYNAMIC) {
       const int n_litlen = huffman_codes(s_freq, ZH_NUM_LITLEN, 257, 15, s_codes, s_lens, s_work);
       const int n_dist = huffman_codes(s_freq + ZH_NUM_LITLEN, ZH_NUM_DIST, 2, 15, s_codes + 288,
                                        s_lens + 288, s_work);
-      s_nlitlen = (uint32_t)n_litlen;
-      s_ndist = (uint32_t)n_dist;
       const int num_codes = n_litlen + n_dist;
       for (int i = 0; i < n_litlen; i++) s_cl_all[i] = s_lens[i];
       for (int i = 0; i < n_dist; i++) s_cl_all[n_litlen + i] = s_lens[288 + i];
