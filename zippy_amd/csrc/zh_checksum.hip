@@ -11,6 +11,8 @@
 //   * lanes are aligned to the end of the piece by one multiplication with
 //     x^(8*d) (d from a small table) and XOR-reduced across the wave.
 // Algorithmic traffic: each input byte is read once.
+#include <mutex>
+
 #include "zh_common.h"
 #include "zh_tables.h"
 
@@ -217,10 +219,13 @@ __global__ __launch_bounds__(64) void zh_checksum_combine_kernel(
 }
 
 // ---- host side ------------------------------------------------------------
+// one table set per device, shared by the contexts on it (contexts may be created concurrently)
 static ChecksumTables* g_tabs_dev[64] = {nullptr};
+static std::mutex g_tabs_mutex;
 
 extern "C" const void* zh_checksum_tables(int device) {
   if (device < 0 || device >= 64) device = 0;
+  std::lock_guard<std::mutex> lock(g_tabs_mutex);
   if (g_tabs_dev[device]) return g_tabs_dev[device];
   ChecksumTables* h = new ChecksumTables;
   constexpr zh::CrcTables ct = zh::make_crc_tables();
