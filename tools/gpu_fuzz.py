@@ -99,6 +99,39 @@ def main(first, count):
             if (st == 0) != (wst == 0) or (st == 0 and o != want):
                 bad += 1
                 print("DAMAGED MISMATCH seed", seed, len(blob), st, wst)
+        # block-parallel form: bytes + index against the oracle, indexed decode, wrong index rejected
+        big = b"".join(bufs[:12])
+        for level, bb in ((1, 32768), (rnd.choice((-1, 6, 9)), rnd.choice((32768, 65536, 131072))), (0, 32768)):
+            want, widx = oracle.compress_blocks(big, level, oracle.dfGzip, bb, fname_len=0)
+            got, idx = eng.compress_blocks(big, level, oracle.dfGzip, bb)
+            if got != want or idx != widx or eng.uncompress_indexed(got, idx, oracle.dfGzip) != big:
+                bad += 1
+                print("BLOCKS MISMATCH seed", seed, level, bb)
+            if len(idx) > 3:
+                k = rnd.randrange(1, len(idx) - 1)
+                wrong = idx[:k] + [(idx[k][0] + rnd.choice((-3, 1, 5)), idx[k][1])] + idx[k + 1:]
+                try:
+                    out = eng.uncompress_indexed(got, wrong, oracle.dfGzip)
+                    if out != big:
+                        bad += 1
+                        print("BLOCKS WRONG-INDEX ACCEPTED WITH WRONG BYTES seed", seed)
+                except Exception:
+                    pass
+        # ZIP: create == oracle, readable by zipfile, extract batch == contents
+        import io
+        import zipfile
+        from oracle import zip_oracle
+        entries = [("f%03d/%d.bin" % (i % 5, i), bufs[i]) for i in rnd.sample(range(len(bufs)), 25)]
+        arc = eng.create_zip(entries, 0x6000, 0x5a21)
+        if arc != zip_oracle.create_archive(entries, 0x6000, 0x5a21) or zipfile.ZipFile(io.BytesIO(arc)).testzip():
+            bad += 1
+            print("ZIP CREATE MISMATCH seed", seed)
+        rd = eng.open_zip(arc)
+        outs, sts = rd.extract_batch(list(range(len(entries))))
+        if any(sts) or outs != [c for _, c in reversed(entries)]:
+            bad += 1
+            print("ZIP EXTRACT MISMATCH seed", seed)
+        rd.close()
         print("seed", seed, "ok so far" if not bad else "BAD %d" % bad, flush=True)
     print("gpu_fuzz: seeds %d..%d bad %d" % (first, first + count - 1, bad))
     return bad
