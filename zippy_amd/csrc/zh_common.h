@@ -123,6 +123,16 @@ __device__ __forceinline__ void zh_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A store the caches need not keep (streamed results next to hot tables).
+template <class T>
+__device__ __forceinline__ void zh_store_nt(T* p, T v) {
+#ifdef ZH_EMU
+  *p = v;
+#else
+  __builtin_nontemporal_store(v, p);
+#endif
+}
+
 __device__ __forceinline__ uint32_t zh_bcast(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint64_t zh_bcast64(uint64_t v) {
   uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);

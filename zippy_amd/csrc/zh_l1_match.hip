@@ -303,9 +303,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
               KPROF_COUNT(8, __popcll(sel));
               if ((sel >> lane) & 1ull) {  // every match lane files its own record
                 const uint32_t k = nm + (uint32_t)__popcll(sel & zh_lanemask_lt());
-                m_pos[k] = (uint16_t)pos;
-                m_len[k] = (uint16_t)eqlen;
-                m_off[k] = (uint16_t)(pos - old);
+                zh_store_nt(m_pos + k, (uint16_t)pos);  // (streaming: keep the records out of the tables' way)
+                zh_store_nt(m_len + k, (uint16_t)eqlen);
+                zh_store_nt(m_off + k, (uint16_t)(pos - old));
               }
               nm += (uint32_t)__popcll(sel);
             }
@@ -447,9 +447,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
           }
           if (matched > limit - mp) matched = limit - mp;
           if (lane == 0) {
-            m_pos[nm] = (uint16_t)mp;
-            m_len[nm] = (uint16_t)matched;
-            m_off[nm] = (uint16_t)(mp - cand);
+            zh_store_nt(m_pos + nm, (uint16_t)mp);
+            zh_store_nt(m_len + nm, (uint16_t)matched);
+            zh_store_nt(m_off + nm, (uint16_t)(mp - cand));
           }
           nm++;
           ip = mp + matched;
