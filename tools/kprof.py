@@ -17,6 +17,8 @@ L1 = ["stage-in", "step: vector part", "step: fast walk", "step: slow walk", "st
       "stats phase", "#steps", "#fast steps", "#events fast", "#events slow", "#match extensions",
       "#waves", "#slow: all lanes miss", "#slow: (unused)", "#slow: shared-slot lane",
       "#slow: plain hit"]
+EMIT = ["flush + loop", "chunk bitmaps", "bitmaps, source, scan, match fields", "codes", "scan + LDS ORs",
+        "last flush", "#waves", "#(unused)"]
 INF_O = ["waiting for a round", "working", "#rounds", "#waves", "#long rounds", "#far rounds", "#doubling turns", "#tail matches"]
 INF_D = ["waiting for the output wave", "other work", "#rounds", "#waves", "vector decode", "chain walks", "staging",
          "#(unused)"]
@@ -72,6 +74,7 @@ def main():
     eng.lib.zh_kprof_read(slots, 0)
     print("kernel ms:", {k: round(v, 3) for k, v in cplan.kernel_times() + uplan.kernel_times()})
     show("zh_l1_match_kernel", L1, list(slots[0:16]))
+    show("zh_emit_kernel", EMIT, list(slots[32:40]))
     show("zh_inflate_kernel: output wave", INF_O, list(slots[16:24]))
     show("zh_inflate_kernel: decode wave", INF_D, list(slots[24:32]))
 

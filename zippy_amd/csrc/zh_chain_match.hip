@@ -250,10 +250,10 @@ __global__ __launch_bounds__(64) void zh_frag_stats_kernel(const uint8_t* __rest
     if (m < nmatch) {
       p = m_pos[m];
       const uint32_t l = m_len[m], o = m_off[m];
-      const uint32_t li = c_len.index_of[l - 3], di = zh_dist_code(o);
+      const uint32_t li = zh_len_code(l), di = zh_dist_code(o);
       atomicAdd(&s_hist[257 + li], 1u);
       atomicAdd(&s_hist[ZH_NUM_LITLEN + di], 1u);
-      extra_bits += c_len.extra[li] + c_dist.extra[di];
+      extra_bits += zh_len_extra_bits(li) + zh_dist_extra_bits(di);
       e = p + l;
       if (e > n) e = n;
     } else {

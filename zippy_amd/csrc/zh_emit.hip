@@ -162,17 +162,17 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
       uint32_t nbits = 0;
       if ((st4 >> k) & 1u) {
         const uint32_t length = ml[k], offset = mo[k];
-        const uint32_t li = c_len.index_of[length - 3], di = zh_dist_code(offset);
+        const uint32_t li = zh_len_code(length), di = zh_dist_code(offset);
         const uint32_t lc = s_lit[257 + li], dc = s_dist[di];
         // deflate.nim:417-433
         v = lc & 0xffffu;
         nbits = lc >> 16;
-        v |= (uint64_t)(length - c_len.base[li]) << nbits;
-        nbits += c_len.extra[li];
+        v |= (uint64_t)(length - zh_len_base(li)) << nbits;
+        nbits += zh_len_extra_bits(li);
         v |= (uint64_t)(dc & 0xffffu) << nbits;
         nbits += dc >> 16;
-        v |= (uint64_t)(offset - c_dist.base[di]) << nbits;
-        nbits += c_dist.extra[di];
+        v |= (uint64_t)(offset - zh_dist_base(di)) << nbits;
+        nbits += zh_dist_extra_bits(di);
       } else if (!((skip4 >> k) & 1u)) {
         const uint32_t lc = s_lit[(w >> (8u * k)) & 255u];
         v = lc & 0xffffu;

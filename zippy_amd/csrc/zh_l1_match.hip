@@ -495,10 +495,10 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   uint32_t extra_bits = 0, covered = 0;
   for (uint32_t m = lane; m < nmatch; m += 64) {
     const uint32_t p = m_pos[m], l = m_len[m], o = m_off[m];
-    const uint32_t li = c_len.index_of[l - 3], di = zh_dist_code(o);
+    const uint32_t li = zh_len_code(l), di = zh_dist_code(o);
     atomicAdd(&s_hist[257 + li], 1u);
     atomicAdd(&s_hist[ZH_NUM_LITLEN + di], 1u);
-    extra_bits += c_len.extra[li] + c_dist.extra[di];
+    extra_bits += zh_len_extra_bits(li) + zh_dist_extra_bits(di);
     covered += l;
     const uint32_t e = p + l;  // set bits [p, e)
     for (uint32_t w = p >> 5; w <= (e - 1) >> 5; w++) {

@@ -74,3 +74,24 @@ __host__ __device__ inline uint32_t zh_dist_code(uint32_t dist) {
   uint32_t hb = 31u - (uint32_t)__builtin_clz(v);  // v >= 4
   return 2u * hb + ((v >> (hb - 1)) & 1u);
 }
+
+// The same tables as arithmetic, for the device hot paths (a per-lane lookup in a __constant__
+// array is a dependent trip to memory; these are a dozen ALU operations).  zh_selfcheck_tables()
+// in the tests compares them with the tables above for every length and distance.
+// length 3..258 -> code index 0..28 (internal.nim:46-73 baseLengthIndices)
+__host__ __device__ inline uint32_t zh_len_code(uint32_t length) {
+  const uint32_t l = length - 3u;
+  if (l < 8u) return l;
+  if (l == 255u) return 28u;
+  const uint32_t hb = 31u - (uint32_t)__builtin_clz(l);  // 3..7
+  return 4u * (hb - 1u) + ((l >> (hb - 2u)) & 3u);
+}
+__host__ __device__ inline uint32_t zh_len_extra_bits(uint32_t li) { return li < 8u || li == 28u ? 0u : (li - 4u) >> 2; }
+__host__ __device__ inline uint32_t zh_len_base(uint32_t li) {
+  return li < 8u ? li + 3u : li == 28u ? 258u : 3u + ((4u + (li & 3u)) << ((li - 4u) >> 2));
+}
+__host__ __device__ inline uint32_t zh_dist_extra_bits(uint32_t di) { return di < 4u ? 0u : (di - 2u) >> 1; }
+__host__ __device__ inline uint32_t zh_dist_base(uint32_t di) {
+  return di < 4u ? di + 1u : 1u + ((2u + (di & 1u)) << ((di - 2u) >> 1));
+}
+
