@@ -16,6 +16,7 @@
 // (+ the match list produced by the matcher).
 #include "zh_common.h"
 #include "zh_tables.h"
+#include "zh_kprof.h"
 
 namespace {
 __constant__ zh::LenTables c_len = zh::make_len_tables();
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   __shared__ uint32_t s_stage[kStageWords + 4];
 
   const unsigned lane = zh_lane();
+  KPROF_DECL(8);  // 0 flush + loop, 1 chunk bitmaps, 2 bitmaps/source/scan/match fields, 3 codes, 4 scan + LDS ORs, 5 last flush, 6 waves
   const uint32_t f = blockIdx.x;
   const ZhFragDesc fd = a.frags[f];
   const uint32_t n = fd.len;
@@ -128,7 +130,9 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   auto dw = [&](uint32_t i) -> uint32_t { return asrc[i < last_dw ? i : last_dw]; };
 
   for (uint32_t base = 0; base < n; base += 256) {
+    KPROF_MARK(0);
     if ((base & (kChunk - 1u)) == 0) build_chunk(base);
+    KPROF_MARK(1);
     const uint32_t p0 = base + 4u * lane;  // this lane's four positions p0 .. p0+3
     const bool in = p0 < n;
     const uint32_t bw = in ? (p0 & (kChunk - 1u)) >> 5 : 0u, bs = p0 & 31u;  // p0 is a multiple of 4: one bitmap word
@@ -154,6 +158,10 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
         m++;
       }
     }
+#ifdef ZH_KPROF
+    asm volatile("" ::"v"(ml[0]), "v"(mo[0]), "v"(ml[3]), "v"(w));
+#endif
+    KPROF_MARK(2);
     uint64_t val[4];
     uint32_t nb[4], lane_bits = 0;
 #pragma unroll
@@ -183,6 +191,10 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
       lane_bits += nbits;
     }
 
+#ifdef ZH_KPROF
+    asm volatile("" ::"v"(lane_bits));
+#endif
+    KPROF_MARK(3);
     const uint32_t incl = zh_wave_scan(lane_bits);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
     uint32_t bp = stage_bits + incl - lane_bits;
@@ -198,6 +210,10 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
       }
     }
     stage_bits += total;
+#ifdef ZH_KPROF
+    zh_wave_sync();
+#endif
+    KPROF_MARK(4);
 
     const bool last = base + 256 >= n;
     if (stage_bits >= kFlushBits || last) {
@@ -225,6 +241,9 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
       }
     }
   }
+  KPROF_MARK(5);
+  KPROF_COUNT(6, 1);
+  KPROF_FLUSH(32, 8);
 }
 
 extern "C" void zh_launch_emit(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst,
