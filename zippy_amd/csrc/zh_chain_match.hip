@@ -26,8 +26,6 @@
 #include "zh_tables.h"
 
 namespace {
-__constant__ zh::LenTables c_len = zh::make_len_tables();
-__constant__ zh::DistTables c_dist = zh::make_dist_tables();
 constexpr uint32_t kHashMul = 0x1e35a7bdu;
 constexpr uint32_t kHashBits = 17;
 

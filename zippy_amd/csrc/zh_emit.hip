@@ -19,8 +19,6 @@
 #include "zh_kprof.h"
 
 namespace {
-__constant__ zh::LenTables c_len = zh::make_len_tables();
-__constant__ zh::DistTables c_dist = zh::make_dist_tables();
 constexpr uint32_t kChunk = 4096;                      // positions per match-bitmap chunk (16 passes)
 constexpr uint32_t kStageWords = 512;                  // 2 KiB staging window
 constexpr uint32_t kFlushBits = (kStageWords - 200) * 32;  // flush threshold: a 256-position pass adds < 6400 bits

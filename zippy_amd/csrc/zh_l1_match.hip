@@ -24,8 +24,6 @@
 #include "zh_tables.h"
 
 namespace {
-__constant__ zh::LenTables c_len = zh::make_len_tables();
-__constant__ zh::DistTables c_dist = zh::make_dist_tables();
 constexpr uint32_t kHashMul = 0x1e35a7bdu;  // snappy.nim:70-71
 // byte-wide per-step slot counters, four to a dword, keyed by the low hash bits (also the size
 // of the coverage bitmap that reuses the array: 1024 words = 32768 bits)
