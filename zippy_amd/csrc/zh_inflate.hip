@@ -25,6 +25,10 @@
 
 namespace {
 
+// (table entries are built once per block and in the rare lone-token path: tables are fine here,
+// and the arithmetic forms of zh_tables.h cost the round loop registers)
+__constant__ zh::LenTables c_len = zh::make_len_tables();
+__constant__ zh::DistTables c_dist = zh::make_dist_tables();
 __constant__ uint8_t c_clcl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 constexpr uint32_t kLitBits = 10, kDistBits = 8;
@@ -140,13 +144,13 @@ __device__ __forceinline__ uint32_t litlen_entry(uint32_t sym, uint32_t len) {
   if (sym == 256) return len | (kKindEob << 8);
   if (sym < 286) {  // inflate.nim:199-209
     const uint32_t li = sym - 257;
-    return len | (zh_len_extra_bits(li) << 4) | (kKindBase << 8) | (zh_len_base(li) << 16);
+    return len | ((uint32_t)c_len.extra[li] << 4) | (kKindBase << 8) | ((uint32_t)c_len.base[li] << 16);
   }
   return len | (kKindBad << 8);  // 286, 287 and the 0xffff "unassigned code" marker
 }
 __device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t len) {
   if (sym < 30)  // inflate.nim:210-222
-    return len | (zh_dist_extra_bits(sym) << 4) | (kKindBase << 8) | (zh_dist_base(sym) << 16);
+    return len | ((uint32_t)c_dist.extra[sym] << 4) | (kKindBase << 8) | ((uint32_t)c_dist.base[sym] << 16);
   return len | (kKindBad << 8);
 }
 __device__ __forceinline__ uint32_t cl_entry(uint32_t sym, uint32_t len) { return len | (sym << 16); }
