@@ -19,6 +19,8 @@ L1 = ["stage-in", "step: vector part", "step: fast walk", "step: slow walk", "st
       "#slow: plain hit"]
 EMIT = ["flush + loop", "chunk bitmaps", "bitmaps, source, scan, match fields", "codes", "scan + LDS ORs",
         "last flush", "#waves", "#(unused)"]
+HUFF = ["histogram sum", "litlen code", "distance code", "run-length coding", "code-length code", "header bits",
+        "tables out + fragment sizes", "#waves"]
 INF_O = ["waiting for a round", "working", "#rounds", "#waves", "#long rounds", "#far rounds", "#doubling turns", "#tail matches"]
 INF_D = ["waiting for the output wave", "other work", "#rounds", "#waves", "vector decode", "chain walks", "staging",
          "#(unused)"]
@@ -75,6 +77,7 @@ def main():
     print("kernel ms:", {k: round(v, 3) for k, v in cplan.kernel_times() + uplan.kernel_times()})
     show("zh_l1_match_kernel", L1, list(slots[0:16]))
     show("zh_emit_kernel", EMIT, list(slots[32:40]))
+    show("zh_huffman_kernel", HUFF, list(slots[40:48]))
     show("zh_inflate_kernel: output wave", INF_O, list(slots[16:24]))
     show("zh_inflate_kernel: decode wave", INF_D, list(slots[24:32]))
 

@@ -25,6 +25,7 @@
 // (zippy.nim:47-58,71-78).  All of it is OR-ed into a zeroed output.
 #include "zh_common.h"
 #include "zh_tables.h"
+#include "zh_kprof.h"
 
 namespace {
 
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   __shared__ uint32_t s_mode, s_hdr_bits;
 
   const unsigned lane = zh_lane();
+  KPROF_DECL(8);
   const uint32_t b = blockIdx.x;
   const ZhBlockDesc bd = a.blocks[b];
   const int level = a.level;
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
     s_lens[i] = 0;
   }
   zh_wave_sync();
+  KPROF_MARK(0);
 
   if (lane == 0) {
     uint32_t mode;
@@ -303,8 +306,10 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
       hdr_add(h, 1, 2);
     } else if (mode == ZH_MODE_DYNAMIC) {
       const int n_litlen = huffman_codes(s_freq, ZH_NUM_LITLEN, 257, 15, s_codes, s_lens, s_work);
+      KPROF_MARK(1);
       const int n_dist = huffman_codes(s_freq + ZH_NUM_LITLEN, ZH_NUM_DIST, 2, 15, s_codes + 288,
                                        s_lens + 288, s_work);
+      KPROF_MARK(2);
       const int num_codes = n_litlen + n_dist;
       for (int i = 0; i < n_litlen; i++) s_cl_all[i] = s_lens[i];
       for (int i = 0; i < n_dist; i++) s_cl_all[n_litlen + i] = s_lens[288 + i];
@@ -346,6 +351,7 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
           i++;
         }
       }
+      KPROF_MARK(3);
       uint32_t cl_freq[19];
       for (int i = 0; i < 19; i++) cl_freq[i] = 0;
       for (int i = 0; i < rle_len; i++) {  // deflate.nim:352-360
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
       int hclen = 19;
       while (clcl_ordered[hclen - 1] == 0) hclen--;
       hclen -= 4;
+      KPROF_MARK(4);
       hdr_add(h, bd.is_final ? 1 : 0, 1);  // deflate.nim:376-383
       hdr_add(h, 2, 2);
       hdr_add(h, (uint32_t)(n_litlen - 257), 5);
@@ -377,6 +384,7 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
     s_hdr_bits = h.bits;
   }
   zh_wave_sync();
+  KPROF_MARK(5);
 
   const uint32_t mode = s_mode;
   if (lane == 0) {
@@ -404,6 +412,9 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
     total += acc;
   }
   if (lane == 0) a.b_bits[b] = total;
+  KPROF_MARK(6);
+  KPROF_COUNT(7, 1);
+  KPROF_FLUSH(40, 8);
 }
 
 __global__ __launch_bounds__(64) void zh_layout_kernel(uint8_t* __restrict__ d_dst, ZhCompressArgs a,
