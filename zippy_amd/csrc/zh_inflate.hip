@@ -401,8 +401,10 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
       const uint32_t total = totalA + totalB;
       if (total - 1u < 64u) {
         const bool is_match = in_chain && !is_lit, is_matchB = in_chainB && !is_litB;
-        if (__ballot((is_match && (uint64_t)valA > op + opre) ||
-                     (is_matchB && (uint64_t)valB > op + opreB))) {  // inflate.nim:224-225
+        // inflate.nim:224-225 `distance > op`: a distance is at most 32768 (30 codes), so the lanes
+        // only need asking while the stream is that young
+        if (op < 32768u && __ballot((is_match && (uint64_t)valA > op + opre) ||
+                                    (is_matchB && (uint64_t)valB > op + opreB))) {
           st = ZH_ERR_INVALID_BUFFER;
         } else if (!count_only && op + total > cap) {
           st = ZH_ERR_DST_TOO_SMALL;
