@@ -417,20 +417,17 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
           zh_wave_sync();
           const uint32_t tk = zh_wave_scan_max(s_map[lane]);  // token (window, lane) + 1 of output byte `lane`
           const uint32_t j = (tk - 1u) & 63u;
-          const uint32_t f1 = (is_lit ? 0x10000u : 0u) | valA;
-          uint32_t g1 = (uint32_t)__shfl((int)f1, (int)j, 64);
-          if (use_b) {
-            const uint32_t f1B = (is_litB ? 0x10000u : 0u) | valB;
-            const uint32_t g1B = (uint32_t)__shfl((int)f1B, (int)j, 64);
-            if (tk > 64u) g1 = g1B;
-          }
-          const uint32_t gd = g1 & 0xffffu;
+          // both windows' tokens of a lane travel in one cross-lane fetch: 16 bits each, a distance
+          // (<= 0x8000) as it is, a literal as 0x9000 | byte
+          const uint32_t f1 = (is_lit ? 0x9000u | valA : valA) | ((is_litB ? 0x9000u | valB : valB) << 16);
+          const uint32_t g2 = (uint32_t)__shfl((int)f1, (int)j, 64);
+          const uint32_t gd = tk > 64u ? g2 >> 16 : g2 & 0xffffu;
           const bool live = lane < total;
           uint32_t val = gd & 0xffu;
           uint32_t par = lane;  // source byte inside this round (itself: a root)
           bool far = false;
           uint32_t back = 0;
-          if (live && !(g1 & 0x10000u)) {
+          if (live && gd < 0x9000u) {
             if (gd <= lane) {
               par = lane - gd;
             } else {
