@@ -14,6 +14,9 @@ def engine():
     if _engine is None:
         import build_emu
         from zippy_amd._binding import Engine
+        # few table slots, so that the matcher's persistent waves take several fragments each (their
+        # tables are reused without clearing) in batches the emulator can afford
+        os.environ.setdefault("ZH_L1_SLOTS", "64")
         _engine = Engine(build_emu.build())
         _engine.set_gzip_fname_len(0)
     return _engine
