@@ -46,6 +46,16 @@ def cpu_baseline(bufs, level, cores):
         t2 = time.perf_counter()
     assert outs[0] == bufs[0]
     nbytes = sum(len(b) for b in bufs)
+    # second yardstick (the reference's own tests/bench.nim does the same): system zlib
+    # on the same sample and threads (zlib releases the GIL)
+    import zlib
+    zl = 1 if level == 1 else 6 if level == -1 else max(0, min(9, level))
+    with ThreadPoolExecutor(cores) as ex:
+        t3 = time.perf_counter()
+        zblobs = list(ex.map(lambda b: zlib.compress(b, zl), bufs))
+        t4 = time.perf_counter()
+        list(ex.map(zlib.decompress, zblobs))
+        t5 = time.perf_counter()
     return {
         "value": nbytes / GIB / (t2 - t0),
         "unit": "GiB/s",
@@ -55,6 +65,10 @@ def cpu_baseline(bufs, level, cores):
                   "%d threads; compress %.3f GiB/s, uncompress %.3f GiB/s" % (
                       len(bufs), len(bufs[0]), level, cores, nbytes / GIB / (t1 - t0),
                       nbytes / GIB / (t2 - t1)),
+        "zlib": {"level": zl, "compress_GiBps": round(nbytes / GIB / (t4 - t3), 3),
+                 "uncompress_GiBps": round(nbytes / GIB / (t5 - t4), 3),
+                 "both_GiBps": round(nbytes / GIB / (t5 - t3), 3),
+                 "ratio": round(nbytes / sum(len(z) for z in zblobs), 4)},
     }
 
 
