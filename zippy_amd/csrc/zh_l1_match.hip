@@ -8,12 +8,12 @@
 // so the match list equals the reference's token stream fragment by fragment
 // (tests compare them token for token through zh_debug_tokens).
 //
-// LDS per wave: the u16 hash table (32 KiB, snappy.nim:7), 4 KiB of per-step slot
-// counters (reused as the coverage bitmap afterwards) and the symbol histograms -- 38 KiB,
-// four waves per CU.  The fragment's own bytes are read through L1/L2 instead of a second
-// 32 KiB LDS copy: a lone wave runs at well under a tenth of its SIMD's issue rate (every
-// step is a chain of dependent round trips), so waves per CU, not latency per access, is
-// what buys throughput.
+// Each wave keeps its u16 hash table (32 KiB, snappy.nim:7) in a pooled, L2/MALL-resident slot
+// of HBM scratch and only 7.4 KiB in LDS (per-step slot counters, reused as the coverage bitmap
+// afterwards; the slot-written bitmap; the symbol histograms): 20 waves per CU.  A lone wave runs
+// at well under a tenth of its SIMD's issue rate (every step is a chain of dependent round
+// trips), so waves per CU, not latency per access, is what buys throughput.  The fragment's own
+// bytes and the candidates' are read through L1/L2 with unaligned 128-bit loads.
 // Output per fragment (HBM scratch): the match list (start, length, offset as
 // u16 SoA), the litlen/distance histograms (u16 x 320), literal count and the
 // sum of extra bits -- everything the Huffman and emission kernels need.
@@ -28,6 +28,10 @@ constexpr uint32_t kHashMul = 0x1e35a7bdu;  // snappy.nim:70-71
 // byte-wide per-step slot counters, four to a dword, keyed by the low hash bits (also the size
 // of the coverage bitmap that reuses the array: 1024 words = 32768 bits)
 constexpr uint32_t kCntWords = 1024;
+// 16 bytes at any byte address (gfx950 global loads need no alignment)
+struct __attribute__((packed)) Bytes16 {
+  uint32_t x, y, z, w;
+};
 
 }  // namespace
 
@@ -134,10 +138,11 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         }
         const bool valid = pos + step <= ip_limit;  // the reference's `nextIp > ipLimit` test
         if (!valid) pos = 1;  // keep LDS reads in range; the lane is never walked
-        // round trip 1: 16 source bytes at pos (five aligned dwords)
-        const uint32_t pq = pos + mis, pw = pq >> 2;
-        const uint32_t p0 = dw(pw), p1 = dw(pw + 1), p2 = dw(pw + 2), p3 = dw(pw + 3), p4 = dw(pw + 4);
-        const uint32_t a0 = __builtin_amdgcn_alignbyte(p1, p0, pq);
+        // round trip 1: the 16 source bytes at pos, one unaligned 128-bit load (a valid lane has
+        // pos + 16 <= n, and so has every candidate, which lies before it)
+        Bytes16 av = {0, 0, 0, 0};
+        if (valid) av = *reinterpret_cast<const Bytes16*>(src + pos);
+        const uint32_t a0 = av.x, a1 = av.y, a2 = av.z, a3 = av.w;
         const uint32_t hp = a0 * kHashMul;
         const uint32_t h = hp >> shift, tag = (hp >> 17) & 1u;
         // round trip 2: the table slot; every lane also ticks a counter of its (folded) hash,
@@ -150,26 +155,17 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         const uint32_t ck = (h & (kCntWords * 4u - 1u)) >> 2, cs = (h & 3u) * 8u;
         if (valid) atomicAdd(&s_scr[ck], 1u << cs);
         zh_wave_sync();  // (orders the counter traffic between lanes; emits nothing)
-        const uint32_t a1 = __builtin_amdgcn_alignbyte(p2, p1, pq);
-        const uint32_t a2 = __builtin_amdgcn_alignbyte(p3, p2, pq);
-        const uint32_t a3 = __builtin_amdgcn_alignbyte(p4, p3, pq);
-        // round trip 3: 16 bytes at the candidate the table held when the step began
-        const uint32_t oq = old + mis, ow = oq >> 2;
-        uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
-        if (fetch) {
-          q0 = dw(ow);
-          q1 = dw(ow + 1);
-          q2 = dw(ow + 2);
-          q3 = dw(ow + 3);
-          q4 = dw(ow + 4);
-        }
+        // round trip 3: 16 bytes at the candidate the table held when the step began -- one
+        // scattered 128-bit load per lane (one L1 tag lookup instead of five)
+        Bytes16 qv = {0, 0, 0, 0};
+        if (fetch) qv = *reinterpret_cast<const Bytes16*>(src + old);
         const uint32_t cnt = valid ? (s_scr[ck] >> cs) & 255u : 0u;
         zh_wave_sync();
         if (valid) s_scr[ck] = 0;
-        const uint32_t x0 = fetch ? a0 ^ __builtin_amdgcn_alignbyte(q1, q0, oq) : 1u;
-        const uint32_t x1 = a1 ^ __builtin_amdgcn_alignbyte(q2, q1, oq);
-        const uint32_t x2 = a2 ^ __builtin_amdgcn_alignbyte(q3, q2, oq);
-        const uint32_t x3 = a3 ^ __builtin_amdgcn_alignbyte(q4, q3, oq);
+        const uint32_t x0 = fetch ? a0 ^ qv.x : 1u;
+        const uint32_t x1 = a1 ^ qv.y;
+        const uint32_t x2 = a2 ^ qv.z;
+        const uint32_t x3 = a3 ^ qv.w;
         // equal leading bytes 0..16, branch-free: ffs(0) - 1 = 0xffffffff -> min(.., 4) = 4
         const uint32_t c0 = min(((uint32_t)__ffs((int)x0) - 1u) >> 3, 4u);
         const uint32_t c1 = min(((uint32_t)__ffs((int)x1) - 1u) >> 3, 4u);
