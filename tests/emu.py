@@ -17,6 +17,10 @@ def engine():
         # few table slots, so that the matcher's persistent waves take several fragments each (their
         # tables are reused without clearing) in batches the emulator can afford
         os.environ.setdefault("ZH_L1_SLOTS", "64")
+        # small staging chunks and several host threads: the host-buffer calls of every test cross
+        # chunk and thread borders inside buffers
+        os.environ.setdefault("ZH_PIN_CHUNK", "131072")
+        os.environ.setdefault("ZH_HOST_THREADS", "3")
         _engine = Engine(build_emu.build())
         _engine.set_gzip_fname_len(0)
     return _engine

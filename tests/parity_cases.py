@@ -359,3 +359,32 @@ def check_tar_errors(eng):
                     fn(bad)
     with pytest.raises(either):
         eng.open_tar(b"\x1f\x8b" + b"\0" * 30)
+
+
+def check_ragged_staging(eng, scale):
+    """Host-buffer calls whose buffers straddle the staging chunks (upload) and whose results
+    straddle them again (download): ragged sizes, empty buffers in between, one buffer of
+    several chunks.  `scale` stretches the sizes (1 for the emulator's 128 KiB chunks)."""
+    from zippy_amd import synth
+    sizes = [0, 70001, 1, 262144 + 13, 0, 0, 4095, 400000 + 7, 65536, 131072, 3, 0, 99999, 0]
+    pool = synth.gen_batch("mix", 8, 1 << 20).tobytes()
+    bufs, at = [], 0
+    for k, sz in enumerate(sizes):
+        sz *= scale
+        rep = -(-(sz + 1) // len(pool))
+        bufs.append((pool * rep)[at % 4096:at % 4096 + sz])
+        at += 977
+    for level, fmt in ((1, oracle.dfGzip), (0, oracle.dfZlib), (-2, oracle.dfDeflate)):
+        outs, sts = eng.compress_batch(bufs, level, fmt)
+        assert all(s == 0 for s in sts), sts
+        for i in (1, 3, 7, 12) if scale > 1 else range(len(bufs)):
+            assert outs[i] == oracle.compress(bufs[i], level, fmt, fname_len=0), (level, i)
+        back, sts = eng.uncompress_batch(outs, fmt)
+        assert all(s == 0 for s in sts), sts
+        assert back == bufs, level
+        if fmt == oracle.dfGzip:  # a damaged member in the middle only fails its own slot
+            bad = list(outs)
+            bad[7] = bad[7][:len(bad[7]) // 2] + bytes([bad[7][len(bad[7]) // 2] ^ 0x55]) + bad[7][len(bad[7]) // 2 + 1:]
+            back, sts = eng.uncompress_batch(bad, fmt)
+            assert sts[7] != 0 and back[7] is None
+            assert [b for i, b in enumerate(back) if i != 7] == [b for i, b in enumerate(bufs) if i != 7]

@@ -110,3 +110,7 @@ def test_emu_level1_many_fragments(eng):
     assert all(s == 0 for s in sts)
     for src, out in zip(bufs, outs):
         assert out == oracle.deflate(src, 1)
+
+
+def test_emu_ragged_staging(eng):
+    pc.check_ragged_staging(eng, 1)

@@ -103,6 +103,12 @@ def test_gpu_level1_identical_at_scale(eng):
     assert all(s == 0 for s in sts) and back == bufs
 
 
+def test_gpu_host_api_ragged_staging(eng):
+    """~135 MiB through the host-buffer API in 32 MiB staging chunks: buffers and results that
+    straddle chunk and thread borders, empty buffers, a damaged member."""
+    pc.check_ragged_staging(eng, 128)
+
+
 def test_gpu_config4_default_compression_ratio(eng):
     """BASELINE.json configs[3] at test size: DefaultCompression, identical to the oracle."""
     bufs = [b.tobytes() for b in synth.gen_batch("mix", 12, 1 << 20)]

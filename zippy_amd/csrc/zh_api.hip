@@ -7,7 +7,9 @@
 #include <cstring>
 #include <random>
 #include <chrono>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "zh_common.h"
@@ -57,6 +59,11 @@ struct zh_ctx {
   std::string last_error;
   const void* cktabs = nullptr;
   std::mt19937 rng{std::random_device{}()};
+  // host-buffer calls: two pinned staging chunks between the caller's pageable memory and HBM
+  // (allocated on the first such call)
+  uint8_t* pin[2] = {nullptr, nullptr};
+  hipEvent_t pin_ev[2] = {nullptr, nullptr};
+  bool pin_busy[2] = {false, false};
 };
 
 #define ZH_HIP(ctx, call)                                                            \
@@ -143,6 +150,10 @@ extern "C" int zh_create(int device, void* stream, zh_ctx** out) {
 
 extern "C" void zh_destroy(zh_ctx* ctx) {
   if (!ctx) return;
+  for (int k = 0; k < 2; k++) {
+    if (ctx->pin_ev[k]) (void)hipEventDestroy(ctx->pin_ev[k]);
+    if (ctx->pin[k]) (void)hipHostFree(ctx->pin[k]);
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -767,6 +778,84 @@ struct Trace {
   }
 };
 
+// ---- staging between pageable host memory and HBM ----
+// The caller's buffers are pageable and the results are fresh `malloc`s: a plain hipMemcpy of
+// either runs at a fraction of the link (a bounce copy inside the runtime, one page fault per
+// 4 KiB of a fresh result).  Instead the batch moves in chunks through two pinned buffers: host
+// threads gather/scatter one chunk while the DMA engine moves the other.
+// bytes per staging chunk (ZH_PIN_CHUNK: test override, so that small cases cross chunk borders)
+size_t pin_chunk() {
+  static const size_t c = [] {
+    const char* e = getenv("ZH_PIN_CHUNK");
+    const long long v = e ? atoll(e) : 0;
+    return v >= 65536 && v <= ((long long)1 << 30) ? (size_t)v & ~(size_t)4095 : (size_t)32 << 20;
+  }();
+  return c;
+}
+
+unsigned host_threads() {
+  static const unsigned t = [] {
+    const char* e = getenv("ZH_HOST_THREADS");
+    const long v = e ? atol(e) : 0;
+    if (v >= 1 && v <= 64) return (unsigned)v;
+    const unsigned hc = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(8u, hc / 2u));
+  }();
+  return t;
+}
+
+// f(t) on `nt` threads (the caller's included), all joined on return
+template <class F>
+void on_threads(unsigned nt, F&& f) {
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; t++) th.emplace_back([&f, t] { f(t); });
+  f(0u);
+  for (auto& x : th) x.join();
+}
+
+int pin_init(zh_ctx* ctx) {
+  for (int k = 0; k < 2; k++) {
+    if (!ctx->pin[k]) ZH_HIP(ctx, hipHostMalloc(&ctx->pin[k], pin_chunk(), 0));
+    if (!ctx->pin_ev[k]) ZH_HIP(ctx, hipEventCreate(&ctx->pin_ev[k]));
+  }
+  return ZH_OK;
+}
+// the DMA that last used staging chunk k has finished
+int pin_wait(zh_ctx* ctx, int k) {
+  if (ctx->pin_busy[k]) {
+    ctx->pin_busy[k] = false;
+    ZH_HIP(ctx, hipEventSynchronize(ctx->pin_ev[k]));
+  }
+  return ZH_OK;
+}
+
+// A batch laid out in one linear range: buffer i occupies [off[i], off[i] + len[i]) of it.
+// Copies range [lo, hi) between that layout and a staging chunk that holds it from `lo`:
+// to_stage: host buffers -> staging, else staging -> host buffers.
+void stage_range(uint8_t* stage, uint64_t lo, uint64_t hi, const std::vector<uint64_t>& off,
+                 const std::vector<uint64_t>& len, void* const* host, bool to_stage) {
+  size_t i = (size_t)(std::upper_bound(off.begin(), off.end(), lo) - off.begin());
+  if (i) i--;
+  for (; i < off.size() && off[i] < hi; i++) {
+    const uint64_t b = std::max(off[i], lo), e = std::min(off[i] + len[i], hi);
+    if (b >= e || !host[i]) continue;
+    uint8_t* h = (uint8_t*)host[i] + (b - off[i]);
+    if (to_stage)
+      memcpy(stage + (b - lo), h, e - b);
+    else
+      memcpy(h, stage + (b - lo), e - b);
+  }
+}
+void stage_chunk(uint8_t* stage, uint64_t lo, uint64_t hi, const std::vector<uint64_t>& off,
+                 const std::vector<uint64_t>& len, void* const* host, bool to_stage) {
+  const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(host_threads(), (hi - lo) >> 16));
+  const uint64_t per = ((hi - lo + nt - 1) / nt + 4095) & ~(uint64_t)4095;
+  on_threads(nt, [&](unsigned t) {
+    const uint64_t a = lo + per * t, b = std::min(hi, a + per);
+    if (a < b) stage_range(stage + (a - lo), a, b, off, len, host, to_stage);
+  });
+}
+
 // Pack host buffers into one device allocation (256-byte aligned slices).
 int upload(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n, DevBuf& dev,
            std::vector<uint64_t>& off, std::vector<uint64_t>& len64) {
@@ -778,10 +867,98 @@ int upload(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n, D
     len64[i] = lens[i];
     total += (lens[i] + 255) & ~(uint64_t)255;
   }
-  total += 256;
-  if (hipMalloc(&dev.p, total) != hipSuccess) return ZH_ERR_NOMEM;
-  for (size_t i = 0; i < n; i++)
-    if (lens[i]) ZH_HIP(ctx, hipMemcpyAsync(dev.p + off[i], srcs[i], lens[i], hipMemcpyHostToDevice, ctx->stream));
+  if (hipMalloc(&dev.p, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
+  int st = pin_init(ctx);
+  if (st) return st;
+  int k = 0;
+  for (uint64_t lo = 0; lo < total; lo += pin_chunk(), k ^= 1) {
+    const uint64_t hi = std::min<uint64_t>(total, lo + pin_chunk());
+    if ((st = pin_wait(ctx, k))) return st;
+    stage_chunk(ctx->pin[k], lo, hi, off, len64, (void* const*)srcs, true);
+    ZH_HIP(ctx, hipMemcpyAsync(dev.p + lo, ctx->pin[k], hi - lo, hipMemcpyHostToDevice, ctx->stream));
+    ZH_HIP(ctx, hipEventRecord(ctx->pin_ev[k], ctx->stream));
+    ctx->pin_busy[k] = true;
+  }
+  return ZH_OK;
+}
+
+struct PackPiece {
+  uint64_t src, dst;
+  uint32_t len, pad;
+};
+struct alignas(16) Vec16 {
+  uint32_t a, b, c, d;
+};
+}  // namespace
+
+// results gathered from their (sparse) output slots into one dense range, 16 bytes at a time
+__global__ __launch_bounds__(256) void zh_pack_kernel(const uint8_t* __restrict__ src,
+                                                      uint8_t* __restrict__ dst,
+                                                      const PackPiece* __restrict__ pieces) {
+  const PackPiece p = pieces[blockIdx.x];
+  const Vec16* s = reinterpret_cast<const Vec16*>(src + p.src);
+  Vec16* d = reinterpret_cast<Vec16*>(dst + p.dst);
+  const uint32_t nv = p.len >> 4;
+  for (uint32_t i = threadIdx.x; i < nv; i += 256) d[i] = s[i];
+  for (uint32_t i = (nv << 4) + threadIdx.x; i < p.len; i += 256) dst[p.dst + i] = src[p.src + i];
+}
+
+namespace {
+// Results of the buffers with status ZH_OK: `malloc`ed and filled from their device slots
+// d_dst + doff[i] (olen[i] bytes each).
+int download(zh_ctx* ctx, const uint8_t* d_dst, size_t n, const std::vector<uint64_t>& doff,
+             const std::vector<uint64_t>& olen, const std::vector<char>& take, void** dsts,
+             size_t* dst_lens, int32_t* statuses) {
+  constexpr uint32_t kPiece = 1u << 18;
+  std::vector<uint64_t> poff(n), plen(n);
+  std::vector<PackPiece> pieces;
+  uint64_t total = 0;
+  for (size_t i = 0; i < n; i++) {
+    poff[i] = total;
+    plen[i] = take[i] ? olen[i] : 0;
+    for (uint64_t o = 0; o < plen[i]; o += kPiece)
+      pieces.push_back({doff[i] + o, total + o, (uint32_t)std::min<uint64_t>(kPiece, plen[i] - o), 0});
+    total += (plen[i] + 15) & ~(uint64_t)15;
+  }
+  for (size_t i = 0; i < n; i++) {
+    if (!take[i]) continue;
+    dsts[i] = malloc(olen[i] ? olen[i] : 1);
+    if (!dsts[i]) {
+      statuses[i] = ZH_ERR_NOMEM;
+      continue;
+    }
+    dst_lens[i] = olen[i];
+  }
+  if (!total) return ZH_OK;
+  DevBuf d_pack, d_pieces;
+  if (hipMalloc(&d_pack.p, total) != hipSuccess) return ZH_ERR_NOMEM;
+  if (hipMalloc(&d_pieces.p, pieces.size() * sizeof(PackPiece)) != hipSuccess) return ZH_ERR_NOMEM;
+  ZH_HIP(ctx, hipMemcpyAsync(d_pieces.p, pieces.data(), pieces.size() * sizeof(PackPiece),
+                             hipMemcpyHostToDevice, ctx->stream));
+  uint8_t* const pack = d_pack.p;
+  const PackPiece* const dev_pieces = reinterpret_cast<const PackPiece*>(d_pieces.p);
+  hipLaunchKernelGGL(zh_pack_kernel, dim3((uint32_t)pieces.size()), dim3(256), 0, ctx->stream, d_dst,
+                     pack, dev_pieces);
+  int st = pin_init(ctx);
+  if (st) return st;
+  // chunk c+1 is on the wire while the host threads scatter chunk c
+  const uint64_t nchunks = (total + pin_chunk() - 1) / pin_chunk();
+  auto fetch = [&](uint64_t c) -> int {
+    const int k = (int)(c & 1);
+    const uint64_t lo = c * pin_chunk(), hi = std::min<uint64_t>(total, lo + pin_chunk());
+    ZH_HIP(ctx, hipMemcpyAsync(ctx->pin[k], d_pack.p + lo, hi - lo, hipMemcpyDeviceToHost, ctx->stream));
+    ZH_HIP(ctx, hipEventRecord(ctx->pin_ev[k], ctx->stream));
+    ctx->pin_busy[k] = true;
+    return ZH_OK;
+  };
+  if ((st = pin_wait(ctx, 0)) || (st = pin_wait(ctx, 1)) || (st = fetch(0))) return st;
+  for (uint64_t c = 0; c < nchunks; c++) {
+    if (c + 1 < nchunks && (st = fetch(c + 1))) return st;
+    const int k = (int)(c & 1);
+    if ((st = pin_wait(ctx, k))) return st;
+    const uint64_t lo = c * pin_chunk(), hi = std::min<uint64_t>(total, lo + pin_chunk());
+    stage_chunk(ctx->pin[k], lo, hi, poff, plen, dsts, false);
+  }
   return ZH_OK;
 }
 }  // namespace
@@ -840,18 +1017,12 @@ static int compress_batch_impl(zh_ctx* ctx, const void* const* srcs, const size_
     for (size_t i = 0; i < n; i++)
       if (ost[i] == ZH_ERR_DST_TOO_SMALL) retry = true;
     if (retry && attempt == 0) continue;
+    std::vector<char> take(n);
     for (size_t i = 0; i < n; i++) {
       statuses[i] = ost[i];
-      if (ost[i] != ZH_OK) continue;
-      dsts[i] = malloc(olen[i] ? olen[i] : 1);
-      if (!dsts[i]) {
-        statuses[i] = ZH_ERR_NOMEM;
-        continue;
-      }
-      dst_lens[i] = olen[i];
-      ZH_HIP(ctx, hipMemcpyAsync(dsts[i], d_dst.p + doff[i], olen[i], hipMemcpyDeviceToHost, ctx->stream));
+      take[i] = ost[i] == ZH_OK;
     }
-    ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((st = download(ctx, d_dst.p, n, doff, olen, take, dsts, dst_lens, statuses))) return st;
     tr.mark(ctx, "compress: download");
     break;
   }
@@ -960,6 +1131,7 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
       continue;
     }
     bool again = false;
+    std::vector<char> take(n, 0);
     for (size_t i = 0; i < n; i++) {
       if (dsts[i] || (pass == 2 && statuses[i] != ZH_ERR_DST_TOO_SMALL)) continue;
       statuses[i] = ost[i];
@@ -971,16 +1143,10 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
         continue;
       }
       if (ost[i] != ZH_OK) continue;
-      dsts[i] = malloc(olen[i] ? olen[i] : 1);
-      if (!dsts[i]) {
-        statuses[i] = ZH_ERR_NOMEM;
-        continue;
-      }
-      dst_lens[i] = olen[i];
+      take[i] = 1;
       if (crcs) crcs[i] = ocrc[i];
-      if (olen[i]) ZH_HIP(ctx, hipMemcpyAsync(dsts[i], d_dst.p + doff[i], olen[i], hipMemcpyDeviceToHost, ctx->stream));
     }
-    ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((st = download(ctx, d_dst.p, n, doff, olen, take, dsts, dst_lens, statuses))) return st;
     tr.mark(ctx, "uncompress: download");
     if (!again) break;
     for (size_t i = 0; i < n; i++)
