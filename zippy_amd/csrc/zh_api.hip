@@ -1226,16 +1226,17 @@ extern "C" int zh_compress_blocks(zh_ctx* ctx, const void* src, size_t len, int 
     if (ost != ZH_OK) return ost;
     st = zh_plan_block_index(pg.p, 0, index, n_entries);
     if (st) return st;
-    *dst = malloc(olen ? olen : 1);
-    if (!*dst) {
+    int32_t dst_st = ZH_OK;
+    st = download(ctx, d_dst.p, 1, {doff}, {olen}, {1}, dst, dst_len, &dst_st);
+    if (st || dst_st) {
       free(*index);
+      free(*dst);
       *index = nullptr;
+      *dst = nullptr;
       *n_entries = 0;
-      return ZH_ERR_NOMEM;
+      *dst_len = 0;
+      return st ? st : dst_st;
     }
-    *dst_len = olen;
-    ZH_HIP(ctx, hipMemcpyAsync(*dst, d_dst.p, olen, hipMemcpyDeviceToHost, ctx->stream));
-    ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZH_OK;
   }
   return ZH_ERR_DST_TOO_SMALL;
@@ -1269,11 +1270,14 @@ extern "C" int zh_uncompress_indexed(zh_ctx* ctx, const void* src, size_t len, i
   st = zh_plan_results(pg.p, &olen, &ost);
   if (st) return st;
   if (ost != ZH_OK) return ost;
-  *dst = malloc(olen ? olen : 1);
-  if (!*dst) return ZH_ERR_NOMEM;
-  *dst_len = olen;
-  if (olen) ZH_HIP(ctx, hipMemcpyAsync(*dst, d_dst.p, olen, hipMemcpyDeviceToHost, ctx->stream));
-  ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int32_t dst_st = ZH_OK;
+  st = download(ctx, d_dst.p, 1, {0}, {olen}, {1}, dst, dst_len, &dst_st);
+  if (st || dst_st) {
+    free(*dst);
+    *dst = nullptr;
+    *dst_len = 0;
+    return st ? st : dst_st;
+  }
   return ZH_OK;
 }
 
