@@ -17,12 +17,13 @@
 //   * computes every fragment's encoded bit length as a dot product of its
 //     histogram with the code lengths (all 64 lanes).
 //
-// zh_layout_kernel (one wave per buffer) turns bit lengths into absolute bit
-// positions (the job of BitStreamWriter.pos/bitPos, bitstreams.nim:84-123),
-// and writes everything that is not fragment payload: container header
-// (zippy.nim:22-42,61-69), block headers, end-of-block codes, stored-block
-// headers (deflate.nim:179-205), final padding and the trailer
-// (zippy.nim:47-58,71-78).  All of it is OR-ed into a zeroed output.
+// zh_layout_kernel (one wave per buffer) turns block bit lengths into absolute bit
+// positions (the job of BitStreamWriter.pos/bitPos, bitstreams.nim:84-123) and writes the
+// container header (zippy.nim:22-42,61-69), the final padding and the trailer
+// (zippy.nim:47-58,71-78); zh_block_layout_kernel (one wave per block) follows with the
+// block header, the bit position of each fragment, the end-of-block code and, for stored
+// blocks, the chunk headers (deflate.nim:179-205).  Everything that is not fragment payload
+// comes from these two; all of it is OR-ed into a zeroed output.
 #include "zh_common.h"
 #include "zh_tables.h"
 #include "zh_kprof.h"

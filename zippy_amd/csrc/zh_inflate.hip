@@ -1,22 +1,21 @@
-// Batched inflate: container unwrap + RFC 1951 decode, one 64-lane wave per
-// stream (a foreign deflate stream has no block index, so the only parallelism
-// across a stream is lane-level; throughput comes from thousands of streams).
+// Batched inflate: container unwrap + RFC 1951 decode, one workgroup of two 64-lane waves
+// per stream (a foreign deflate stream has no block index, so the only parallelism across a
+// stream is lane-level; throughput comes from thousands of streams -- or, for streams this
+// library wrote with a block index, from zh_plan_uncompress_indexed, which makes every block
+// a "stream" of this kernel).
 //
 // Replaces src/zippy.nim:100-165 (format detect / zlib header), gzip.nim:3-88
 // (gzip header + trailer), inflate.nim:24-291 (Huffman tables, decode loop,
 // stored blocks) and the BitStreamReader of bitstreams.nim:22-82.
 //
-// Per wave, in LDS (22 KiB, 7 waves per CU -- a wave alone on its SIMD issues one
-// instruction per ~4.4 cycles, so resident waves are what buys throughput): the last
-// 16 KiB of output as a ring (LZ copies that reach further back, a few percent, re-read
-// the already written-back output through L2), a 10-bit literal/length LUT and an 8-bit distance
-// LUT of self-describing 32-bit entries (inflate.nim's 9-bit `fast` table,
-// re-shaped), and the canonical slow-path arrays (firstCode / firstSymbol /
-// maxCodes / values, inflate.nim:14-19).  The compressed stream is held 512
-// bytes at a time in two VGPRs per lane and fed to a wave-uniform 64-bit bit
-// buffer with v_readlane, so the per-symbol chain is one LDS lookup.  The decode
-// state lives in scalar registers; the 64 lanes cooperate on LZ copies, stored
-// block copies, table construction and the coalesced write-back of the window.
+// Per workgroup, in LDS (9.3 KiB, 16 workgroups = 32 waves per CU -- a wave alone on its SIMD
+// issues one instruction per ~4.4 cycles, so resident waves are what buys throughput): a 10-bit
+// literal/length root LUT with second-level tables behind it for longer codes and an 8-bit
+// distance LUT, all of self-describing 32-bit entries (inflate.nim's 9-bit `fast` table,
+// re-shaped), the canonical slow-path arrays (firstCode / firstSymbol / maxCodes / values,
+// inflate.nim:14-19), a 512-byte staging ring of the compressed stream and two round
+// descriptors.  There is no window copy: the LZ window is the output itself, read back through
+// L2.  The decode wave and the output wave are described above zh_inflate_kernel.
 // Algorithmic traffic: compressed bytes read once, output written once.
 #include "zh_common.h"
 #include "zh_kprof.h"
@@ -269,8 +268,8 @@ __device__ int build_table(const uint8_t* lens, uint32_t n, uint32_t* lut, uint3
 //   (two LDS lookups, inflate.nim:93-100 / 199-222 for all offsets at once).  A wave-uniform
 //   walk then follows the real chain of token starts through those lanes (seven instructions
 //   per symbol), DPP prefix sums of the chain's output lengths place every token, and the
-//   round goes into one of two descriptor buffers in LDS.  Anything the 10-/7-bit LUTs cannot
-//   finish (longer codes, end of block, invalid symbols) stops the chain and is decoded alone
+//   round goes into one of two descriptor buffers in LDS.  Anything the LUTs cannot finish in
+//   the lane (codes past the tables' reach, end of block, invalid symbols) stops the chain and is decoded alone
 //   with the canonical slow path (inflate.nim:67-91) as the round's "tail".  Block headers,
 //   table construction and stored blocks happen here too.
 // OUTPUT wave: owns the output.  Rounds of <= 64 bytes (the usual case) get one lane per
