@@ -808,8 +808,16 @@ unsigned host_threads() {
 template <class F>
 void on_threads(unsigned nt, F&& f) {
   std::vector<std::thread> th;
-  for (unsigned t = 1; t < nt; t++) th.emplace_back([&f, t] { f(t); });
+  unsigned started = 1;
+  for (; started < nt; started++) {
+    try {
+      th.emplace_back([&f, t = started] { f(t); });
+    } catch (...) {  // no more threads to be had: the remaining shares run on this one
+      break;
+    }
+  }
   f(0u);
+  for (unsigned t = started; t < nt; t++) f(t);
   for (auto& x : th) x.join();
 }
 
