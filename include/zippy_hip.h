@@ -94,6 +94,12 @@ void *zh_stream(zh_ctx *ctx);           /* the hipStream_t work is enqueued on *
  * reference; 0..25: fixed (deterministic output for tests). */
 void zh_set_gzip_fname_len(zh_ctx *ctx, int k);
 
+/* Host-buffer compress calls of at least min_batch_bytes of input run as pipelined groups of
+ * about group_bytes each: one group's kernels overlap the neighbours' transfers (no reference
+ * counterpart; the results are the same bytes either way).  0 = default (3 GiB / 1 GiB, or the
+ * ZH_PIPE_MIN / ZH_PIPE_GROUP environment variables). */
+void zh_set_host_pipeline(zh_ctx *ctx, size_t min_batch_bytes, size_t group_bytes);
+
 /* Upper bound of compress() output for len input bytes: stored form
  * len + 5*ceil(len/65535) (deflate.nim:179-205) + container + slack. */
 size_t zh_compress_bound(size_t len, int data_format);

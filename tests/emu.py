@@ -21,6 +21,9 @@ def engine():
         # chunk and thread borders inside buffers
         os.environ.setdefault("ZH_PIN_CHUNK", "131072")
         os.environ.setdefault("ZH_HOST_THREADS", "3")
+        # and batches of more than one group's worth of input run as pipelined groups
+        os.environ.setdefault("ZH_PIPE_MIN", "1")
+        os.environ.setdefault("ZH_PIPE_GROUP", "150000")
         _engine = Engine(build_emu.build())
         _engine.set_gzip_fname_len(0)
     return _engine

@@ -375,8 +375,16 @@ def check_ragged_staging(eng, scale):
         bufs.append((pool * rep)[at % 4096:at % 4096 + sz])
         at += 977
     for level, fmt in ((1, oracle.dfGzip), (0, oracle.dfZlib), (-2, oracle.dfDeflate)):
-        outs, sts = eng.compress_batch(bufs, level, fmt)
+        # one plan for the whole batch, then the same batch as pipelined groups: identical results
+        try:
+            eng.set_host_pipeline(1 << 60, 0)
+            outs, sts = eng.compress_batch(bufs, level, fmt)
+            eng.set_host_pipeline(1, 150000 * scale)
+            outs2, sts2 = eng.compress_batch(bufs, level, fmt)
+        finally:
+            eng.set_host_pipeline(0, 0)
         assert all(s == 0 for s in sts), sts
+        assert sts2 == sts and outs2 == outs, level
         for i in (1, 3, 7, 12) if scale > 1 else range(len(bufs)):
             assert outs[i] == oracle.compress(bufs[i], level, fmt, fname_len=0), (level, i)
         back, sts = eng.uncompress_batch(outs, fmt)

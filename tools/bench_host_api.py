@@ -38,11 +38,15 @@ def main():
         assert all(s == 0 for s in sts)
     assert back == bufs
     cc, cu = c_abi_times(api.engine(), bufs, outs, args.reps)
+    c_plain = c_abi_compress_time(api.engine(), bufs, args.reps, False)
+    c_pipe = c_abi_compress_time(api.engine(), bufs, args.reps, True)
     print(json.dumps({
         "workload": "%d x %d B host buffers through zh_compress_batch / zh_uncompress_batch (level 1, gzip)" %
                     (args.buffers, args.size),
         "c_abi": {"compress_GiBps": round(total / cc, 3), "uncompress_GiBps": round(total / cu, 3),
                   "both_GiBps": round(total / (cc + cu), 3),
+                  "compress_one_plan_GiBps": round(total / c_plain, 3),
+                  "compress_pipelined_groups_GiBps": round(total / c_pipe, 3),
                   "note": "the C call alone: pageable host buffers in, malloc'ed results out"},
         "python_mirror": {"compress_GiBps": round(total / tc, 3), "uncompress_GiBps": round(total / tu, 3),
                           "both_GiBps": round(total / (tc + tu), 3),
@@ -70,6 +74,28 @@ def c_abi_times(eng, bufs, blobs, reps):
     cc = min(call(eng.lib.zh_compress_batch, bufs, 1, 2) for _ in range(reps))
     cu = min(call(eng.lib.zh_uncompress_batch, blobs, 0) for _ in range(reps))
     return cc, cu
+
+
+def c_abi_compress_time(eng, bufs, reps, pipelined):
+    """zh_compress_batch with the pipelined-groups rule forced on or off."""
+    import ctypes as c
+    n = len(bufs)
+    srcs = (c.c_void_p * n)(*[c.cast(c.c_char_p(k), c.c_void_p) for k in bufs])
+    lens = (c.c_size_t * n)(*[len(k) for k in bufs])
+    best = 1e9
+    eng.set_host_pipeline(1 if pipelined else 1 << 60, 0)
+    try:
+        for _ in range(reps):
+            dsts, dlens, sts = (c.c_void_p * n)(), (c.c_size_t * n)(), (c.c_int32 * n)()
+            t = time.perf_counter()
+            rc = eng.lib.zh_compress_batch(eng._h, srcs, lens, n, 1, 2, dsts, dlens, sts)
+            best = min(best, time.perf_counter() - t)
+            assert rc == 0 and not any(sts)
+            for i in range(n):
+                eng.lib.zh_free(dsts[i])
+    finally:
+        eng.set_host_pipeline(0, 0)
+    return best
 
 
 if __name__ == "__main__":

@@ -18,6 +18,7 @@ _SIGS = {
     "zh_last_error": (_c.c_char_p, [_c.c_void_p]),
     "zh_stream": (_c.c_void_p, [_c.c_void_p]),
     "zh_set_gzip_fname_len": (None, [_c.c_void_p, _c.c_int]),
+    "zh_set_host_pipeline": (None, [_c.c_void_p, _c.c_size_t, _c.c_size_t]),
     "zh_compress_bound": (_c.c_size_t, [_c.c_size_t, _c.c_int]),
     "zh_compress_batch": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
                                      _c.c_size_t, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p),
@@ -306,6 +307,9 @@ class Engine:
 
     def set_gzip_fname_len(self, k):
         self.lib.zh_set_gzip_fname_len(self._h, k)
+
+    def set_host_pipeline(self, min_batch_bytes=0, group_bytes=0):
+        self.lib.zh_set_host_pipeline(self._h, min_batch_bytes, group_bytes)
 
     def compress_bound(self, n, data_format=dfGzip):
         return self.lib.zh_compress_bound(n, data_format)

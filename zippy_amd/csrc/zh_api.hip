@@ -64,6 +64,8 @@ struct zh_ctx {
   uint8_t* pin[2] = {nullptr, nullptr};
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   bool pin_busy[2] = {false, false};
+  hipStream_t copy_stream = nullptr;  // transfers of a pipelined batch, next to `stream`'s kernels
+  uint64_t pipe_min = 0, pipe_group = 0;  // zh_set_host_pipeline (0: ZH_PIPE_MIN / ZH_PIPE_GROUP / default)
 };
 
 #define ZH_HIP(ctx, call)                                                            \
@@ -154,6 +156,7 @@ extern "C" void zh_destroy(zh_ctx* ctx) {
     if (ctx->pin_ev[k]) (void)hipEventDestroy(ctx->pin_ev[k]);
     if (ctx->pin[k]) (void)hipHostFree(ctx->pin[k]);
   }
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -163,6 +166,11 @@ extern "C" void zh_set_gzip_fname_len(zh_ctx* ctx, int k) {
   if (ctx) ctx->fname_len = k > 25 ? 25 : k;
 }
 extern "C" void zh_free(void* p) { free(p); }
+extern "C" void zh_set_host_pipeline(zh_ctx* ctx, size_t min_batch_bytes, size_t group_bytes) {
+  if (!ctx) return;
+  ctx->pipe_min = min_batch_bytes;
+  ctx->pipe_group = group_bytes;
+}
 
 static size_t container_overhead(int fmt) {
   return fmt == ZH_DF_GZIP ? 10 + 26 + 8 : fmt == ZH_DF_ZLIB ? 6 : 0;
@@ -864,9 +872,9 @@ void stage_chunk(uint8_t* stage, uint64_t lo, uint64_t hi, const std::vector<uin
   });
 }
 
-// Pack host buffers into one device allocation (256-byte aligned slices).
-int upload(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n, DevBuf& dev,
-           std::vector<uint64_t>& off, std::vector<uint64_t>& len64) {
+// 256-byte aligned slices of one linear range; returns its size
+uint64_t layout_slices(const size_t* lens, size_t n, std::vector<uint64_t>& off,
+                       std::vector<uint64_t>& len64) {
   off.resize(n);
   len64.resize(n);
   uint64_t total = 0;
@@ -875,7 +883,12 @@ int upload(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n, D
     len64[i] = lens[i];
     total += (lens[i] + 255) & ~(uint64_t)255;
   }
-  if (hipMalloc(&dev.p, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
+  return total;
+}
+// host buffers -> dev[0, total) in that layout, chunk by chunk on `stream`
+int upload_slices(zh_ctx* ctx, hipStream_t stream, const void* const* srcs,
+                  const std::vector<uint64_t>& off, const std::vector<uint64_t>& len64,
+                  uint64_t total, uint8_t* dev) {
   int st = pin_init(ctx);
   if (st) return st;
   int k = 0;
@@ -883,11 +896,18 @@ int upload(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n, D
     const uint64_t hi = std::min<uint64_t>(total, lo + pin_chunk());
     if ((st = pin_wait(ctx, k))) return st;
     stage_chunk(ctx->pin[k], lo, hi, off, len64, (void* const*)srcs, true);
-    ZH_HIP(ctx, hipMemcpyAsync(dev.p + lo, ctx->pin[k], hi - lo, hipMemcpyHostToDevice, ctx->stream));
-    ZH_HIP(ctx, hipEventRecord(ctx->pin_ev[k], ctx->stream));
+    ZH_HIP(ctx, hipMemcpyAsync(dev + lo, ctx->pin[k], hi - lo, hipMemcpyHostToDevice, stream));
+    ZH_HIP(ctx, hipEventRecord(ctx->pin_ev[k], stream));
     ctx->pin_busy[k] = true;
   }
   return ZH_OK;
+}
+// Pack host buffers into one device allocation.
+int upload(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n, DevBuf& dev,
+           std::vector<uint64_t>& off, std::vector<uint64_t>& len64) {
+  const uint64_t total = layout_slices(lens, n, off, len64);
+  if (hipMalloc(&dev.p, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
+  return upload_slices(ctx, ctx->stream, srcs, off, len64, total, dev.p);
 }
 
 struct PackPiece {
@@ -913,21 +933,32 @@ __global__ __launch_bounds__(256) void zh_pack_kernel(const uint8_t* __restrict_
 
 namespace {
 // Results of the buffers with status ZH_OK: `malloc`ed and filled from their device slots
-// d_dst + doff[i] (olen[i] bytes each).
-int download(zh_ctx* ctx, const uint8_t* d_dst, size_t n, const std::vector<uint64_t>& doff,
-             const std::vector<uint64_t>& olen, const std::vector<char>& take, void** dsts,
-             size_t* dst_lens, int32_t* statuses) {
+// d_dst + doff[i] (olen[i] bytes each), in two steps.
+struct Download {
+  std::vector<uint64_t> poff, plen;  // the dense layout the results are packed into
+  uint64_t total = 0;
+  DevBuf own_pack, d_pieces;
+  uint8_t* pack = nullptr;
+};
+// step 1, on `stream`: allocate the results and pack them densely on the device (into `pack`,
+// at least as large as the output slots together, or into a buffer of the Download's own)
+int download_pack(zh_ctx* ctx, hipStream_t stream, Download& dl, const uint8_t* d_dst, size_t n,
+                  const std::vector<uint64_t>& doff, const std::vector<uint64_t>& olen,
+                  const std::vector<char>& take, uint8_t* pack, void** dsts, size_t* dst_lens,
+                  int32_t* statuses) {
   constexpr uint32_t kPiece = 1u << 18;
-  std::vector<uint64_t> poff(n), plen(n);
+  dl.poff.assign(n, 0);
+  dl.plen.assign(n, 0);
   std::vector<PackPiece> pieces;
   uint64_t total = 0;
   for (size_t i = 0; i < n; i++) {
-    poff[i] = total;
-    plen[i] = take[i] ? olen[i] : 0;
-    for (uint64_t o = 0; o < plen[i]; o += kPiece)
-      pieces.push_back({doff[i] + o, total + o, (uint32_t)std::min<uint64_t>(kPiece, plen[i] - o), 0});
-    total += (plen[i] + 15) & ~(uint64_t)15;
+    dl.poff[i] = total;
+    dl.plen[i] = take[i] ? olen[i] : 0;
+    for (uint64_t o = 0; o < dl.plen[i]; o += kPiece)
+      pieces.push_back({doff[i] + o, total + o, (uint32_t)std::min<uint64_t>(kPiece, dl.plen[i] - o), 0});
+    total += (dl.plen[i] + 15) & ~(uint64_t)15;
   }
+  dl.total = total;
   for (size_t i = 0; i < n; i++) {
     if (!take[i]) continue;
     dsts[i] = malloc(olen[i] ? olen[i] : 1);
@@ -938,24 +969,31 @@ int download(zh_ctx* ctx, const uint8_t* d_dst, size_t n, const std::vector<uint
     dst_lens[i] = olen[i];
   }
   if (!total) return ZH_OK;
-  DevBuf d_pack, d_pieces;
-  if (hipMalloc(&d_pack.p, total) != hipSuccess) return ZH_ERR_NOMEM;
-  if (hipMalloc(&d_pieces.p, pieces.size() * sizeof(PackPiece)) != hipSuccess) return ZH_ERR_NOMEM;
-  ZH_HIP(ctx, hipMemcpyAsync(d_pieces.p, pieces.data(), pieces.size() * sizeof(PackPiece),
-                             hipMemcpyHostToDevice, ctx->stream));
-  uint8_t* const pack = d_pack.p;
-  const PackPiece* const dev_pieces = reinterpret_cast<const PackPiece*>(d_pieces.p);
-  hipLaunchKernelGGL(zh_pack_kernel, dim3((uint32_t)pieces.size()), dim3(256), 0, ctx->stream, d_dst,
-                     pack, dev_pieces);
+  if (!pack) {
+    if (hipMalloc(&dl.own_pack.p, total) != hipSuccess) return ZH_ERR_NOMEM;
+    pack = dl.own_pack.p;
+  }
+  dl.pack = pack;
+  if (hipMalloc(&dl.d_pieces.p, pieces.size() * sizeof(PackPiece)) != hipSuccess) return ZH_ERR_NOMEM;
+  ZH_HIP(ctx, hipMemcpyAsync(dl.d_pieces.p, pieces.data(), pieces.size() * sizeof(PackPiece),
+                             hipMemcpyHostToDevice, stream));
+  const PackPiece* const dev_pieces = reinterpret_cast<const PackPiece*>(dl.d_pieces.p);
+  hipLaunchKernelGGL(zh_pack_kernel, dim3((uint32_t)pieces.size()), dim3(256), 0, stream, d_dst, pack,
+                     dev_pieces);
+  return ZH_OK;
+}
+// step 2, on `stream` (ordered behind step 1 by the caller): chunk c+1 is on the wire while the
+// host threads scatter chunk c
+int download_fetch(zh_ctx* ctx, hipStream_t stream, const Download& dl, void** dsts) {
+  if (!dl.total) return ZH_OK;
   int st = pin_init(ctx);
   if (st) return st;
-  // chunk c+1 is on the wire while the host threads scatter chunk c
-  const uint64_t nchunks = (total + pin_chunk() - 1) / pin_chunk();
+  const uint64_t total = dl.total, nchunks = (total + pin_chunk() - 1) / pin_chunk();
   auto fetch = [&](uint64_t c) -> int {
     const int k = (int)(c & 1);
     const uint64_t lo = c * pin_chunk(), hi = std::min<uint64_t>(total, lo + pin_chunk());
-    ZH_HIP(ctx, hipMemcpyAsync(ctx->pin[k], d_pack.p + lo, hi - lo, hipMemcpyDeviceToHost, ctx->stream));
-    ZH_HIP(ctx, hipEventRecord(ctx->pin_ev[k], ctx->stream));
+    ZH_HIP(ctx, hipMemcpyAsync(ctx->pin[k], dl.pack + lo, hi - lo, hipMemcpyDeviceToHost, stream));
+    ZH_HIP(ctx, hipEventRecord(ctx->pin_ev[k], stream));
     ctx->pin_busy[k] = true;
     return ZH_OK;
   };
@@ -965,8 +1003,151 @@ int download(zh_ctx* ctx, const uint8_t* d_dst, size_t n, const std::vector<uint
     const int k = (int)(c & 1);
     if ((st = pin_wait(ctx, k))) return st;
     const uint64_t lo = c * pin_chunk(), hi = std::min<uint64_t>(total, lo + pin_chunk());
-    stage_chunk(ctx->pin[k], lo, hi, poff, plen, dsts, false);
+    stage_chunk(ctx->pin[k], lo, hi, dl.poff, dl.plen, dsts, false);
   }
+  return ZH_OK;
+}
+int download(zh_ctx* ctx, const uint8_t* d_dst, size_t n, const std::vector<uint64_t>& doff,
+             const std::vector<uint64_t>& olen, const std::vector<char>& take, void** dsts,
+             size_t* dst_lens, int32_t* statuses) {
+  Download dl;
+  int st = download_pack(ctx, ctx->stream, dl, d_dst, n, doff, olen, take, nullptr, dsts, dst_lens, statuses);
+  if (st) return st;
+  return download_fetch(ctx, ctx->stream, dl, dsts);
+}
+
+// Batches of several GiB: groups of buffers (ZH_PIPE_GROUP bytes of input each) take turns, so
+// that the kernels of one group run while the host threads and the DMA engine move the
+// previous group's results out and the next group's buffers in.  A group must fill the machine
+// by itself, or splitting costs more than the overlap hides (ZH_PIPE_MIN: smallest batch that is
+// split).
+uint64_t env_bytes(const char* name, uint64_t dflt) {
+  const char* e = getenv(name);
+  const long long v = e ? atoll(e) : 0;
+  return v > 0 ? (uint64_t)v : dflt;
+}
+uint64_t pipe_group_bytes(const zh_ctx* ctx) {
+  static const uint64_t v = env_bytes("ZH_PIPE_GROUP", (uint64_t)1 << 30);
+  return ctx->pipe_group ? ctx->pipe_group : v;
+}
+uint64_t pipe_min_bytes(const zh_ctx* ctx) {
+  static const uint64_t v = env_bytes("ZH_PIPE_MIN", (uint64_t)3 << 30);
+  return ctx->pipe_min ? ctx->pipe_min : v;
+}
+constexpr int kPipeFallback = -1;  // not a status: "run this batch the plain way"
+
+struct PipeGroup {
+  size_t i0 = 0, n = 0;
+  std::vector<uint64_t> soff, slen, doff, dcap;
+  uint64_t src_total = 0, dst_total = 0;
+  DevBuf d_src, d_dst, d_pack;
+  PlanGuard pg;
+  hipEvent_t uploaded = nullptr, packed = nullptr;
+  Download dl;
+  ~PipeGroup() {
+    if (uploaded) (void)hipEventDestroy(uploaded);
+    if (packed) (void)hipEventDestroy(packed);
+  }
+};
+
+// ZH_OK: done.  kPipeFallback: the batch does not split, memory for the groups' second set of
+// buffers is not to be had, or some buffer outgrew its typical slot; nothing was returned, the
+// caller runs the batch the plain way.
+int compress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
+                             int level, int data_format, void** dsts, size_t* dst_lens,
+                             int32_t* statuses, uint32_t* crcs) {
+  std::vector<size_t> cut{0};
+  uint64_t acc = 0;
+  for (size_t i = 0; i < n; i++) {
+    acc += lens[i];
+    if (acc >= pipe_group_bytes(ctx)) {
+      cut.push_back(i + 1);
+      acc = 0;
+    }
+  }
+  if (cut.back() != n) cut.push_back(n);
+  const size_t G = cut.size() - 1;
+  if (G < 2) return kPipeFallback;
+  if (!ctx->copy_stream) ZH_HIP(ctx, hipStreamCreate(&ctx->copy_stream));
+  hipStream_t cs = ctx->copy_stream, ks = ctx->stream;
+  Trace tr;
+  std::vector<PipeGroup> gs(G);
+  int st;
+  for (size_t g = 0; g < G; g++) {  // every allocation up front: hipFree would serialise the pipeline
+    PipeGroup& q = gs[g];
+    q.i0 = cut[g];
+    q.n = cut[g + 1] - cut[g];
+    q.src_total = layout_slices(lens + q.i0, q.n, q.soff, q.slen);
+    q.doff.resize(q.n);
+    q.dcap.resize(q.n);
+    for (size_t i = 0; i < q.n; i++) {
+      q.doff[i] = q.dst_total;
+      q.dcap[i] = typical_cap(lens[q.i0 + i], data_format);
+      q.dst_total += (q.dcap[i] + 255) & ~(uint64_t)255;
+    }
+    if (hipMalloc(&q.d_src.p, q.src_total + 256) != hipSuccess ||
+        hipMalloc(&q.d_dst.p, q.dst_total + 256) != hipSuccess ||
+        hipMalloc(&q.d_pack.p, q.dst_total + 256) != hipSuccess) {
+      (void)hipGetLastError();
+      return kPipeFallback;
+    }
+    ZH_HIP(ctx, hipEventCreate(&q.uploaded));
+    ZH_HIP(ctx, hipEventCreate(&q.packed));
+    st = zh_plan_compress(ctx, q.n, q.soff.data(), q.slen.data(), q.doff.data(), q.dcap.data(), level,
+                          data_format, &q.pg.p);
+    if (st == ZH_ERR_NOMEM) return kPipeFallback;
+    if (st) return st;
+    if (crcs) zh_plan_request_crc32(q.pg.p, 1);
+  }
+  ZH_HIP(ctx, hipStreamSynchronize(ks));  // the plans' descriptors are in place
+  auto up = [&](size_t g) -> int {
+    PipeGroup& q = gs[g];
+    int e = upload_slices(ctx, cs, srcs + q.i0, q.soff, q.slen, q.src_total, q.d_src.p);
+    if (e) return e;
+    ZH_HIP(ctx, hipEventRecord(q.uploaded, cs));
+    return ZH_OK;
+  };
+  auto run = [&](size_t g) -> int {
+    PipeGroup& q = gs[g];
+    ZH_HIP(ctx, hipStreamWaitEvent(ks, q.uploaded, 0));
+    return zh_plan_run(q.pg.p, q.d_src.p, q.d_dst.p);
+  };
+  auto give_up = [&](int code) -> int {  // nothing is handed out from a failed call
+    (void)hipStreamSynchronize(cs);
+    (void)hipStreamSynchronize(ks);
+    for (int k = 0; k < 2; k++) ctx->pin_busy[k] = false;
+    for (size_t i = 0; i < n; i++) {
+      free(dsts[i]);
+      dsts[i] = nullptr;
+      dst_lens[i] = 0;
+      statuses[i] = ZH_OK;
+    }
+    return code;
+  };
+  if ((st = up(0)) || (st = run(0))) return give_up(st);
+  for (size_t g = 0; g < G; g++) {
+    PipeGroup& q = gs[g];
+    if (g + 1 < G && (st = up(g + 1))) return give_up(st);  // while group g's kernels run
+    std::vector<uint64_t> olen(q.n);
+    std::vector<int32_t> ost(q.n);
+    if ((st = zh_plan_results(q.pg.p, olen.data(), ost.data()))) return give_up(st);
+    if (crcs && (st = zh_plan_crc32(q.pg.p, crcs + q.i0))) return give_up(st);
+    std::vector<char> take(q.n);
+    for (size_t i = 0; i < q.n; i++) {
+      if (ost[i] == ZH_ERR_DST_TOO_SMALL) return give_up(kPipeFallback);
+      statuses[q.i0 + i] = ost[i];
+      take[i] = ost[i] == ZH_OK;
+    }
+    st = download_pack(ctx, ks, q.dl, q.d_dst.p, q.n, q.doff, olen, take, q.d_pack.p, dsts + q.i0,
+                       dst_lens + q.i0, statuses + q.i0);
+    if (st) return give_up(st);
+    if (hipEventRecord(q.packed, ks) != hipSuccess) return give_up(ZH_ERR_DEVICE);
+    if (g + 1 < G && (st = run(g + 1))) return give_up(st);  // next kernels behind the pack
+    if (hipStreamWaitEvent(cs, q.packed, 0) != hipSuccess) return give_up(ZH_ERR_DEVICE);
+    if ((st = download_fetch(ctx, cs, q.dl, dsts + q.i0))) return give_up(st);
+  }
+  ZH_HIP(ctx, hipStreamSynchronize(cs));
+  tr.mark(ctx, "compress: pipelined groups");
   return ZH_OK;
 }
 }  // namespace
@@ -990,6 +1171,13 @@ static int compress_batch_impl(zh_ctx* ctx, const void* const* srcs, const size_
   }
   if (!n) return ZH_OK;
   ZH_HIP(ctx, hipSetDevice(ctx->device));
+  uint64_t in_total = 0;
+  for (size_t i = 0; i < n; i++) in_total += lens[i];
+  if (in_total >= pipe_min_bytes(ctx)) {
+    const int ps = compress_batch_pipelined(ctx, srcs, lens, n, level, data_format, dsts, dst_lens,
+                                            statuses, crcs);
+    if (ps != kPipeFallback) return ps;
+  }
   DevBuf d_src;
   std::vector<uint64_t> soff, slen;
   Trace tr;
