@@ -118,6 +118,22 @@ def test_gpu_config4_default_compression_ratio(eng):
         assert out == oracle.compress(src, -1, oracle.dfGzip, fname_len=0)
 
 
+def test_gpu_config4_full_share_runs(eng):
+    """BASELINE.json configs[3], one GPU's share at full size (4096 x 1 MiB, DefaultCompression):
+    2^32 positions, more than one launch of the thread-per-position search may take.  bench.py
+    checks every status, every length and (inside uncompress) every CRC-32 of the round trip."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--level", "-1", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] > 0 and 2.4 < line["ratio"] < 2.9
+
+
 def test_gpu_config5_single_large_buffer(eng):
     """BASELINE.json configs[4] substitute (tor-list.gold is absent): one 40 MiB buffer =
     10 deflate blocks x 128 LZ-independent fragments, compress + uncompress."""

@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __r
                                                               ZhCompressArgs a, int good, int nice,
                                                               int max_chain,
                                                               const uint64_t* __restrict__ prevw,
-                                                              uint32_t* __restrict__ best) {
-  const uint32_t f = blockIdx.x / (ZH_FRAG_SIZE / 256u);
+                                                              uint32_t* __restrict__ best,
+                                                              uint32_t first_frag) {
+  const uint32_t f = first_frag + blockIdx.x / (ZH_FRAG_SIZE / 256u);
   const uint32_t local = (blockIdx.x % (ZH_FRAG_SIZE / 256u)) * 256u + threadIdx.x;
   const ZhFragDesc fd = a.frags[f];
   if (local >= fd.len) return;
@@ -295,9 +296,14 @@ extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, Z
 extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
                                        int good, int nice, int max_chain, const uint64_t* prevw,
                                        uint32_t* best) {
-  if (!a.nfrags) return;
-  hipLaunchKernelGGL(zh_chain_search_kernel, dim3(a.nfrags * (ZH_FRAG_SIZE / 256u)), dim3(256), 0, stream,
-                     d_src, a, good, nice, max_chain, prevw, best);
+  // one thread per position: a launch takes at most 2^30 of them (a grid of 2^32 threads or more is
+  // refused), so batches of 1 GiB and more go in slices
+  constexpr uint32_t kSlice = 32768;  // fragments per launch
+  for (uint32_t f0 = 0; f0 < a.nfrags; f0 += kSlice) {
+    const uint32_t nf = a.nfrags - f0 < kSlice ? a.nfrags - f0 : kSlice;
+    hipLaunchKernelGGL(zh_chain_search_kernel, dim3(nf * (ZH_FRAG_SIZE / 256u)), dim3(256), 0, stream,
+                       d_src, a, good, nice, max_chain, prevw, best, f0);
+  }
 }
 extern "C" void zh_launch_chain_select(hipStream_t stream, ZhCompressArgs a, const uint32_t* best) {
   if (!a.nblocks) return;
