@@ -118,8 +118,8 @@ def test_gpu_config4_default_compression_ratio(eng):
         assert out == oracle.compress(src, -1, oracle.dfGzip, fname_len=0)
 
 
-def test_gpu_config4_full_share_runs(eng):
-    """BASELINE.json configs[3], one GPU's share at full size (4096 x 1 MiB, DefaultCompression):
+def test_gpu_config4_whole_batch_on_one_gpu(eng):
+    """BASELINE.json configs[3] unsharded (4096 x 1 MiB, DefaultCompression, on one GPU):
     2^32 positions, more than one launch of the thread-per-position search may take.  bench.py
     checks every status, every length and (inside uncompress) every CRC-32 of the round trip."""
     import json
