@@ -7,7 +7,9 @@
 #include <cstring>
 #include <random>
 #include <chrono>
-#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -812,22 +814,92 @@ unsigned host_threads() {
   return t;
 }
 
-// f(t) on `nt` threads (the caller's included), all joined on return
-template <class F>
-void on_threads(unsigned nt, F&& f) {
-  std::vector<std::thread> th;
-  unsigned started = 1;
-  for (; started < nt; started++) {
-    try {
-      th.emplace_back([&f, t = started] { f(t); });
-    } catch (...) {  // no more threads to be had: the remaining shares run on this one
-      break;
+// The host threads that gather and scatter staging chunks: one pool per process, grown on demand,
+// so that a chunk costs a wake-up, not a round of thread creation.
+class HostPool {
+ public:
+  static HostPool& get() {
+    static HostPool pool;
+    return pool;
+  }
+  // f(t) for every share t in [0, nt), on the caller and up to nt - 1 pool threads; returns when
+  // all shares are done.  (Threads that cannot be had only mean fewer helpers.)
+  void run(unsigned nt, const std::function<void(unsigned)>& f) {
+    if (nt <= 1) {
+      f(0u);
+      return;
+    }
+    std::lock_guard<std::mutex> one_job(call_m_);
+    grow(nt - 1);
+    {
+      std::lock_guard<std::mutex> l(m_);
+      job_ = &f;
+      shares_ = nt;
+      next_ = 0;
+      left_ = nt;
+      gen_++;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> l(m_);
+    done_cv_.wait(l, [&] { return left_ == 0; });
+    job_ = nullptr;
+  }
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+
+ private:
+  void grow(unsigned want) {
+    while (th_.size() < want && th_.size() < 63) {
+      try {
+        th_.emplace_back([this] {
+          uint64_t seen = 0;
+          for (;;) {
+            {
+              std::unique_lock<std::mutex> l(m_);
+              cv_.wait(l, [&] { return stop_ || gen_ != seen; });
+              if (stop_) return;
+              seen = gen_;
+            }
+            work();
+          }
+        });
+      } catch (...) {
+        return;
+      }
     }
   }
-  f(0u);
-  for (unsigned t = started; t < nt; t++) f(t);
-  for (auto& x : th) x.join();
-}
+  void work() {  // take shares until none is left
+    for (;;) {
+      unsigned t;
+      const std::function<void(unsigned)>* job;
+      {
+        std::lock_guard<std::mutex> l(m_);
+        if (!job_ || next_ >= shares_) return;
+        t = next_++;
+        job = job_;
+      }
+      (*job)(t);
+      {
+        std::lock_guard<std::mutex> l(m_);
+        if (--left_ == 0) done_cv_.notify_all();
+      }
+    }
+  }
+  std::mutex call_m_, m_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> th_;
+  const std::function<void(unsigned)>* job_ = nullptr;
+  unsigned shares_ = 0, next_ = 0, left_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
 
 int pin_init(zh_ctx* ctx) {
   for (int k = 0; k < 2; k++) {
@@ -866,7 +938,7 @@ void stage_chunk(uint8_t* stage, uint64_t lo, uint64_t hi, const std::vector<uin
                  const std::vector<uint64_t>& len, void* const* host, bool to_stage) {
   const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(host_threads(), (hi - lo) >> 16));
   const uint64_t per = ((hi - lo + nt - 1) / nt + 4095) & ~(uint64_t)4095;
-  on_threads(nt, [&](unsigned t) {
+  HostPool::get().run(nt, [&](unsigned t) {
     const uint64_t a = lo + per * t, b = std::min(hi, a + per);
     if (a < b) stage_range(stage + (a - lo), a, b, off, len, host, to_stage);
   });
