@@ -96,7 +96,7 @@ void zh_set_gzip_fname_len(zh_ctx *ctx, int k);
 
 /* Host-buffer compress calls of at least min_batch_bytes of input run as pipelined groups of
  * about group_bytes each: one group's kernels overlap the neighbours' transfers (no reference
- * counterpart; the results are the same bytes either way).  0 = default (3 GiB / 1 GiB, or the
+ * counterpart; the results are the same bytes either way).  0 = default (1 GiB / 512 MiB, or the
  * ZH_PIPE_MIN / ZH_PIPE_GROUP environment variables). */
 void zh_set_host_pipeline(zh_ctx *ctx, size_t min_batch_bytes, size_t group_bytes);
 

@@ -1088,7 +1088,7 @@ int download(zh_ctx* ctx, const uint8_t* d_dst, size_t n, const std::vector<uint
   return download_fetch(ctx, ctx->stream, dl, dsts);
 }
 
-// Batches of several GiB: groups of buffers (ZH_PIPE_GROUP bytes of input each) take turns, so
+// Batches of a GiB and more: groups of buffers (ZH_PIPE_GROUP bytes of input each) take turns, so
 // that the kernels of one group run while the host threads and the DMA engine move the
 // previous group's results out and the next group's buffers in.  A group must fill the machine
 // by itself, or splitting costs more than the overlap hides (ZH_PIPE_MIN: smallest batch that is
@@ -1099,11 +1099,11 @@ uint64_t env_bytes(const char* name, uint64_t dflt) {
   return v > 0 ? (uint64_t)v : dflt;
 }
 uint64_t pipe_group_bytes(const zh_ctx* ctx) {
-  static const uint64_t v = env_bytes("ZH_PIPE_GROUP", (uint64_t)1 << 30);
+  static const uint64_t v = env_bytes("ZH_PIPE_GROUP", (uint64_t)512 << 20);
   return ctx->pipe_group ? ctx->pipe_group : v;
 }
 uint64_t pipe_min_bytes(const zh_ctx* ctx) {
-  static const uint64_t v = env_bytes("ZH_PIPE_MIN", (uint64_t)3 << 30);
+  static const uint64_t v = env_bytes("ZH_PIPE_MIN", (uint64_t)1 << 30);
   return ctx->pipe_min ? ctx->pipe_min : v;
 }
 constexpr int kPipeFallback = -1;  // not a status: "run this batch the plain way"
