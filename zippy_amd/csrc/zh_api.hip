@@ -1128,11 +1128,15 @@ struct PipeGroup {
 int compress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
                              int level, int data_format, void** dsts, size_t* dst_lens,
                              int32_t* statuses, uint32_t* crcs) {
+  // at most 16 groups (each has its own plan scratch): very large batches get larger groups
+  uint64_t in_total = 0;
+  for (size_t i = 0; i < n; i++) in_total += lens[i];
+  const uint64_t group_bytes = std::max<uint64_t>(pipe_group_bytes(ctx), in_total / 16);
   std::vector<size_t> cut{0};
   uint64_t acc = 0;
   for (size_t i = 0; i < n; i++) {
     acc += lens[i];
-    if (acc >= pipe_group_bytes(ctx)) {
+    if (acc >= group_bytes) {
       cut.push_back(i + 1);
       acc = 0;
     }
