@@ -1,7 +1,7 @@
 #!/bin/bash
 # The per-round evidence under profiles/ (run on the GPU box from the repo root):
 #   bash tools/prof/final_pass.sh r01_g
-# -> gpurun_out/<tag>_bench.json, _kernel_stats.csv, _pytest_gpu.log, _c5.json, hbm_traffic.json
+# -> gpurun_out/<tag>_bench.json, _kernel_stats.csv, _pytest_gpu.log, _c5.json, _host_api.json, hbm_traffic.json
 R=$(pwd); T=${1:-r01}
 O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
@@ -9,6 +9,7 @@ timeout 600 python -m pytest tests -m gpu -q > $O/${T}_pytest_gpu.log 2>&1
 timeout 600 python bench.py --steps 5 --warmup 1 2>/dev/null | tail -1 > $O/${T}_bench.json
 timeout 300 python tools/bench_c5.py --plain 2>/dev/null | tail -1 > $O/${T}_c5.json
 timeout 300 python tools/bench_c5.py --level -1 --steps 2 2>/dev/null | tail -1 >> $O/${T}_c5.json
+timeout 300 python tools/bench_host_api.py --reps 2 2>/dev/null | tail -1 > $O/${T}_host_api.json
 cd /tmp
 rm -rf /tmp/kt /tmp/pf /tmp/pw
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${T}_rocprof_bench.log 2>&1
