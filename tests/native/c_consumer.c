@@ -72,6 +72,58 @@ int main(void) {
     zh_free(comp[i]);
     zh_free(back[i]);
   }
+
+  /* block-parallel form of one buffer: independent 32 KiB deflate blocks + their index */
+  {
+    void *blk = NULL, *out = NULL;
+    size_t blk_len = 0, out_len = 0, n_entries = 0;
+    zh_block_entry *index = NULL;
+    rc = zh_compress_blocks(ctx, text[3], lens[3], 1, ZH_DF_GZIP, 32768, &blk, &blk_len, &index, &n_entries);
+    if (rc != ZH_OK) return fail("zh_compress_blocks", rc);
+    if (n_entries != 3 + 1 || index[n_entries - 1].out_off != lens[3]) return fail("block index shape", -1);
+    rc = zh_uncompress_indexed(ctx, blk, blk_len, ZH_DF_DETECT, index, n_entries, &out, &out_len);
+    if (rc != ZH_OK) return fail("zh_uncompress_indexed", rc);
+    if (out_len != lens[3] || memcmp(out, text[3], out_len) != 0) return fail("indexed round trip differs", -1);
+    zh_free(out);
+    zh_free(index);
+    zh_free(blk);
+  }
+
+  /* ZIP: create, open, look up, extract (ziparchives.nim) */
+  {
+    const char *names[3] = {"docs/a.txt", "b.bin", "empty"};
+    const size_t name_lens[3] = {10, 5, 5};
+    const void *contents[3];
+    size_t content_lens[3];
+    void *zip = NULL, *got[2];
+    size_t zip_len = 0, got_len[2], idx[2], where = 0;
+    zh_zip_reader *rd = NULL;
+    zh_zip_entry ent;
+    contents[0] = text[3];
+    content_lens[0] = lens[3];
+    contents[1] = text[2];
+    content_lens[1] = lens[2];
+    contents[2] = text[0];
+    content_lens[2] = 0;
+    rc = zh_zip_create(ctx, names, name_lens, contents, content_lens, 3, 0, 33, &zip, &zip_len);
+    if (rc != ZH_OK) return fail("zh_zip_create", rc);
+    if ((rc = zh_zip_open(zip, zip_len, &rd)) != ZH_OK) return fail("zh_zip_open", rc);
+    if (zh_zip_num_entries(rd) != 3) return fail("zip entry count", -1);
+    if ((rc = zh_zip_find(rd, "b.bin", 5, &where)) != ZH_OK) return fail("zh_zip_find", rc);
+    if ((rc = zh_zip_entry_at(rd, where, &ent)) != ZH_OK) return fail("zh_zip_entry_at", rc);
+    if (ent.path_len != 5 || memcmp(ent.path, "b.bin", 5) != 0 || ent.is_directory) return fail("zip entry fields", -1);
+    idx[0] = where;
+    if ((rc = zh_zip_find(rd, names[0], name_lens[0], &idx[1])) != ZH_OK) return fail("zh_zip_find (2)", rc);
+    rc = zh_zip_extract_batch(ctx, rd, idx, 2, got, got_len, st);
+    if (rc != ZH_OK || st[0] != ZH_OK || st[1] != ZH_OK) return fail("zh_zip_extract_batch", rc ? rc : (st[0] ? st[0] : st[1]));
+    if (got_len[0] != lens[2] || memcmp(got[0], text[2], lens[2]) != 0) return fail("zip entry b.bin differs", -1);
+    if (got_len[1] != lens[3] || memcmp(got[1], text[3], lens[3]) != 0) return fail("zip entry docs/a.txt differs", -1);
+    if (zh_zip_find(rd, "missing", 7, &where) == ZH_OK) return fail("found a missing entry", -1);
+    zh_free(got[0]);
+    zh_free(got[1]);
+    zh_zip_close(rd);
+    zh_free(zip);
+  }
   zh_destroy(ctx);
   printf("c_consumer ok\n");
   return 0;
