@@ -390,7 +390,8 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
                o_st = ar.reserve(n * 4);
   p->head_bytes = chain ? nb * ((size_t)2 << 17) : 0;
   const size_t o_head = ar.reserve(p->head_bytes);
-  const size_t o_l1tab = ar.reserve(level == 1 ? (size_t)zh_l1_table_slots() * 32768 : 0);
+  // one 32 KiB hash table per persistent matcher wave (zh_launch_l1_match: min(fragments, slots) waves)
+  const size_t o_l1tab = ar.reserve(level == 1 ? std::min<size_t>(nf, zh_l1_table_slots()) * 32768 : 0);
   const size_t o_cprev = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 8 : 0);
   const size_t o_cbest = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 4 : 0);
   ar.reserve(256);
