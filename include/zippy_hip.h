@@ -143,8 +143,8 @@ int zh_compress_batch_crc32(zh_ctx *ctx, const void *const *srcs, const size_t *
                             int level, int data_format, void **dsts, size_t *dst_lens,
                             int32_t *statuses, uint32_t *crcs);
 /* zh_uncompress_batch for callers that know the output sizes up front (ZIP central directory,
- * ziparchives.nim:85-93; gzip.nim:72-76 trustSize): size_hints[i] replaces the sizing pass of
- * zlib/raw streams (a wrong hint only costs a retry), crcs[i] (optional) = crc32 of output i. */
+ * ziparchives.nim:85-93; gzip.nim:72-76 trustSize): size_hints[i] replaces the guess (4x the
+ * stream, then a sizing pass if that was too little) of zlib/raw streams (a wrong hint only costs a retry), crcs[i] (optional) = crc32 of output i. */
 int zh_uncompress_batch_sized(zh_ctx *ctx, const void *const *srcs, const size_t *lens, size_t n,
                               int data_format, const uint64_t *size_hints, void **dsts,
                               size_t *dst_lens, int32_t *statuses, uint32_t *crcs);

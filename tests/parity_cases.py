@@ -396,3 +396,39 @@ def check_ragged_staging(eng, scale):
             back, sts = eng.uncompress_batch(bad, fmt)
             assert sts[7] != 0 and back[7] is None
             assert [b for i, b in enumerate(back) if i != 7] == [b for i, b in enumerate(bufs) if i != 7]
+
+
+def check_unsized_streams(eng):
+    """zlib / raw deflate streams carry no size: the host call guesses 4x, and streams that
+    outgrow the guess are sized and decoded again -- next to streams that fit, damaged ones and
+    (for dfDetect) gzip members, in one call."""
+    import zlib
+    from zippy_amd import synth
+    text = synth.corpus_file("alice29.txt")[:90000]
+    plain = [b"", b"a", text, b"\x00" * 300000, bytes(range(256)) * 40, b"ab" * 70000, text[:777],
+             b"\xff" * 1000000]
+    for fmt, wb in ((oracle.dfZlib, 15), (oracle.dfDeflate, -15)):
+        blobs = []
+        for k, b in enumerate(plain):
+            if k % 2:
+                c = zlib.compressobj(6, zlib.DEFLATED, wb)
+                blobs.append(c.compress(b) + c.flush())
+            else:
+                blobs.append(oracle.compress(b, 1, fmt))
+        hurt = bytearray(blobs[3])
+        hurt[len(hurt) // 2] ^= 0x40
+        blobs.append(bytes(hurt))           # damaged, highly compressible
+        blobs.append(blobs[2][:len(blobs[2]) // 2])  # truncated
+        outs, sts = eng.uncompress_batch(blobs, fmt)
+        for i, blob in enumerate(blobs):
+            try:
+                want = oracle.uncompress(blob, fmt)
+            except oracle.ZippyError:
+                want = None
+            assert (outs[i] if sts[i] == 0 else None) == want, (fmt, i, sts[i])
+            if i < len(plain):
+                assert want == plain[i]
+    mixed = [oracle.compress(plain[3], 1, oracle.dfZlib), oracle.compress(text, 1, oracle.dfGzip, fname_len=3),
+             zlib.compress(plain[7], 9), oracle.compress(plain[5], -1, oracle.dfGzip, fname_len=0)]
+    outs, sts = eng.uncompress_batch(mixed)
+    assert sts == [0, 0, 0, 0] and outs == [plain[3], text, plain[7], plain[5]]

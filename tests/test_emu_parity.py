@@ -114,3 +114,7 @@ def test_emu_level1_many_fragments(eng):
 
 def test_emu_ragged_staging(eng):
     pc.check_ragged_staging(eng, 1)
+
+
+def test_emu_unsized_streams(eng):
+    pc.check_unsized_streams(eng)

@@ -103,6 +103,10 @@ def test_gpu_level1_identical_at_scale(eng):
     assert all(s == 0 for s in sts) and back == bufs
 
 
+def test_gpu_unsized_streams(eng):
+    pc.check_unsized_streams(eng)
+
+
 def test_gpu_host_api_ragged_staging(eng):
     """~135 MiB through the host-buffer API in 32 MiB staging chunks: buffers and results that
     straddle chunk and thread borders, empty buffers, a damaged member."""

@@ -1348,43 +1348,47 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
   if (st) return st;
   tr.mark(ctx, "uncompress: upload");
 
-  // Output sizes: gzip members carry ISIZE (gzip.nim:64-66, trusted only as a
-  // capacity hint and verified afterwards); zlib / raw streams get a sizing pass.
+  // Output sizes: gzip members carry ISIZE (gzip.nim:64-66, trusted only as a capacity hint and
+  // verified afterwards); zlib / raw streams carry nothing: they get a guess (4x their size,
+  // enough for most data) and, if they outgrow it, a sizing pass (count only) and a second decode.
   std::vector<uint64_t> cap(n, 0);
-  std::vector<char> need_count(n, 0);
-  bool any_count = false;
+  std::vector<char> guessed(n, 0), active(n, 1);
   for (size_t i = 0; i < n; i++) {
     const uint8_t* s8 = (const uint8_t*)srcs[i];
     const int f = host_detect(s8, lens[i], data_format);
+    const uint64_t max_out = (uint64_t)lens[i] * 1032 + 64;  // deflate cannot expand further
     if (f == ZH_DF_GZIP && lens[i] >= 18) {
       const uint8_t* t = s8 + lens[i] - 4;
       const uint64_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint64_t)t[3] << 24);
-      const uint64_t max_out = (uint64_t)lens[i] * 1032 + 64;  // deflate cannot expand further
       cap[i] = std::min(isize, max_out);
     } else if (f == ZH_DF_ZLIB || f == ZH_DF_DEFLATE) {
       if (size_hints) {
-        cap[i] = std::min<uint64_t>(size_hints[i], (uint64_t)lens[i] * 1032 + 64);
+        cap[i] = std::min<uint64_t>(size_hints[i], max_out);
       } else {
-        need_count[i] = 1;
-        any_count = true;
+        guessed[i] = 1;
+        cap[i] = std::min<uint64_t>((uint64_t)lens[i] * 4 + 65536, max_out);
       }
     }
   }
-  std::vector<uint64_t> zero_off(n, 0);
-  for (int pass = any_count ? 0 : 1; pass < 3; pass++) {
-    // pass 0: sizing (count only) of the streams without a size field
-    // pass 1: decode; pass 2: re-decode gzip members whose ISIZE wrapped (>= 4 GiB)
-    std::vector<uint64_t> doff(n), dcap(n);
+  // pass 1: decode.  Streams that need more room than they were given run again -- after pass 0
+  // (sizing of the guessed ones) -- in pass 2; gzip members get the expansion bound there (more
+  // data than ISIZE promised: a >= 4 GiB member, ISIZE being mod 2^32, or a corrupt stream).
+  // A stream whose outcome is final is handed to later passes with length 0: it costs nothing.
+  int pass = 1;
+  for (int turn = 0; turn < 3; turn++) {
+    std::vector<uint64_t> doff(n), dcap(n), slen_now(n);
     uint64_t total = 0;
     for (size_t i = 0; i < n; i++) {
+      const bool runs = active[i] && (pass != 0 || guessed[i]);
+      slen_now[i] = runs ? slen[i] : 0;
       doff[i] = total;
-      dcap[i] = pass == 0 ? 0 : cap[i];
-      if (pass != 0) total += (dcap[i] + 255) & ~(uint64_t)255;
+      dcap[i] = pass == 0 || !runs ? 0 : cap[i];
+      total += (dcap[i] + 255) & ~(uint64_t)255;
     }
     DevBuf d_dst;
     if (hipMalloc(&d_dst.p, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
     PlanGuard pg;
-    st = zh_plan_uncompress(ctx, n, soff.data(), slen.data(), doff.data(), dcap.data(), data_format, &pg.p);
+    st = zh_plan_uncompress(ctx, n, soff.data(), slen_now.data(), doff.data(), dcap.data(), data_format, &pg.p);
     if (st) return st;
     tr.mark(ctx, "uncompress: alloc + plan");
     plan_set_count_only(pg.p, pass == 0);
@@ -1400,30 +1404,32 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
     tr.mark(ctx, "uncompress: kernels");
     if (pass == 0) {
       for (size_t i = 0; i < n; i++)
-        if (need_count[i]) cap[i] = olen[i];
+        if (active[i] && guessed[i]) cap[i] = olen[i];
+      pass = 2;
       continue;
     }
-    bool again = false;
+    bool again = false, size_first = false;
     std::vector<char> take(n, 0);
     for (size_t i = 0; i < n; i++) {
-      if (dsts[i] || (pass == 2 && statuses[i] != ZH_ERR_DST_TOO_SMALL)) continue;
+      if (!active[i]) continue;
       statuses[i] = ost[i];
       if (ost[i] == ZH_ERR_DST_TOO_SMALL && pass == 1) {
-        // more data than ISIZE promised: a >= 4 GiB member (ISIZE is mod 2^32) or a
-        // corrupt stream.  Give it the deflate expansion bound once.
-        cap[i] = (uint64_t)lens[i] * 1032 + 64;
+        if (guessed[i])
+          size_first = true;
+        else
+          cap[i] = (uint64_t)lens[i] * 1032 + 64;
         again = true;
         continue;
       }
+      active[i] = 0;
       if (ost[i] != ZH_OK) continue;
       take[i] = 1;
       if (crcs) crcs[i] = ocrc[i];
     }
     if ((st = download(ctx, d_dst.p, n, doff, olen, take, dsts, dst_lens, statuses))) return st;
     tr.mark(ctx, "uncompress: download");
-    if (!again) break;
-    for (size_t i = 0; i < n; i++)
-      if (statuses[i] != ZH_ERR_DST_TOO_SMALL) cap[i] = 0;  // only the wrapped members run again
+    if (!again || pass == 2) break;
+    pass = size_first ? 0 : 2;
   }
   for (size_t i = 0; i < n; i++)
     if (statuses[i] == ZH_ERR_DST_TOO_SMALL) statuses[i] = ZH_ERR_CHECKSUM;
