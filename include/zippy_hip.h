@@ -168,7 +168,20 @@ int zh_plan_compress(zh_ctx *ctx, size_t n, const uint64_t *src_off, const uint6
 int zh_plan_uncompress(zh_ctx *ctx, size_t n, const uint64_t *src_off, const uint64_t *src_len,
                        const uint64_t *dst_off, const uint64_t *dst_cap, int data_format,
                        zh_plan **out);
-/* Enqueue the plan. d_src/d_dst are device pointers. */
+/* Enqueue the plan. d_src/d_dst are device pointers.
+ * Preconditions and side effects (compress plans):
+ *  - d_dst must be 4-byte aligned (the encoder addresses the output as 32-bit words; slot
+ *    offsets themselves may be any byte); a misaligned d_dst returns ZH_ERR_ARGUMENT;
+ *  - every slot [dst_off, dst_off + dst_cap) is zeroed before encoding -- the whole slot, not
+ *    only the bytes the stream ends up using.  Bytes of d_dst outside the slots are never
+ *    modified (slots that tile one range are cleared by one memset, others one by one);
+ *  - slots must not overlap.
+ * Both directions read whole aligned 32-bit words around a source buffer, i.e. up to 3 bytes
+ * before src_off and after src_off + src_len: those bytes must be mapped (true inside any
+ * hipMalloc allocation, which is 256-byte aligned and padded); their values are ignored.
+ * Uncompress plans: on ZH_ERR_DST_TOO_SMALL out_len is the number of bytes written before the
+ * token that did not fit (out_len <= dst_cap), not the required size; callers that need the
+ * size use the host-buffer calls (which size and retry) or a larger slot. */
 int zh_plan_run(zh_plan *plan, const void *d_src, void *d_dst);
 /* Wait for the stream and fetch per-buffer output lengths and statuses. */
 int zh_plan_results(zh_plan *plan, uint64_t *out_lens, int32_t *statuses);

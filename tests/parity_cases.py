@@ -154,6 +154,27 @@ def check_error_statuses(eng):
     outs, sts = eng.uncompress_batch([good, bytes(bad), good])
     assert sts[0] == 0 and sts[2] == 0 and sts[1] != 0
     assert outs[0] == b"neighbour" * 100 and outs[2] == outs[0]
+    # A gzip member whose ISIZE (the host path's output capacity) is far below what its body
+    # produces -- one stored block of 65535 bytes behind ISIZE = 1, and a literal/match body
+    # behind ISIZE = 3: the decoder stops at the capacity, and the checksum pass must not read
+    # past the slot (it did once: out_len overshot the slot by the failing token).  The oracle
+    # decodes with a growing buffer and then fails on the size/CRC check; both must reject.
+    import struct
+    big = bytes(range(256)) * 256
+    stored = b"\x01" + struct.pack("<HH", 65535, 0) + big[:65535]
+    liar = b"\x1f\x8b\x08\x00" + b"\x00" * 6 + stored + struct.pack("<II", zlib.crc32(big[:65535]), 1)
+    assert status_of(liar) != 0
+    body = zlib.compress(b"abcdefgh" * 4000, 6)[2:-4]
+    liar2 = b"\x1f\x8b\x08\x00" + b"\x00" * 6 + body + struct.pack("<II", 0, 3)
+    assert status_of(liar2) != 0
+    for blob in (liar, liar2):
+        try:
+            oracle.uncompress(blob)
+            assert False, "the oracle must reject it too"
+        except oracle.ZippyError:
+            pass
+    outs, sts = eng.uncompress_batch([good, liar, liar2, good])
+    assert sts[0] == 0 and sts[3] == 0 and sts[1] != 0 and sts[2] != 0 and outs[3] == outs[0]
     import pytest
     from zippy_amd.common import ZippyError
     for level in (10, -3):
@@ -283,6 +304,21 @@ def check_zip_errors(eng):
             eng.open_zip(blob)
         with pytest.raises(either):
             zip_oracle.open_archive(blob)
+    # zip64 fields near INT64_MAX / above it (an overflow-checked reference raises; here the
+    # bounds checks must not wrap): a zip64 locator pointing its EOCD64 at 0x7fffffffffffffe0,
+    # and a real EOCD64 whose directory offset / size / record count are absurd
+    import struct
+    eocd = b"PK\x05\x06" + b"\x00" * 18
+    for off in (0x7fffffffffffffe0, 0xffffffffffffffff, 1 << 63, 1 << 40):
+        blob = b"PK\x06\x07" + struct.pack("<IQI", 0, off, 1) + eocd
+        with pytest.raises(ZippyError):
+            eng.open_zip(blob)
+    for fields in ((1, 1, 0x7ffffffffffffff0, 0), (1, 1, 0, 0x7ffffffffffffff0), (1 << 62, 1 << 62, 10, 0),
+                   (0xffffffffffffffff, 0xffffffffffffffff, 46, 0)):
+        e64 = b"PK\x06\x06" + struct.pack("<QHHIIQQQQ", 44, 45, 45, 0, 0, *fields)
+        blob = e64 + b"PK\x06\x07" + struct.pack("<IQI", 0, 0, 1) + eocd
+        with pytest.raises(ZippyError):
+            eng.open_zip(blob)
     for entries in ([("", b"x")], [("/abs", b"x")], [("n" * 70000, b"x")]):
         with pytest.raises(ZippyError):
             eng.create_zip(entries)

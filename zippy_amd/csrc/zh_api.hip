@@ -224,6 +224,8 @@ struct zh_plan {
   uint64_t* chain_prev = nullptr;
   uint32_t* chain_best = nullptr;
   uint64_t dst_lo = 0, dst_hi = 0;  // byte range of d_dst covered by the slots
+  bool dst_dense = true;            // the slots tile [dst_lo, dst_hi) without gaps
+  uint64_t dst_max_cap = 0;
   uint64_t* out_len = nullptr;
   int32_t* status = nullptr;
   const uint64_t* src_len_dev = nullptr;
@@ -315,7 +317,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   std::vector<ZhBlockDesc> blocks;
   std::vector<ZhFragDesc> frags;
   std::vector<ZhPieceDesc> pieces;
-  uint64_t lo = ~0ull, hi = 0;
+  uint64_t lo = ~0ull, hi = 0, cap_sum = 0, cap_max = 0;
   for (size_t i = 0; i < n; i++) {
     ZhBufDesc& b = bufs[i];
     b.src_off = src_off[i];
@@ -356,6 +358,8 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
     b.npieces = (uint32_t)frags.size() - b.first_piece;
     lo = std::min(lo, b.dst_off);
     hi = std::max(hi, b.dst_off + b.dst_cap);
+    cap_sum += b.dst_cap;
+    cap_max = std::max(cap_max, b.dst_cap);
   }
   if (blocks.size() >= 0xffffffffull || frags.size() >= 0xffffffffull) return ZH_ERR_ARGUMENT;
 
@@ -367,6 +371,8 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   p->fmt = data_format;
   p->dst_lo = n ? lo : 0;
   p->dst_hi = n ? hi : 0;
+  p->dst_dense = !n || cap_sum >= hi - lo;  // (overlapping slots are the caller's error either way)
+  p->dst_max_cap = cap_max;
   const size_t nf = frags.size(), nb = blocks.size();
   const bool chain = level == -1 || level >= 2;
   const bool need_matches = level != 0;
@@ -534,7 +540,7 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
     b.dst_cap = dst_cap[i];
     b.first_piece = (uint32_t)pieces.size();
     for (uint64_t o = 0; o < b.dst_cap; o += ZH_FRAG_SIZE)
-      pieces.push_back(ZhPieceDesc{b.dst_off + o, 0, (uint32_t)i, o});
+      pieces.push_back(ZhPieceDesc{b.dst_off + o, (uint32_t)std::min<uint64_t>(b.dst_cap - o, ZH_FRAG_SIZE), (uint32_t)i, o});
     b.npieces = (uint32_t)pieces.size() - b.first_piece;
   }
   zh_plan* p = new zh_plan;
@@ -659,6 +665,27 @@ extern "C" int zh_plan_set_src_lens_device(zh_plan* plan, const uint64_t* d_lens
 
 static void plan_set_count_only(zh_plan* plan, int on) { plan->ia.count_only = on; }
 
+// Output slots start out zeroed (every shared output word is OR-ed into place).  Slots that tile
+// one range are cleared with a single memset; slots with gaps between them are cleared one by
+// one, byte-exact, so that caller data lying between two slots is never touched.
+__global__ __launch_bounds__(256) void zh_zero_slots_kernel(uint8_t* __restrict__ d_dst,
+                                                            const ZhBufDesc* __restrict__ bufs) {
+  const ZhBufDesc b = bufs[blockIdx.x];
+  uint8_t* const base = d_dst + b.dst_off;
+  const uint64_t cap = b.dst_cap;
+  uint64_t head = (16u - ((uintptr_t)base & 15u)) & 15u;
+  if (head > cap) head = cap;
+  const uint64_t nvec = (cap - head) >> 4;
+  uint4* const body = reinterpret_cast<uint4*>(base + head);
+  for (uint64_t i = (uint64_t)blockIdx.y * 256u + threadIdx.x; i < nvec; i += (uint64_t)gridDim.y * 256u)
+    body[i] = make_uint4(0, 0, 0, 0);
+  if (blockIdx.y == 0) {
+    if (threadIdx.x < head) base[threadIdx.x] = 0;
+    const uint64_t t0 = head + (nvec << 4);
+    if (t0 + threadIdx.x < cap) base[t0 + threadIdx.x] = 0;
+  }
+}
+
 extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
   if (!p) return ZH_ERR_ARGUMENT;
   zh_ctx* ctx = p->ctx;
@@ -671,8 +698,15 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     const ZhCompressArgs& a = p->ca;
     const int want_crc = p->fmt == ZH_DF_GZIP || p->force_crc, want_adler = p->fmt == ZH_DF_ZLIB;
     // every shared output word is OR-ed into place, so the slots start out zeroed
+    // zh_emit_kernel and zh_layout_kernel address the output as aligned 32-bit words
+    if ((uintptr_t)d_dst & 3u) return ZH_ERR_ARGUMENT;
     prof_mark(p, "memset_dst");
-    ZH_HIP(ctx, hipMemsetAsync(d_dst + p->dst_lo, 0, p->dst_hi - p->dst_lo, s));
+    if (p->dst_dense) {
+      ZH_HIP(ctx, hipMemsetAsync(d_dst + p->dst_lo, 0, p->dst_hi - p->dst_lo, s));
+    } else {
+      const uint32_t gy = (uint32_t)std::min<uint64_t>(64, (p->dst_max_cap >> 16) + 1);
+      hipLaunchKernelGGL(zh_zero_slots_kernel, dim3((uint32_t)p->n, gy), dim3(256), 0, s, d_dst, p->d_bufs);
+    }
     if (p->level == 1 || p->level == -2) {
       prof_mark(p, "zh_l1_match_kernel");
       zh_launch_l1_match(s, d_src, a, p->level == -2, p->l1_tables);

@@ -75,6 +75,9 @@ __global__ __launch_bounds__(64) void zh_checksum_pieces_kernel(
     if (dyn_len) {
       uint64_t total = dyn_len[pd.buf];
       len = total > pd.rel_off ? (uint32_t)(total - pd.rel_off < 32768u ? total - pd.rel_off : 32768u) : 0u;
+      // never past the slot: pd.len is the piece's share of the slot's capacity (a stream that
+      // failed with DST_TOO_SMALL must not make this kernel read behind its slot)
+      if (len > pd.len) len = pd.len;
     }
     const uint8_t* base = d_data + pd.off;
     // head: bytes before the first 16-byte boundary (handled by lane 0)

@@ -85,10 +85,11 @@ struct ZhCompressArgs {
 };
 
 // Checksum piece: d_data[off .. off+len), len <= 32768.  With a device-side length
-// array (inflate output) len = clamp(dyn_len[buf] - rel_off, 0, 32768).
+// array (inflate output) len = clamp(dyn_len[buf] - rel_off, 0, len): `len` is then the
+// piece's share of the slot capacity.
 struct ZhPieceDesc {
   uint64_t off;      // absolute byte offset in d_data
-  uint32_t len;      // static length (ignored when dyn_len is used)
+  uint32_t len;      // static length (an upper bound when dyn_len is used)
   uint32_t buf;
   uint64_t rel_off;  // offset of the piece inside its buffer
 };

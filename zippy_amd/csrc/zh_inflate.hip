@@ -451,7 +451,9 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
           }
           if (live) dst[op + lane] = (uint8_t)val;
         }
-        op += total;
+        // a failed stream reports the bytes it really wrote (out_len <= cap): `op` stops at the
+        // last round that fitted
+        if (st == ZH_OK) op += total;
       } else if (total) {
         // long rounds: per window, literal runs by their lanes and copies in order
         KPROF_COUNT(4, 1);
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
                 if (op + nl > cap) st = ZH_ERR_DST_TOO_SMALL;
                 else if ((grp >> lane) & 1ull) dst[op0 + opre_w] = (uint8_t)(rec_w >> 16);
               }
-              op += nl;
+              if (st == ZH_OK) op += nl;
             }
           }
         };
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
             if (op + 1 > cap) st = ZH_ERR_DST_TOO_SMALL;
             else if (lane == 0) dst[op] = (uint8_t)tail_a;
           }
-          op += 1;
+          if (st == ZH_OK) op += 1;
         } else if (tail == kTailMatch) {
           KPROF_COUNT(7, 1);
           lz_copy(tail_a, tail_b);
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
               for (uint32_t i = lane; i < tail_a; i += 64) dst[op + i] = raw[i];
             }
           }
-          op += tail_a;
+          if (st == ZH_OK) op += tail_a;
         }
       }
       if (st != ZH_OK && lane == 0) s_ostatus = st;

@@ -54,6 +54,9 @@ struct Image {
     return (uint32_t)p[at] | ((uint32_t)p[at + 1] << 8) | ((uint32_t)p[at + 2] << 16) | ((uint32_t)p[at + 3] << 24);
   }
   uint64_t u64(int64_t at) const { return (uint64_t)u32(at) | ((uint64_t)u32(at + 4) << 32); }
+  // [at, at + n) lies inside the image.  Written without additions: `at` and `n` come from
+  // 64-bit fields of the (untrusted) archive and may be anywhere up to INT64_MAX or negative.
+  bool has(int64_t at, int64_t n) const { return at >= 0 && n >= 0 && n <= size && at <= size - n; }
 };
 
 struct Record {
@@ -138,7 +141,7 @@ extern "C" int zh_zip_open(const void* archive, size_t len, zh_zip_reader** out)
     if (im.u32(eocd - 20 + 4) != 0) return ZH_ERR_ZIP_UNSUPPORTED;   // disk of the zip64 EOCD
     const int64_t pos = (int64_t)im.u64(eocd - 20 + 8);
     if (im.u32(eocd - 20 + 16) != 1) return ZH_ERR_ZIP_UNSUPPORTED;  // number of disks
-    if (pos < 0 || pos + 64 > im.size) return ZH_ERR_ARCHIVE_EOF;
+    if (!im.has(pos, 64)) return ZH_ERR_ARCHIVE_EOF;
     if (im.u32(pos) != kZip64EocdSig) return ZH_ERR_ZIP_CENTRAL_HEADER;
     disk_number = im.u32(pos + 16);
     start_disk = im.u32(pos + 20);
@@ -155,6 +158,12 @@ extern "C" int zh_zip_open(const void* archive, size_t len, zh_zip_reader** out)
     cd_start = im.u32(eocd + 16);
   }
   if (disk_number != 0 || start_disk != 0 || records_on_disk != num_records) return ZH_ERR_ZIP_UNSUPPORTED;
+  // zip64 fields above INT64_MAX arrive here negative; nothing in an archive can lie or reach
+  // beyond the image, and a record takes at least 46 bytes (the reference runs overflow-checked
+  // and ends up raising on such values: same outcome, no wild read)
+  if (cd_start < 0 || cd_start > im.size || cd_size < 0 || cd_size > im.size || num_records < 0 ||
+      num_records > im.size / 46)
+    return ZH_ERR_ARCHIVE_EOF;
 
   // :257-268 an archive may sit at the end of another file: find the first central header by
   // counting signatures backwards from the EOCD; any failure keeps the recorded start
@@ -174,7 +183,7 @@ extern "C" int zh_zip_open(const void* archive, size_t len, zh_zip_reader** out)
   std::unordered_set<std::string> seen;
   int status = ZH_OK;
   for (int64_t k = 0; k < num_records && status == ZH_OK; k++) {  // :275-361
-    if (pos < 0 || pos + 46 > im.size) { status = ZH_ERR_ARCHIVE_EOF; break; }
+    if (!im.has(pos, 46)) { status = ZH_ERR_ARCHIVE_EOF; break; }
     if (im.u32(pos) != kCentralSig) { status = ZH_ERR_ZIP_CENTRAL_HEADER; break; }
     const uint16_t flags = im.u16(pos + 8), method = im.u16(pos + 10);
     const uint32_t crc = im.u32(pos + 16);
@@ -185,7 +194,7 @@ extern "C" int zh_zip_open(const void* archive, size_t len, zh_zip_reader** out)
     if (file_disk != 0) { status = ZH_ERR_ZIP_DISK_NUMBER; break; }
     int64_t csize = im.u32(pos + 20), usize = im.u32(pos + 24), hoff = im.u32(pos + 42);
     pos += 46;
-    if (pos + name_len > im.size) { status = ZH_ERR_ARCHIVE_EOF; break; }
+    if (!im.has(pos, name_len)) { status = ZH_ERR_ARCHIVE_EOF; break; }
     const std::string raw((const char*)im.p + pos, (size_t)name_len);
     if (seen.count(raw)) { status = ZH_ERR_ZIP_DUPLICATE; break; }
     pos += name_len;
@@ -195,7 +204,7 @@ extern "C" int zh_zip_open(const void* archive, size_t len, zh_zip_reader** out)
       // kept as is: every common writer (and createZipArchive) puts it first.
       int64_t cursor = pos;
       while (cursor < pos + extra_len) {
-        if (pos + 4 > im.size) { status = ZH_ERR_ARCHIVE_EOF; break; }
+        if (!im.has(pos, 4)) { status = ZH_ERR_ARCHIVE_EOF; break; }
         const uint16_t id = im.u16(pos);
         const int64_t flen = im.u16(pos + 2);
         cursor += 4;
@@ -206,7 +215,7 @@ extern "C" int zh_zip_open(const void* archive, size_t len, zh_zip_reader** out)
         int64_t at = cursor;
         const int64_t fend = cursor + flen;
         auto take64 = [&](int64_t& v) {
-          if (at + 8 > fend || at + 8 > im.size) { status = ZH_ERR_ARCHIVE_EOF; return; }
+          if (at > fend - 8 || !im.has(at, 8)) { status = ZH_ERR_ARCHIVE_EOF; return; }
           v = (int64_t)im.u64(at);
           at += 8;
         };
@@ -217,13 +226,18 @@ extern "C" int zh_zip_open(const void* archive, size_t len, zh_zip_reader** out)
       }
       if (status != ZH_OK) break;
     }
-    pos += extra_len + comment_len;
+    pos += extra_len + comment_len;  // (pos <= size + 3 * 65535: no overflow)
     if (pos > socd_offset + cd_start + cd_size) { status = ZH_ERR_ZIP_CENTRAL_SIZE; break; }
+    // sizes and offsets no image can hold (or above INT64_MAX): the entry is kept, as the
+    // reference keeps it, but can only fail with "end of archive" when it is extracted
+    if (hoff < 0 || hoff > im.size) hoff = -1;
+    if (csize < 0 || csize > im.size) csize = -1;
+    if (usize < 0) usize = -1;
 
     Record rec;
     rec.path = (flags & 0x0800) ? raw : utf8ify(raw);  // :345-350 language-encoding flag
     rec.directory = (external & 0x10u) != 0 || (external & (0x4000u << 16)) != 0 || ends_with_slash(rec.path);
-    rec.header_offset = hoff + socd_offset;
+    rec.header_offset = hoff < 0 ? -1 : hoff + socd_offset;
     rec.crc = crc;
     rec.compressed_size = csize;
     rec.uncompressed_size = usize;
@@ -284,11 +298,11 @@ extern "C" int zh_zip_extract_batch(zh_ctx* ctx, const zh_zip_reader* r, const s
     if (indices[k] >= r->records.size()) { statuses[k] = ZH_ERR_ZIP_NO_RECORD; continue; }
     const Record& rec = r->records[indices[k]];
     int64_t pos = rec.header_offset;
-    if (pos < 0 || pos + kFileHeaderLen > im.size) { statuses[k] = ZH_ERR_ARCHIVE_EOF; continue; }
+    if (!im.has(pos, kFileHeaderLen)) { statuses[k] = ZH_ERR_ARCHIVE_EOF; continue; }
     if (im.u32(pos) != kFileHeaderSig) { statuses[k] = ZH_ERR_ZIP_FILE_HEADER; continue; }
     const uint16_t method = im.u16(pos + 8);  // the LOCAL header's method decides (:62)
     pos += kFileHeaderLen + im.u16(pos + 26) + im.u16(pos + 28);
-    if (rec.compressed_size < 0 || pos + rec.compressed_size > im.size) { statuses[k] = ZH_ERR_ARCHIVE_EOF; continue; }
+    if (rec.uncompressed_size < 0 || !im.has(pos, rec.compressed_size)) { statuses[k] = ZH_ERR_ARCHIVE_EOF; continue; }
     if (rec.directory) { statuses[k] = ZH_ERR_ZIP_NO_RECORD; continue; }
     want_crc[k] = rec.crc;
     if (method == 0) {
@@ -299,7 +313,9 @@ extern "C" int zh_zip_extract_batch(zh_ctx* ctx, const zh_zip_reader* r, const s
       deflated.push_back(k);
       d_src.push_back(im.p + pos);
       d_len.push_back((size_t)rec.compressed_size);
-      d_hint.push_back((uint64_t)rec.uncompressed_size);
+      // (deflate cannot expand beyond 1032:1; a hint above that is a damaged directory and only
+      // costs the sized retry)
+      d_hint.push_back((uint64_t)std::min<int64_t>(rec.uncompressed_size, rec.compressed_size * 1032 + 1024));
     } else {
       statuses[k] = ZH_ERR_ZIP_METHOD;
     }
