@@ -3,19 +3,30 @@
 
   metric   : GiB/s of UNCOMPRESSED data through compress(BestSpeed, gzip) followed
              by uncompress(gzip, CRC verified), value = N_total / (T_compress + T_uncompress)
-  workload : 4096 x 1 MiB synthetic "Silesia-mix" buffers per GPU,
-             inputs resident in HBM when the timed region starts
+  workload : 4096 x 1 MiB synthetic "Silesia-mix" buffers, inputs resident
+             in HBM when the timed region starts
   step     : one compress pass + one uncompress pass over the whole batch
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--buffers 4096] [--size 1048576]
+                    [--scaling strong|weak] [--level 1] [--foreign LEVEL] [--uncompress-only]
 
-N > 1 is launched by torch.distributed.run (one process per GPU).  The path has no
-exchange step (buffers are independent), so ranks run their own shard
-(weak scaling) and only the barrier + max-over-ranks timing go through RCCL.
+One process per GPU.  N > 1 is launched by `python -m torch.distributed.run` (the driver does
+that itself; a plain `python bench.py --gpus N` re-executes itself under it) and fails loudly
+when the box has fewer than N GPUs.  The path has no exchange step (buffers are independent,
+zippy.nim:11-16):
+  --scaling strong (default for N > 1): the batch of --buffers buffers is sharded over the ranks
+      by contiguous index ranges (zippy_amd/sharding.py shard_range) -- BASELINE.json's
+      "4096 x 1 MiB on 8 GPUs";
+  --scaling weak: every rank runs --buffers buffers of its own.
+The timed region has no data-path collective (barrier + max-over-ranks only).  For N > 1 a
+separate, separately reported leg moves the batch from and to rank 0 over RCCL
+(scatter_fixed / gather_variable / scatter_variable / gather_fixed): `transfer`.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -25,66 +36,114 @@ sys.path.insert(0, ROOT)
 
 GIB = float(1 << 30)
 HBM_PEAK = 8.0e12  # bytes/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+HBM_COPY_PEAK = 6.29e12  # bytes/s, the guide's measured copy rate
 
 
-def cpu_baseline(bufs, level, cores):
-    """The oracle (C restatement of zippy, oracle/zippy_oracle.c) timed on the host
-    cores: compress(level, gzip) + uncompress, one buffer per task."""
+def source_sha():
+    """Fingerprint of the kernel sources: profiles/hbm_traffic.json carries the one it was
+    measured with, and its numbers are only quoted for the same sources (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "zippy_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def _stats(times, nbytes):
+    avg = sum(times) / len(times)
+    sd = math.sqrt(sum((t - avg) ** 2 for t in times) / len(times))
+    return {"min_ms": round(min(times) * 1e3, 3), "avg_ms": round(avg * 1e3, 3), "sd_ms": round(sd * 1e3, 3),
+            "GiBps_at_min": round(nbytes / GIB / min(times), 4), "GiBps_at_avg": round(nbytes / GIB / avg, 4)}
+
+
+def cpu_baseline(bufs, level, cores, reps=10):
+    """The oracle (C restatement of zippy, oracle/zippy_oracle.c) timed on the host cores the way
+    the reference times itself (tests/bench.nim:27-28,63-64 with benchy: warm-up, >= 10 repetitions,
+    min / avg / sd): compress(level, gzip) and uncompress (CRC verified), one buffer per task, on
+    1 thread and on `cores` threads; system zlib at the matching level as the second yardstick
+    (tests/bench.nim:30-34,66-70)."""
+    import zlib
     import oracle
     from concurrent.futures import ThreadPoolExecutor
     oracle.lib()
-
-    def comp(b):
-        return oracle.compress(b, level, oracle.dfGzip, fname_len=0)
-
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(comp, bufs[:cores]))  # warm-up
-        t0 = time.perf_counter()
-        blobs = list(ex.map(comp, bufs))
-        t1 = time.perf_counter()
-        outs = list(ex.map(oracle.uncompress, blobs))
-        t2 = time.perf_counter()
-    assert outs[0] == bufs[0]
-    nbytes = sum(len(b) for b in bufs)
-    # second yardstick (SURVEY.md 8d, the reference's own tests/bench.nim does the same): system zlib
-    # on the same sample and threads (zlib releases the GIL)
-    import zlib
     zl = 1 if level == 1 else 6 if level == -1 else max(0, min(9, level))
-    with ThreadPoolExecutor(cores) as ex:
-        t3 = time.perf_counter()
-        zblobs = list(ex.map(lambda b: zlib.compress(b, zl), bufs))
-        t4 = time.perf_counter()
-        list(ex.map(zlib.decompress, zblobs))
-        t5 = time.perf_counter()
+
+    def leg(sample, threads):
+        nbytes = sum(len(b) for b in sample)
+        out = {}
+        with ThreadPoolExecutor(threads) as ex:
+            for tag, comp, unc in (("oracle", lambda b: oracle.compress(b, level, oracle.dfGzip, fname_len=0),
+                                    oracle.uncompress),
+                                   ("zlib", lambda b: zlib.compress(b, zl), zlib.decompress)):
+                blobs = list(ex.map(comp, sample))  # warm-up
+                assert unc(blobs[0]) == sample[0]
+                tc, tu = [], []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    blobs = list(ex.map(comp, sample))
+                    t1 = time.perf_counter()
+                    list(ex.map(unc, blobs))
+                    t2 = time.perf_counter()
+                    tc.append(t1 - t0)
+                    tu.append(t2 - t1)
+                out[tag] = {"compress": _stats(tc, nbytes), "uncompress": _stats(tu, nbytes),
+                            "both_GiBps_at_avg": round(nbytes / GIB / (sum(tc) / reps + sum(tu) / reps), 4),
+                            "ratio": round(nbytes / sum(len(z) for z in blobs), 4)}
+        out["threads"] = threads
+        out["sample_bytes"] = nbytes
+        return out
+
+    one = leg(bufs[:max(1, min(len(bufs), (8 << 20) // max(1, len(bufs[0]))))], 1)
+    many = leg(bufs, cores)
     return {
-        "value": nbytes / GIB / (t2 - t0),
+        "value": many["oracle"]["both_GiBps_at_avg"],
         "unit": "GiB/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d x %d B of the same G-mix batch, oracle compress(level %d, gzip)+uncompress, "
-                  "%d threads; compress %.3f GiB/s, uncompress %.3f GiB/s" % (
-                      len(bufs), len(bufs[0]), level, cores, nbytes / GIB / (t1 - t0),
-                      nbytes / GIB / (t2 - t1)),
-        "zlib": {"level": zl, "compress_GiBps": round(nbytes / GIB / (t4 - t3), 3),
-                 "uncompress_GiBps": round(nbytes / GIB / (t5 - t4), 3),
-                 "both_GiBps": round(nbytes / GIB / (t5 - t3), 3),
-                 "ratio": round(nbytes / sum(len(z) for z in zblobs), 4)},
+        "sample": "%d x %d B of the same G-mix batch (1 thread: %d B), oracle = C restatement of zippy: "
+                  "compress(level %d, gzip) + uncompress(CRC verified), one buffer per task, %d repetitions "
+                  "after a warm-up; value = uncompressed bytes / (avg compress + avg uncompress) on %d threads" % (
+                      len(bufs), len(bufs[0]), one["sample_bytes"], level, reps, cores),
+        "value_1_thread": one["oracle"]["both_GiBps_at_avg"],
+        "all_cores": many,
+        "one_thread": one,
+        "zlib_level": zl,
     }
 
 
-def hbm_traffic(kernel, n, size):
-    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/
+def hbm_traffic(n, size):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
     (tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs of this same command, units and
-    gfx950 corrections as the MI355X guide prescribes); None when no pass matches this workload."""
+    gfx950 corrections as the MI355X guide prescribes).  Quoted only when the file was taken with
+    THESE kernel sources and this workload; otherwise {} (-> "traffic": null)."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as fh:
             t = json.load(fh)
-        if t.get("buffers") == n and t.get("buffer_bytes") == size:
-            return t["kernels"][kernel]["hbm_bytes_per_launch"]
+        if t.get("buffers") == n and t.get("buffer_bytes") == size and t.get("source_sha") == source_sha():
+            return {k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()}
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return {}
+
+
+def relaunch_under_torchrun(args):
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: this box has %d GPU(s); refusing to report a %d-GPU number "
+                         "from fewer devices" % (args.gpus, have, args.gpus))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
@@ -95,8 +154,21 @@ def main():
     ap.add_argument("--buffers", type=int, default=4096)
     ap.add_argument("--size", type=int, default=1 << 20)
     ap.add_argument("--level", type=int, default=1)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default=None)
+    ap.add_argument("--foreign", type=int, default=None, metavar="ZLIB_LEVEL",
+                    help="uncompress streams made by system zlib at this level (multi-block, foreign "
+                         "Huffman tables) instead of this library's own output; implies --uncompress-only")
+    ap.add_argument("--uncompress-only", action="store_true",
+                    help="BASELINE config 3: time only the uncompress pass (inflate + CRC-32)")
+    ap.add_argument("--compress-only", action="store_true", help="BASELINE configs 2/4: time only the compress pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-transfer", action="store_true", help="skip the RCCL scatter/gather leg (N > 1)")
     args = ap.parse_args()
+    if args.foreign is not None:
+        args.uncompress_only = True
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)
 
     import numpy as np
     import torch
@@ -105,22 +177,35 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch one rank per GPU" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (zippy_amd has no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     # under torchrun the collective path is used even with one rank (exercises it on a 1-GPU box)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus
 
-    from zippy_amd import api, synth
+    from zippy_amd import api, sharding, synth
     from zippy_amd._binding import Engine
 
-    n, size = args.buffers, args.size
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    size = args.size
+    if scaling == "strong":
+        lo, hi = sharding.shard_range(args.buffers, rank, world)
+        total_buffers = args.buffers
+    else:
+        lo, hi = rank * args.buffers, (rank + 1) * args.buffers
+        total_buffers = args.buffers * world
+    n = hi - lo
     # ---- synthetic batch (this rank's shard), staged into HBM ----
     t_gen = time.perf_counter()
-    host = synth.gen_batch("mix", n, size, first_index=rank * n)
+    host = synth.gen_batch("mix", n, size, first_index=lo)
     t_gen = time.perf_counter() - t_gen
     d_src = torch.from_numpy(host.reshape(-1)).cuda()
     stream = torch.cuda.current_stream()
@@ -134,13 +219,32 @@ def main():
     src_off = [i * size for i in range(n)]
     comp_off = [i * slot for i in range(n)]
     cplan = eng.plan_compress(src_off, [size] * n, comp_off, [cap] * n, args.level, api.dfGzip)
-    uplan = eng.plan_uncompress(comp_off, [cap] * n, src_off, [size] * n, api.dfGzip)
-    uplan.set_src_lens_device(cplan.device_lens())
+    if args.foreign is not None:
+        # config 3's foreign set: gzip members made by system zlib (multi-block dynamic streams)
+        import zlib
+        blobs = []
+        for i in range(n):
+            c = zlib.compressobj(args.foreign, zlib.DEFLATED, 31)
+            blobs.append(c.compress(host[i].tobytes()) + c.flush())
+        comp_lens = [len(b) for b in blobs]
+        assert max(comp_lens) <= cap
+        stage = np.zeros((n, slot), dtype=np.uint8)
+        for i, b in enumerate(blobs):
+            stage[i, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+        d_comp.copy_(torch.from_numpy(stage.reshape(-1)))
+        uplan = eng.plan_uncompress(comp_off, comp_lens, src_off, [size] * n, api.dfGzip)
+        del stage, blobs
+    else:
+        uplan = eng.plan_uncompress(comp_off, [cap] * n, src_off, [size] * n, api.dfGzip)
+        uplan.set_src_lens_device(cplan.device_lens())
     cplan.set_profiling(True)
     uplan.set_profiling(True)
+    do_c = not args.uncompress_only
+    do_u = not args.compress_only
 
-    def step():
-        cplan.run(d_src.data_ptr(), d_comp.data_ptr())
+    def step():  # warm-up passes always go both ways: the round trip is verified before timing
+        if args.foreign is None:
+            cplan.run(d_src.data_ptr(), d_comp.data_ptr())
         uplan.run(d_comp.data_ptr(), d_back.data_ptr())
 
     for _ in range(max(args.warmup, 1)):  # at least one untimed pass: its results are verified below
@@ -148,17 +252,20 @@ def main():
     torch.cuda.synchronize()
 
     # ---- correctness of what is about to be timed ----
-    clens, csts = cplan.results()
+    if args.foreign is None:
+        clens, csts = cplan.results()
+        assert all(s == 0 for s in csts), "compress statuses"
+        comp_total = sum(clens)
+    else:
+        comp_total = sum(comp_lens)
     ulens, usts = uplan.results()
-    assert all(s == 0 for s in csts), "compress statuses"
     assert all(s == 0 for s in usts), "uncompress statuses (CRC-32 / ISIZE verified on device)"
     assert ulens == [size] * n
     assert torch.equal(d_back, d_src), "round trip mismatch"
-    comp_total = sum(clens)
 
     # ---- timed region ----
     kernel_ms = {}
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     t_comp = t_unc = 0.0
     if use_dist:
         dist.barrier()
@@ -166,35 +273,63 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ev[0].record(stream)
-        cplan.run(d_src.data_ptr(), d_comp.data_ptr())
+        if do_c:
+            cplan.run(d_src.data_ptr(), d_comp.data_ptr())
         ev[1].record(stream)
-        uplan.run(d_comp.data_ptr(), d_back.data_ptr())
+        if do_u:
+            uplan.run(d_comp.data_ptr(), d_back.data_ptr())
         ev[2].record(stream)
         ev[2].synchronize()
         t_comp += ev[0].elapsed_time(ev[1])
         t_unc += ev[1].elapsed_time(ev[2])
-        for name, ms in cplan.kernel_times() + uplan.kernel_times():
+        for name, ms in (cplan.kernel_times() if do_c else []) + (uplan.kernel_times() if do_u else []):
             kernel_ms.setdefault(name, []).append(ms)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    comp_all = comp_total
     if use_dist:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed, t_comp, t_unc], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, t_comp, t_unc = (float(x) for x in t.tolist())
+        c = torch.tensor([comp_total], device="cuda", dtype=torch.int64)
+        dist.all_reduce(c)
+        comp_all = int(c.item())
 
-    total_uncompressed = n * size * world
+    total_uncompressed = total_buffers * size
     value = total_uncompressed * args.steps / GIB / elapsed
     ms_per_step = elapsed * 1e3 / args.steps
+
+    # ---- N > 1: the batch lives on rank 0 and comes home to rank 0 (RCCL over xGMI) ----
+    transfer = None
+    if use_dist and scaling == "strong" and not args.no_transfer and do_c and do_u:
+        transfer = transfer_leg(torch, dist, sharding, synth, rank, world, args.buffers, size, slot, lo, hi,
+                                d_src, d_comp, d_back, cplan, uplan, stream, t_comp / args.steps,
+                                t_unc / args.steps)
 
     if rank == 0:
         avg = {k: sum(v) / len(v) for k, v in kernel_ms.items()}
         dom = max((k for k in avg if k.startswith("zh_")), key=lambda k: avg[k])
-        # algorithmic bytes per launch of the batch: every uncompressed byte read (compress)
-        # or written (uncompress) once, every compressed byte written or read once
-        algo_bytes = n * size + comp_total
-        achieved = algo_bytes / (avg[dom] * 1e-3)
+        # Algorithmic bytes of this rank's shard: a pass moves every uncompressed byte
+        # once and every compressed byte once (N + C); a kernel is charged what IT must move:
+        # matcher N (reads the source), emit N + C, inflate C + N, checksum N.
+        N, C = n * size, comp_total
+        own = {"zh_l1_match_kernel": N, "zh_chain_search_kernel": N, "zh_emit_kernel": N + C,
+               "zh_inflate_kernel": N + C, "zh_checksum_pieces_kernel": N}
+        traffic = hbm_traffic(n, size)
+
+        def roof(nbytes, ms, name=None):
+            a = nbytes / (ms * 1e-3)
+            r = {"bound": "hbm", "achieved": round(a / 1e9, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                 "frac": round(a / HBM_PEAK, 6), "frac_of_copy_peak": round(a / HBM_COPY_PEAK, 6),
+                 "traffic": traffic.get(name) if name else None,
+                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(ms, 4)}
+            if name:
+                r["kernel"] = name
+            return r
+
+        mode = "compress + uncompress" if do_c and do_u else "compress only" if do_c else "uncompress only"
         out = {
             "metric": "GiB/s uncompressed throughput (compress BestSpeed + uncompress), 4096x1 MiB batch",
             "value": round(value, 3),
@@ -204,37 +339,108 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic (G-mix: seeded slices of the reference's own test corpus, SURVEY.md 8d)",
             "config": {
-                "workload": "%d x %d B per GPU, compress level %d gzip + uncompress gzip (CRC-32 verified), "
-                            "buffers resident in HBM" % (n, size, args.level),
-                "buffers_per_gpu": n, "buffer_bytes": size, "level": args.level,
-                "sharding": "independent buffers per rank, no data-path collective",
+                "workload": "%d x %d B in total (%d on this rank), %s, level %d gzip%s, CRC-32 verified, "
+                            "buffers resident in HBM" % (
+                                total_buffers, size, n, mode, args.level,
+                                "" if args.foreign is None else "; streams made by system zlib level %d" % args.foreign),
+                "buffers_total": total_buffers, "buffers_per_gpu": n, "buffer_bytes": size, "level": args.level,
+                "sharding": "contiguous index ranges per rank (shard_range), no data-path collective",
             },
-            "compress_GiBps": round(n * size * args.steps / GIB / (t_comp * 1e-3), 3),
-            "uncompress_GiBps": round(n * size * args.steps / GIB / (t_unc * 1e-3), 3),
-            "ratio": round(n * size / comp_total, 4),
+            "compress_GiBps": round(total_uncompressed * args.steps / GIB / (t_comp * 1e-3), 3) if do_c else None,
+            "uncompress_GiBps": round(total_uncompressed * args.steps / GIB / (t_unc * 1e-3), 3) if do_u else None,
+            "ratio": round(total_uncompressed / comp_all, 4),
             "kernels_ms": {k: round(v, 4) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
-            "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 3),
-                "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 6),
-                "traffic": hbm_traffic(dom, n, size),
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "avg_launch_ms": round(avg[dom], 4),
-            },
+            "roofline": roof(own.get(dom, N + C), avg[dom], dom),
+            "roofline_passes": {},
+            "roofline_kernels": {k: roof(b, avg[k], k) for k, b in own.items() if k in avg},
+            "source_sha": source_sha(),
         }
+        if do_c:
+            out["roofline_passes"]["compress"] = roof(N + C, t_comp / args.steps)
+        if do_u:
+            out["roofline_passes"]["uncompress"] = roof(N + C, t_unc / args.steps)
+        if transfer:
+            out["transfer"] = transfer
+            out["value_incl_transfer"] = transfer["value_incl_transfer"]
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             cores = min(os.cpu_count() or 1, 32)
-            per_core = max(2, min(24, (16 << 20) // size * 2))
+            per_core = max(1, min(8, (4 << 20) // size))
             sample = [host[i].tobytes() for i in range(min(n, cores * per_core))]
             out["cpu_baseline"] = cpu_baseline(sample, args.level, cores)
         out["host_gen_s"] = round(t_gen, 1)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def transfer_leg(torch, dist, sharding, synth, rank, world, n_total, size, slot, lo, hi, d_src, d_comp, d_back,
+                 cplan, uplan, stream, t_comp_ms, t_unc_ms):
+    """The whole batch starts and ends on rank 0: raw buffers out (scatter_fixed), compressed
+    streams home (gather_variable), compressed streams out again (scatter_variable), raw results
+    home (gather_fixed).  Whole buffers only, point-to-point from / to the root over its xGMI
+    links; nothing is reduced.  Timed once after a warm-up pass, max over ranks."""
+    n = hi - lo
+    dev = d_src.device
+    whole = None
+    if rank == 0:
+        whole = torch.from_numpy(synth.gen_batch("mix", n_total, size).reshape(-1)).to(dev)
+
+    def timed(fn):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return r, float(t.item()) * 1e3
+
+    res = {}
+    for it in range(2):  # pass 0 warms RCCL's channels up
+        mine, res["scatter_raw_ms"] = timed(lambda: sharding.scatter_fixed(whole, n_total, size, root=0, device=dev))
+        assert torch.equal(mine, d_src)
+        cplan.run(mine.data_ptr(), d_comp.data_ptr())
+        clens, csts = cplan.results()
+        assert all(s == 0 for s in csts)
+        lens_t = torch.tensor(clens, dtype=torch.int64, device=dev)
+
+        def pack():
+            return torch.cat([d_comp[i * slot:i * slot + clens[i]] for i in range(n)]) if n else d_comp[:0]
+        packed, res["pack_ms"] = timed(pack)
+        (all_c, all_lens), res["gather_compressed_ms"] = timed(
+            lambda: sharding.gather_variable(packed, lens_t, root=0))
+        (mine_c, mine_lens), res["scatter_compressed_ms"] = timed(
+            lambda: sharding.scatter_variable(all_c, all_lens if rank == 0 else None, n_total, root=0, device=dev))
+        assert torch.equal(mine_c, packed) and mine_lens.tolist() == clens
+
+        def unpack():
+            off = 0
+            for i in range(n):
+                d_comp[i * slot:i * slot + clens[i]] = mine_c[off:off + clens[i]]
+                off += clens[i]
+        _, res["unpack_ms"] = timed(unpack)
+        uplan.run(d_comp.data_ptr(), d_back.data_ptr())
+        _, usts = uplan.results()
+        assert all(s == 0 for s in usts)
+        home, res["gather_raw_ms"] = timed(lambda: sharding.gather_fixed(d_back, n_total, size, root=0))
+        if rank == 0:
+            assert torch.equal(home, whole), "batch did not come home intact"
+        del home, all_c, mine_c, packed, mine
+    res = {k: round(v, 3) for k, v in res.items()}
+    res["scatter_ms"] = round(res["scatter_raw_ms"] + res["scatter_compressed_ms"], 3)
+    res["gather_ms"] = round(res["gather_compressed_ms"] + res["gather_raw_ms"], 3)
+    moved = sum(res[k] for k in ("scatter_raw_ms", "pack_ms", "gather_compressed_ms", "scatter_compressed_ms",
+                                 "unpack_ms", "gather_raw_ms"))
+    res["value_incl_transfer"] = round(n_total * size / GIB / ((t_comp_ms + t_unc_ms + moved) * 1e-3), 3)
+    res["note"] = ("batch on rank 0 -> shards -> compressed home -> compressed out -> raw home; "
+                   "value_incl_transfer = N_total / (T_compress + T_uncompress + all six transfer legs)")
+    return res
 
 
 if __name__ == "__main__":

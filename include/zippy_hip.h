@@ -124,6 +124,21 @@ int zh_compress_batch(zh_ctx *ctx, const void *const *srcs, const size_t *lens, 
 int zh_uncompress_batch(zh_ctx *ctx, const void *const *srcs, const size_t *lens, size_t n,
                         int data_format, void **dsts, size_t *dst_lens, int32_t *statuses);
 
+/* One batch over several GPUs of a node.  zippy's compress()/uncompress() are pure functions of
+ * one buffer (zippy.nim:11-16,100-104), so a batch shards by contiguous index ranges with no
+ * exchange step: context r (one per device, made with zh_create(r, NULL, &ctx[r])) takes range r
+ * of the batch -- the first n % n_ctx ranges hold one buffer more -- on its own host thread, and
+ * every result lands in the caller's arrays at its own index.  Same results as the
+ * single-context calls.  Contexts must be distinct; two contexts on ONE device are allowed
+ * (they share the GPU).  Returns the first failing shard's call status, else ZH_OK. */
+int zh_device_count(void);
+int zh_compress_batch_multi(zh_ctx *const *ctxs, size_t n_ctx, const void *const *srcs,
+                            const size_t *lens, size_t n, int level, int data_format, void **dsts,
+                            size_t *dst_lens, int32_t *statuses);
+int zh_uncompress_batch_multi(zh_ctx *const *ctxs, size_t n_ctx, const void *const *srcs,
+                              const size_t *lens, size_t n, int data_format, void **dsts,
+                              size_t *dst_lens, int32_t *statuses);
+
 /* Single-buffer forms (batch of 1); return the buffer's status. */
 int zh_compress(zh_ctx *ctx, const void *src, size_t len, int level, int data_format,
                 void **dst, size_t *dst_len);

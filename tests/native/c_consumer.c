@@ -124,6 +124,40 @@ int main(void) {
     zh_zip_close(rd);
     zh_free(zip);
   }
+  /* one batch over two contexts (two GPUs in production; here both on the current device): every
+   * result lands at its own index and equals the single-context result */
+  {
+    zh_ctx *pair[2] = {NULL, NULL};
+    void *one[N], *two[N], *rt[N];
+    size_t one_len[N], two_len[N], rt_len[N];
+    int32_t st2[N];
+    if (zh_device_count() < 1) return fail("zh_device_count", -1);
+    if ((rc = zh_create(-1, NULL, &pair[0])) != ZH_OK) return fail("zh_create (pair 0)", rc);
+    if ((rc = zh_create(-1, NULL, &pair[1])) != ZH_OK) return fail("zh_create (pair 1)", rc);
+    zh_set_gzip_fname_len(pair[0], 0);
+    zh_set_gzip_fname_len(pair[1], 0);
+    rc = zh_compress_batch(ctx, srcs, lens, N, 1, ZH_DF_GZIP, one, one_len, st);
+    if (rc != ZH_OK) return fail("zh_compress_batch (reference for multi)", rc);
+    rc = zh_compress_batch_multi(pair, 2, srcs, lens, N, 1, ZH_DF_GZIP, two, two_len, st2);
+    if (rc != ZH_OK) return fail("zh_compress_batch_multi", rc);
+    for (i = 0; i < N; i++) {
+      if (st2[i] != ZH_OK) return fail("multi compress status", st2[i]);
+      if (two_len[i] != one_len[i] || memcmp(two[i], one[i], one_len[i]) != 0) return fail("multi != single", -1);
+    }
+    rc = zh_uncompress_batch_multi(pair, 2, (const void *const *)two, two_len, N, ZH_DF_DETECT, rt, rt_len, st2);
+    if (rc != ZH_OK) return fail("zh_uncompress_batch_multi", rc);
+    for (i = 0; i < N; i++) {
+      if (st2[i] != ZH_OK) return fail("multi uncompress status", st2[i]);
+      if (rt_len[i] != lens[i] || memcmp(rt[i], text[i], lens[i]) != 0) return fail("multi round trip differs", -1);
+      zh_free(one[i]);
+      zh_free(two[i]);
+      zh_free(rt[i]);
+    }
+    pair[1] = pair[0];
+    if (zh_compress_batch_multi(pair, 2, srcs, lens, N, 1, ZH_DF_GZIP, two, two_len, st2) != ZH_ERR_ARGUMENT)
+      return fail("the same context twice must be refused", -1);
+    zh_destroy(pair[0]);
+  }
   zh_destroy(ctx);
   printf("c_consumer ok\n");
   return 0;

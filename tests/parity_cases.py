@@ -468,3 +468,38 @@ def check_unsized_streams(eng):
              zlib.compress(plain[7], 9), oracle.compress(plain[5], -1, oracle.dfGzip, fname_len=0)]
     outs, sts = eng.uncompress_batch(mixed)
     assert sts == [0, 0, 0, 0] and outs == [plain[3], text, plain[7], plain[5]]
+
+
+def check_plan_slots_with_gaps(eng, upload, download, alloc):
+    """Device plan API (include/zippy_hip.h): output slots at odd offsets with caller data
+    between them -- the slots are zeroed one by one and nothing outside them changes; the
+    streams equal the oracle's; a misaligned d_dst is refused.  upload(bytes) -> (ptr, keep),
+    alloc(n, fill) -> (ptr, keep), download(keep) -> bytes."""
+    import pytest
+    from zippy_amd.common import ZippyError
+    srcs = [synth.corpus_file("alice29.txt")[:50000], b"", synth.corpus_file("html")[:33000], b"x" * 70001]
+    src_off, pos = [], 0
+    for s in srcs:
+        src_off.append(pos)
+        pos += len(s)
+    d_src, keep_src = upload(b"".join(srcs) + b"\0" * 16)
+    caps = [len(s) + len(s) // 8 + 2048 for s in srcs]
+    dst_off, pos = [], 7
+    for i, c in enumerate(caps):
+        dst_off.append(pos)
+        pos += c + (101, 1000, 3, 513)[i]
+    total = pos + 64
+    d_dst, keep_dst = alloc(total, 0xAB)
+    plan = eng.plan_compress(src_off, [len(s) for s in srcs], dst_off, caps, 1, oracle.dfGzip)
+    plan.run(d_src, d_dst)
+    lens, sts = plan.results()
+    assert all(st == 0 for st in sts)
+    got = download(keep_dst)
+    inside = bytearray(total)
+    for s, o, c, ln in zip(srcs, dst_off, caps, lens):
+        assert got[o:o + ln] == oracle.compress(s, 1, oracle.dfGzip, fname_len=0)
+        assert got[o + ln:o + c] == b"\0" * (c - ln)  # the rest of a slot is zeroed
+        inside[o:o + c] = b"\1" * c
+    assert all(got[i] == 0xAB for i in range(total) if not inside[i]), "bytes outside the slots changed"
+    with pytest.raises(ZippyError):
+        plan.run(d_src, d_dst + 1)

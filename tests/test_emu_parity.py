@@ -118,3 +118,14 @@ def test_emu_ragged_staging(eng):
 
 def test_emu_unsized_streams(eng):
     pc.check_unsized_streams(eng)
+
+
+def test_emu_plan_slots_with_gaps(eng):
+    import ctypes
+    def upload(b):
+        buf = ctypes.create_string_buffer(b, len(b))
+        return ctypes.addressof(buf), buf
+    def alloc(n, fill):
+        buf = ctypes.create_string_buffer(bytes([fill]) * n, n)
+        return ctypes.addressof(buf), buf
+    pc.check_plan_slots_with_gaps(eng, upload, lambda keep: keep.raw, alloc)

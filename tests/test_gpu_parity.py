@@ -289,3 +289,14 @@ def test_gpu_device_api_unaligned_offsets(eng, golds):
     small.run(d_src.data_ptr(), d_dst.data_ptr())
     _, sts3 = small.results()
     assert sts3 == [0, 21, 0, 0]
+
+
+def test_gpu_plan_slots_with_gaps(eng):
+    import torch
+    def upload(b):
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+        return t.data_ptr(), t
+    def alloc(n, fill):
+        t = torch.full((n,), fill, dtype=torch.uint8, device="cuda")
+        return t.data_ptr(), t
+    pc.check_plan_slots_with_gaps(eng, upload, lambda t: t.cpu().numpy().tobytes(), alloc)

@@ -59,10 +59,19 @@ def _worker(rank, world, port, n_buffers, buf_bytes, result_path):
     assert all(s == 0 for s in sts)
     local = torch.from_numpy(np.frombuffer(b"".join(back) or b"\0", dtype=np.uint8).copy())
     lens = torch.tensor([len(o) for o in back], dtype=torch.int64)
-    data, all_lens = sharding.gather_variable(local, lens, root=0)
+    data2, all_lens2 = sharding.gather_variable(local, lens, root=0)
     if rank == 0:
-        ok &= data.numpy().tobytes() == batch.numpy().tobytes()
-        ok &= all_lens.tolist() == [buf_bytes] * n_buffers
+        ok &= data2.numpy().tobytes() == batch.numpy().tobytes()
+        ok &= all_lens2.tolist() == [buf_bytes] * n_buffers
+    # the uncompress direction of a batch that lives on rank 0: compressed streams go out with
+    # scatter_variable, results come home with gather_fixed
+    mine_c, mine_lens = sharding.scatter_variable(data, all_lens if rank == 0 else None, n_buffers, root=0)
+    assert mine_lens.tolist() == [len(o) for o in outs]
+    assert mine_c.numpy().tobytes() == b"".join(outs)
+    local = torch.from_numpy(np.frombuffer(b"".join(back) or b"\0", dtype=np.uint8).copy())
+    whole = sharding.gather_fixed(local, n_buffers, buf_bytes, root=0)
+    if rank == 0:
+        ok &= whole.numpy().tobytes() == batch.numpy().tobytes()
         with open(result_path, "w") as fh:
             fh.write("ok" if ok else "mismatch")
     dist.barrier()

@@ -14,7 +14,11 @@ and flagged as uncalibrated.
 """
 import argparse
 import json
+import os
 import sqlite3
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(db_path, counter):
@@ -37,7 +41,10 @@ def main():
     known = a.buffers * a.size
     calls, kib = fetch.get("zh_checksum_pieces_kernel", (0, 0))
     factor = known / (kib * 1024.0 / calls) if calls and kib else 2.0
+    from bench import source_sha
     out = {"buffers": a.buffers, "buffer_bytes": a.size,
+           # bench.py quotes these numbers only while the kernel sources are the ones measured
+           "source_sha": source_sha(),
            "fetch_correction_factor": round(factor, 4),
            "calibration": "zh_checksum_pieces_kernel reads buffers x size bytes once (dwordx4, coalesced)",
            "kernels": {}}

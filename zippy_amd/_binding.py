@@ -27,6 +27,15 @@ _SIGS = {
                                        _c.POINTER(_c.c_size_t), _c.c_size_t, _c.c_int,
                                        _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
                                        _c.POINTER(_c.c_int32)]),
+    "zh_device_count": (_c.c_int, []),
+    "zh_compress_batch_multi": (_c.c_int, [_c.POINTER(_c.c_void_p), _c.c_size_t, _c.POINTER(_c.c_void_p),
+                                           _c.POINTER(_c.c_size_t), _c.c_size_t, _c.c_int, _c.c_int,
+                                           _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
+                                           _c.POINTER(_c.c_int32)]),
+    "zh_uncompress_batch_multi": (_c.c_int, [_c.POINTER(_c.c_void_p), _c.c_size_t, _c.POINTER(_c.c_void_p),
+                                             _c.POINTER(_c.c_size_t), _c.c_size_t, _c.c_int,
+                                             _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
+                                             _c.POINTER(_c.c_int32)]),
     "zh_compress": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int,
                                _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t)]),
     "zh_uncompress": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int,

@@ -669,17 +669,20 @@ static void plan_set_count_only(zh_plan* plan, int on) { plan->ia.count_only = o
 // one range are cleared with a single memset; slots with gaps between them are cleared one by
 // one, byte-exact, so that caller data lying between two slots is never touched.
 __global__ __launch_bounds__(256) void zh_zero_slots_kernel(uint8_t* __restrict__ d_dst,
-                                                            const ZhBufDesc* __restrict__ bufs) {
-  const ZhBufDesc b = bufs[blockIdx.x];
+                                                            const ZhBufDesc* __restrict__ bufs,
+                                                            uint32_t parts) {
+  // `parts` workgroups share a slot
+  const uint32_t part = blockIdx.x % parts;
+  const ZhBufDesc b = bufs[blockIdx.x / parts];
   uint8_t* const base = d_dst + b.dst_off;
   const uint64_t cap = b.dst_cap;
   uint64_t head = (16u - ((uintptr_t)base & 15u)) & 15u;
   if (head > cap) head = cap;
   const uint64_t nvec = (cap - head) >> 4;
   uint4* const body = reinterpret_cast<uint4*>(base + head);
-  for (uint64_t i = (uint64_t)blockIdx.y * 256u + threadIdx.x; i < nvec; i += (uint64_t)gridDim.y * 256u)
+  for (uint64_t i = (uint64_t)part * 256u + threadIdx.x; i < nvec; i += (uint64_t)parts * 256u)
     body[i] = make_uint4(0, 0, 0, 0);
-  if (blockIdx.y == 0) {
+  if (part == 0) {
     if (threadIdx.x < head) base[threadIdx.x] = 0;
     const uint64_t t0 = head + (nvec << 4);
     if (t0 + threadIdx.x < cap) base[t0 + threadIdx.x] = 0;
@@ -705,7 +708,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       ZH_HIP(ctx, hipMemsetAsync(d_dst + p->dst_lo, 0, p->dst_hi - p->dst_lo, s));
     } else {
       const uint32_t gy = (uint32_t)std::min<uint64_t>(64, (p->dst_max_cap >> 16) + 1);
-      hipLaunchKernelGGL(zh_zero_slots_kernel, dim3((uint32_t)p->n, gy), dim3(256), 0, s, d_dst, p->d_bufs);
+      hipLaunchKernelGGL(zh_zero_slots_kernel, dim3((uint32_t)p->n * gy), dim3(256), 0, s, d_dst, p->d_bufs, gy);
     }
     if (p->level == 1 || p->level == -2) {
       prof_mark(p, "zh_l1_match_kernel");
@@ -1480,6 +1483,63 @@ extern "C" int zh_uncompress_batch_sized(zh_ctx* ctx, const void* const* srcs, c
                                          void** dsts, size_t* dst_lens, int32_t* statuses,
                                          uint32_t* crcs) {
   return uncompress_batch_impl(ctx, srcs, lens, n, data_format, size_hints, dsts, dst_lens, statuses, crcs);
+}
+
+// ---- one batch over several contexts (= several GPUs): contiguous index ranges, one host
+// thread per context, no exchange between them (a buffer is a pure function of itself,
+// zippy.nim:11-16).  Range r of n over k: the first n % k ranges get one buffer more -- the
+// same split as zippy_amd/sharding.py shard_range.
+extern "C" int zh_device_count(void) {
+  int count = 0;
+  return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
+
+template <class Fn>
+static int run_sharded(zh_ctx* const* ctxs, size_t n_ctx, size_t n, Fn&& fn) {
+  if (!ctxs || !n_ctx) return ZH_ERR_ARGUMENT;
+  for (size_t r = 0; r < n_ctx; r++) {
+    if (!ctxs[r]) return ZH_ERR_ARGUMENT;
+    for (size_t q = 0; q < r; q++)
+      if (ctxs[q] == ctxs[r]) return ZH_ERR_ARGUMENT;  // a context serves one thread at a time
+  }
+  std::vector<int> rc(n_ctx, ZH_OK);
+  auto shard = [&](size_t r) {
+    const size_t base = n / n_ctx, extra = n % n_ctx;
+    const size_t lo = r * base + std::min(r, extra), cnt = base + (r < extra ? 1 : 0);
+    if (cnt) rc[r] = fn(ctxs[r], lo, cnt);
+  };
+#ifdef ZH_EMU
+  for (size_t r = 0; r < n_ctx; r++) shard(r);  // (the emulator's fibers live on one thread)
+#else
+  std::vector<std::thread> th;
+  for (size_t r = 1; r < n_ctx; r++) th.emplace_back(shard, r);
+  shard(0);
+  for (auto& t : th) t.join();
+#endif
+  for (int v : rc)
+    if (v != ZH_OK) return v;
+  return ZH_OK;
+}
+
+extern "C" int zh_compress_batch_multi(zh_ctx* const* ctxs, size_t n_ctx, const void* const* srcs,
+                                       const size_t* lens, size_t n, int level, int data_format,
+                                       void** dsts, size_t* dst_lens, int32_t* statuses) {
+  if (n && (!srcs || !lens || !dsts || !dst_lens || !statuses)) return ZH_ERR_ARGUMENT;
+  for (size_t i = 0; i < n; i++) dsts[i] = nullptr;
+  return run_sharded(ctxs, n_ctx, n, [&](zh_ctx* c, size_t lo, size_t cnt) {
+    return zh_compress_batch(c, srcs + lo, lens + lo, cnt, level, data_format, dsts + lo, dst_lens + lo,
+                             statuses + lo);
+  });
+}
+extern "C" int zh_uncompress_batch_multi(zh_ctx* const* ctxs, size_t n_ctx, const void* const* srcs,
+                                         const size_t* lens, size_t n, int data_format, void** dsts,
+                                         size_t* dst_lens, int32_t* statuses) {
+  if (n && (!srcs || !lens || !dsts || !dst_lens || !statuses)) return ZH_ERR_ARGUMENT;
+  for (size_t i = 0; i < n; i++) dsts[i] = nullptr;
+  return run_sharded(ctxs, n_ctx, n, [&](zh_ctx* c, size_t lo, size_t cnt) {
+    return zh_uncompress_batch(c, srcs + lo, lens + lo, cnt, data_format, dsts + lo, dst_lens + lo,
+                               statuses + lo);
+  });
 }
 
 extern "C" int zh_compress(zh_ctx* ctx, const void* src, size_t len, int level, int data_format,

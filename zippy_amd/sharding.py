@@ -77,3 +77,59 @@ def gather_variable(local_bytes, local_lens, root=0, group=None):
     for w in (dist.batch_isend_irecv(ops) if ops else []):
         w.wait()
     return out, lens
+
+
+def gather_fixed(local, n_buffers, buf_bytes, root=0, group=None):
+    """Inverse of scatter_fixed: every rank holds its shard (uint8 [(hi-lo) * buf_bytes]); root
+    gets the whole batch in buffer order (elsewhere None).  One receive per peer, all in flight."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(n_buffers, rank, world)
+    if rank != root:
+        if hi > lo:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local[:(hi - lo) * buf_bytes], root, group)]):
+                w.wait()
+        return None
+    out = torch.empty(n_buffers * buf_bytes, dtype=torch.uint8, device=local.device)
+    ops = []
+    for r in range(world):
+        rlo, rhi = shard_range(n_buffers, r, world)
+        if r == root:
+            out[rlo * buf_bytes:rhi * buf_bytes] = local[:(rhi - rlo) * buf_bytes]
+        elif rhi > rlo:
+            ops.append(dist.P2POp(dist.irecv, out[rlo * buf_bytes:rhi * buf_bytes], r, group))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    return out
+
+
+def scatter_variable(batch_bytes, lens, n_buffers, root=0, group=None, device=None):
+    """Inverse of gather_variable: root holds the buffers of the whole batch back to back in
+    `batch_bytes` (uint8) with `lens` (int64 tensor [n_buffers]); every rank gets
+    (its shard's bytes back to back, its shard's lens).  The lengths travel in one broadcast, the
+    payloads in one send per peer."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if rank != root:
+        lens = torch.zeros(n_buffers, dtype=torch.int64, device=device)
+    dist.broadcast(lens, src=root, group=group)
+    ends = torch.cumsum(lens, 0).cpu()
+    def span(r):
+        rlo, rhi = shard_range(n_buffers, r, world)
+        b0 = int(ends[rlo - 1]) if rlo else 0
+        b1 = int(ends[rhi - 1]) if rhi else 0
+        return rlo, rhi, b0, b1
+    lo, hi, b0, b1 = span(rank)
+    if rank == root:
+        ops = []
+        for r in range(world):
+            _, _, r0, r1 = span(r)
+            if r != root and r1 > r0:
+                ops.append(dist.P2POp(dist.isend, batch_bytes[r0:r1], r, group))
+        mine = batch_bytes[b0:b1].clone()
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return mine, lens[lo:hi]
+    mine = torch.empty(b1 - b0, dtype=torch.uint8, device=device)
+    if b1 > b0:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, mine, root, group)]):
+            w.wait()
+    return mine, lens[lo:hi]
