@@ -94,6 +94,12 @@ void *zh_stream(zh_ctx *ctx);           /* the hipStream_t work is enqueued on *
  * reference; 0..25: fixed (deterministic output for tests). */
 void zh_set_gzip_fname_len(zh_ctx *ctx, int k);
 
+/* Which inflate kernels later uncompress calls of this context use (no reference counterpart;
+ * same results either way): 0 = a stream's Huffman codes decoded in parallel, then one writer
+ * per stream (csrc/zh_inflate_split.hip); 1 = the two-wave serial decoder (csrc/zh_inflate.hip);
+ * < 0 = the default (0, or the ZH_INFLATE=serial environment variable). */
+void zh_set_inflate_mode(zh_ctx *ctx, int mode);
+
 /* Host-buffer compress calls of at least min_batch_bytes of input run as pipelined groups of
  * about group_bytes each: one group's kernels overlap the neighbours' transfers (no reference
  * counterpart; the results are the same bytes either way).  0 = default (1 GiB / 512 MiB, or the

@@ -15,7 +15,15 @@ def eng():
     return emu.engine()
 
 
-def test_emu_fixtures_decode(eng):
+@pytest.fixture(params=[0, 1], ids=["split", "serial"])
+def inflate_mode(request, eng):
+    """Both inflate paths (zh_inflate_split.hip, zh_inflate.hip) against the same expectations."""
+    eng.set_inflate_mode(request.param)
+    yield request.param
+    eng.set_inflate_mode(-1)
+
+
+def test_emu_fixtures_decode(eng, inflate_mode):
     pc.check_fixtures(eng, max_len=130000)
 
 
@@ -57,7 +65,7 @@ def test_emu_block_parallel_form(eng):
     pc.check_blocks_bad_index(eng, src)
 
 
-def test_emu_zip_archives(eng):
+def test_emu_zip_archives(eng, inflate_mode):
     # tests/test_ziparchives_read.nim / _write.nim through the batch clients
     assert pc.check_zip_extract(eng, pc.zip_fixture("cat.jpg")) == 3
     image = pc.zip_fixture("Bagnon-10.2.31.zip")
@@ -68,7 +76,7 @@ def test_emu_zip_archives(eng):
     pc.check_zip_errors(eng)
 
 
-def test_emu_tarballs(eng):
+def test_emu_tarballs(eng, inflate_mode):
     # tests/test_tarballs_read.nim in small (the 20 MB fixture itself runs on the GPU)
     files = [("a.txt", b"hello"), ("d", None), ("d/b.bin", synth.corpus_file("html")[:30000])]
     assert pc.check_tarball(eng, pc.make_tar_gz(files, "d/" + "y" * 140 + ".txt")) == 5
@@ -77,7 +85,7 @@ def test_emu_tarballs(eng):
     pc.check_tar_errors(eng)
 
 
-def test_emu_roundtrip_and_random_fname(eng):
+def test_emu_roundtrip_and_random_fname(eng, inflate_mode):
     bufs = [b.tobytes() for b in synth.gen_batch("mix", 4, 65536)]
     pc.check_roundtrip(eng, bufs, 1)
     pc.check_gzip_random_fname(eng, bufs[0][:5000])
@@ -89,12 +97,12 @@ def test_emu_checksums(eng):
                                                                       32768, 32769, 100001)])
 
 
-def test_emu_damaged_streams(eng):
+def test_emu_damaged_streams(eng, inflate_mode):
     pc.check_errors_match_oracle(eng, pc.mutated_fixtures(60, seed=99, max_len=40000))
     pc.check_error_statuses(eng)
 
 
-def test_emu_zlib_and_raw_need_sizing_pass(eng):
+def test_emu_zlib_and_raw_need_sizing_pass(eng, inflate_mode):
     import zlib
     src = synth.corpus_file("alice29.txt")[:60000]
     for wb, fmt in ((15, oracle.dfDetect), (15, oracle.dfZlib), (-15, oracle.dfDeflate)):
@@ -116,7 +124,7 @@ def test_emu_ragged_staging(eng):
     pc.check_ragged_staging(eng, 1)
 
 
-def test_emu_unsized_streams(eng):
+def test_emu_unsized_streams(eng, inflate_mode):
     pc.check_unsized_streams(eng)
 
 

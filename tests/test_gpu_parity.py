@@ -24,7 +24,15 @@ def eng():
     return e
 
 
-def test_gpu_fixtures_decode(eng):
+@pytest.fixture(params=[0, 1], ids=["split", "serial"])
+def inflate_mode(request, eng):
+    """Both inflate paths (zh_inflate_split.hip, zh_inflate.hip) against the same expectations."""
+    eng.set_inflate_mode(request.param)
+    yield request.param
+    eng.set_inflate_mode(-1)
+
+
+def test_gpu_fixtures_decode(eng, inflate_mode):
     pc.check_fixtures(eng)
 
 
@@ -103,7 +111,7 @@ def test_gpu_level1_identical_at_scale(eng):
     assert all(s == 0 for s in sts) and back == bufs
 
 
-def test_gpu_unsized_streams(eng):
+def test_gpu_unsized_streams(eng, inflate_mode):
     pc.check_unsized_streams(eng)
 
 
@@ -170,7 +178,7 @@ def test_gpu_block_parallel_levels_and_bad_index(eng, golds):
     pc.check_blocks_bad_index(eng, src)
 
 
-def test_gpu_zip_archives(eng, golds):
+def test_gpu_zip_archives(eng, golds, inflate_mode):
     """the reference's archive fixtures through the batch clients, and
     createZipArchive of a few hundred entries in one compress batch."""
     assert pc.check_zip_extract(eng, pc.zip_fixture("cat.jpg")) == 3
@@ -188,7 +196,7 @@ def test_gpu_zip_archives(eng, golds):
     pc.check_zip_errors(eng)
 
 
-def test_gpu_tarballs(eng):
+def test_gpu_tarballs(eng, inflate_mode):
     """the reference's tarball fixture (one foreign 3.9 MB gzip member, 20 MB of
     tar) decoded on the device, header walk equal to the oracle's."""
     assert pc.check_tarball(eng, pc.tar_fixture()) > 1000
@@ -230,7 +238,7 @@ def test_gpu_cross_encoder_streams(eng, golds):
     assert all(s == 0 for s in sts) and outs == want
 
 
-def test_gpu_damaged_streams_agree_with_oracle(eng):
+def test_gpu_damaged_streams_agree_with_oracle(eng, inflate_mode):
     pc.check_errors_match_oracle(eng, pc.mutated_fixtures(400, seed=2024))
     pc.check_error_statuses(eng)
 

@@ -19,6 +19,7 @@ _SIGS = {
     "zh_stream": (_c.c_void_p, [_c.c_void_p]),
     "zh_set_gzip_fname_len": (None, [_c.c_void_p, _c.c_int]),
     "zh_set_host_pipeline": (None, [_c.c_void_p, _c.c_size_t, _c.c_size_t]),
+    "zh_set_inflate_mode": (None, [_c.c_void_p, _c.c_int]),
     "zh_compress_bound": (_c.c_size_t, [_c.c_size_t, _c.c_int]),
     "zh_compress_batch": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
                                      _c.c_size_t, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p),
@@ -316,6 +317,10 @@ class Engine:
 
     def set_gzip_fname_len(self, k):
         self.lib.zh_set_gzip_fname_len(self._h, k)
+
+    def set_inflate_mode(self, mode):
+        """0: parallel token decode + writer (default), 1: serial two-wave decoder, -1: default."""
+        self.lib.zh_set_inflate_mode(self._h, mode)
 
     def set_host_pipeline(self, min_batch_bytes=0, group_bytes=0):
         self.lib.zh_set_host_pipeline(self._h, min_batch_bytes, group_bytes)

@@ -32,6 +32,10 @@ void zh_launch_checksum_combine(hipStream_t, const ZhBufDesc* bufs, uint32_t nbu
 void zh_launch_unwrap(hipStream_t, const uint8_t* d_src, ZhInflateArgs a);
 void zh_launch_inflate(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a);
 void zh_launch_verify(hipStream_t, ZhInflateArgs a, const uint32_t* buf_crc, const uint32_t* buf_adler);
+void zh_launch_inflate_tokens(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, uint32_t* tok_pool,
+                              const uint64_t* tok_off, const uint64_t* tok_cap);
+void zh_launch_inflate_write(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a,
+                             const uint32_t* tok_pool, const uint64_t* tok_off);
 void zh_launch_segments_reduce(hipStream_t, ZhInflateArgs seg, ZhInflateArgs whole);
 void zh_launch_l1_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int huffman_only,
                         uint16_t* table_pool);
@@ -58,6 +62,7 @@ struct zh_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int fname_len = -1;
+  int inflate_mode = -1;  // -1: ZH_INFLATE or the default (split), 0 split, 1 serial
   std::string last_error;
   const void* cktabs = nullptr;
   std::mt19937 rng{std::random_device{}()};
@@ -235,6 +240,11 @@ struct zh_plan {
   // block-parallel decode (zh_plan_uncompress_indexed): `ia` describes the one stream, `seg` its blocks
   bool force_crc = false;  // CRC-32 of the uncompressed side whatever the container (ZIP entries)
   bool indexed = false;
+  // split inflate (zh_inflate_split.hip): per-stream token buffers, allocated on the first run
+  uint32_t* tok_pool = nullptr;
+  uint64_t tok_words = 0;
+  const uint64_t *tok_off = nullptr, *tok_cap = nullptr;
+  bool tok_failed = false;
   ZhInflateArgs seg{};
   uint8_t* seg_arena = nullptr;
   // profiling
@@ -286,6 +296,7 @@ extern "C" void zh_plan_destroy(zh_plan* p) {
   (void)hipStreamSynchronize(p->ctx->stream);
   if (p->arena) (void)hipFree(p->arena);
   if (p->seg_arena) (void)hipFree(p->seg_arena);
+  if (p->tok_pool) (void)hipFree(p->tok_pool);
   for (auto e : p->k_events) (void)hipEventDestroy(e);
   delete p;
 }
@@ -555,6 +566,7 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
   const size_t o_bp = ar.reserve(n * 4), o_fmt = ar.reserve(n * 4), o_es = ar.reserve(n * 4),
                o_ei = ar.reserve(n * 4), o_bcrc = ar.reserve(n * 4), o_bad = ar.reserve(n * 4),
                o_olen = ar.reserve(n * 8), o_st = ar.reserve(n * 4);
+  const size_t o_toff = ar.reserve(n * 8), o_tcap = ar.reserve(n * 8);
   ar.reserve(256);
   if (hipMalloc(&p->arena, ar.size) != hipSuccess) {
     ctx->last_error = "hipMalloc(plan arena)";
@@ -562,7 +574,21 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
     return ZH_ERR_NOMEM;
   }
   uint8_t* base = p->arena;
-  hipError_t up = hipMemcpyAsync(base + o_bufs, bufs.data(), n * sizeof(ZhBufDesc), hipMemcpyHostToDevice, ctx->stream);
+  // Token buffers of the split decode: a token makes at least one output byte and takes at least
+  // one input bit; a stored block takes five input bytes and two more records than a token.
+  std::vector<uint64_t> toff(n), tcap(n);
+  uint64_t twords = 0;
+  for (size_t i = 0; i < n; i++) {
+    const uint64_t bits = bufs[i].src_len > (~0ull >> 3) ? ~0ull : bufs[i].src_len * 8;
+    tcap[i] = std::min<uint64_t>(bufs[i].dst_cap, bits) + 2 * (bufs[i].src_len / 5 + 1) + 2;
+    toff[i] = twords;
+    twords += tcap[i] + 1024;  // (the writer reads whole batches of records, up to 640 behind the last)
+  }
+  p->tok_words = twords + 1024;
+  hipError_t up = hipMemcpyAsync(base + o_toff, toff.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (up == hipSuccess) up = hipMemcpyAsync(base + o_tcap, tcap.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (up == hipSuccess)
+    up = hipMemcpyAsync(base + o_bufs, bufs.data(), n * sizeof(ZhBufDesc), hipMemcpyHostToDevice, ctx->stream);
   if (up == hipSuccess)
     up = hipMemcpyAsync(base + o_pieces, pieces.data(), np * sizeof(ZhPieceDesc), hipMemcpyHostToDevice, ctx->stream);
   if (up == hipSuccess) up = hipStreamSynchronize(ctx->stream);
@@ -573,6 +599,8 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
   }
   p->d_bufs = carve<ZhBufDesc>(base, o_bufs);
   p->d_pieces = carve<ZhPieceDesc>(base, o_pieces);
+  p->tok_off = carve<uint64_t>(base, o_toff);
+  p->tok_cap = carve<uint64_t>(base, o_tcap);
   p->npieces = (uint32_t)np;
   p->piece_crc = carve<uint32_t>(base, o_pcrc);
   p->piece_adler = carve<uint32_t>(base, o_pad);
@@ -665,6 +693,33 @@ extern "C" int zh_plan_set_src_lens_device(zh_plan* plan, const uint64_t* d_lens
 
 static void plan_set_count_only(zh_plan* plan, int on) { plan->ia.count_only = on; }
 
+// ZH_INFLATE=serial keeps every stream on the two-wave serial decoder (zh_inflate.hip); the
+// default decodes a stream's Huffman codes in parallel (zh_inflate_split.hip).  Sizing passes and
+// the block-parallel form of one stream always use the serial kernel.
+static bool inflate_split_enabled(const zh_ctx* ctx) {
+  static const bool on = [] {
+    const char* e = getenv("ZH_INFLATE");
+    return !(e && strcmp(e, "serial") == 0);
+  }();
+  return ctx->inflate_mode < 0 ? on : ctx->inflate_mode == 0;
+}
+extern "C" void zh_set_inflate_mode(zh_ctx* ctx, int mode) {
+  if (ctx) ctx->inflate_mode = mode < 0 ? -1 : mode ? 1 : 0;
+}
+// the token pool of a plan, allocated when it first runs in split mode; a failed allocation
+// (it is several times the output) sends the plan to the serial kernel for good
+static bool plan_token_pool(zh_plan* p) {
+  if (p->tok_pool) return true;
+  if (p->tok_failed || !p->tok_words) return false;
+  if (hipMalloc(&p->tok_pool, p->tok_words * 4) != hipSuccess) {
+    (void)hipGetLastError();
+    p->tok_pool = nullptr;
+    p->tok_failed = true;
+    return false;
+  }
+  return true;
+}
+
 // Output slots start out zeroed (every shared output word is OR-ed into place).  Slots that tile
 // one range are cleared with a single memset; slots with gaps between them are cleared one by
 // one, byte-exact, so that caller data lying between two slots is never touched.
@@ -745,12 +800,19 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     const ZhInflateArgs& a = p->ia;
     prof_mark(p, "zh_unwrap_kernel");
     zh_launch_unwrap(s, d_src, a);
-    prof_mark(p, "zh_inflate_kernel");
+    const bool split = !p->indexed && !a.count_only && inflate_split_enabled(ctx) && plan_token_pool(p);
+    if (!split) prof_mark(p, "zh_inflate_kernel");
     if (p->indexed) {
       ZH_HIP(ctx, hipMemsetAsync(p->seg.status, 0, (size_t)p->seg.nbufs * 4, s));
       zh_launch_inflate(s, d_src, d_dst, p->seg);
       prof_mark(p, "zh_segments_reduce_kernel");
       zh_launch_segments_reduce(s, p->seg, a);
+    } else if (split) {
+      // two kernels: tokens (parallel over each stream), then bytes (zh_inflate_split.hip)
+      prof_mark(p, "zh_inflate_tokens_kernel");
+      zh_launch_inflate_tokens(s, d_src, a, p->tok_pool, p->tok_off, p->tok_cap);
+      prof_mark(p, "zh_inflate_write_kernel");
+      zh_launch_inflate_write(s, d_src, d_dst, a, p->tok_pool, p->tok_off);
     } else {
       zh_launch_inflate(s, d_src, d_dst, a);
     }

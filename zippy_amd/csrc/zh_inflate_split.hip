@@ -1,0 +1,600 @@
+// Batched inflate in two kernels ("split" mode): a stream's Huffman decoding is parallel over the
+// stream, only its LZ copies are serial.
+//
+// A deflate block is one long run of variable-length codes, so a serial decoder -- the reference's
+// inflate.nim:173-250 and zh_inflate.hip's two-wave form of it -- spends its time finding where the
+// next code starts.  Huffman decoding re-synchronises by itself, though: a decoder started at an
+// arbitrary bit falls in step with the real code sequence after a few dozen symbols.  So:
+//
+//   zh_inflate_tokens_kernel (256 threads per stream)
+//     blocks in order (inflate.nim:273-289): wave 0 reads the block header and builds the tables
+//     exactly like the serial kernel (zh_inflate_tables.h); then the block's bits are taken
+//     131 072 at a time ("superchunk", staged in LDS), one 512-bit SUBCHUNK per thread.  Every
+//     thread decodes whole tokens (literal, or length+extra+distance+extra, inflate.nim:93-100 /
+//     199-222) from its guessed start to the first token start at or behind its subchunk's end;
+//     that end is the next thread's true start, so starts are handed on and threads whose start
+//     changed decode again until no start changes.  Thread 0's start is exact, so by induction
+//     every start then is: the result is the serial decoder's token sequence -- self-
+//     synchronisation only decides how many turns that takes (two or three), never what comes
+//     out.  Token counts are prefix-summed and a last pass writes the tokens (one 32-bit record
+//     each, the serial kernel's round-record format) to the stream's token buffer in HBM.
+//     End of block, invalid symbols and the end of the input are found by the thread that owns
+//     the bit position, in stream order; stored blocks (inflate.nim:252-266) become one record.
+//   zh_inflate_write_kernel (one wave per stream)
+//     the serial kernel's output wave fed from the token buffer: rounds of up to 64 output bytes,
+//     one lane per byte, LZ window = the output itself.  Keeps inflate.nim:224-225's distance
+//     check and the capacity check; produces out_len and the status.
+//
+// Same checks, same accept/reject decision and the same bytes as zh_inflate_kernel (the tests
+// run both against the oracle).  Algorithmic traffic: C read + N written, plus the token
+// records (4 bytes per token, written once and read once).
+#include "zh_common.h"
+#include "zh_kprof.h"
+#include "zh_tables.h"
+#include "zh_inflate_tables.h"
+
+namespace {
+
+constexpr uint32_t kSplitThreads = 256;
+constexpr uint32_t kSubBits = 512;                            // one thread's share of a superchunk
+constexpr uint32_t kSuperBits = kSplitThreads * kSubBits;     // 16 KiB of the stream per turn
+constexpr uint32_t kStageWords = kSuperBits / 32u + 8u;       // + what the last tokens may read
+constexpr uint32_t kHeaderWords = 288;                        // a dynamic header is < 900 bytes
+constexpr uint32_t kDistSub = 256;                            // second-level distance tables
+constexpr uint32_t kNoStart = 0xffffffffu;                    // "the thread before me ended the block"
+
+// token records (uint32): the serial kernel's round record
+//   bits 0-8 output length | bit 9 literal | (bit 10: in chain, set by the writer) | bits 16-31 value
+// special records have bit 15 set and length 0:
+//   bits 11-12 = 1: stored run of `value` bytes, followed by two words: byte offset in the stream
+//   bits 11-12 = 2: end of the stream, value = status
+constexpr uint32_t kRecSpecial = 0x8000u, kRecStored = 1u << 11, kRecEnd = 2u << 11;
+
+struct RunResult {
+  uint32_t end;   // bit position (superchunk-relative) behind the last token taken
+  uint32_t n;     // tokens
+  uint32_t term;  // 0 none, 1 end of block, else a ZH_ERR_* status
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* __restrict__ d_src,
+                                                                ZhInflateArgs a,
+                                                                uint32_t* __restrict__ tok_pool,
+                                                                const uint64_t* __restrict__ tok_off,
+                                                                const uint64_t* __restrict__ tok_cap) {
+  __shared__ uint32_t s_lit[(1u << kLitBits) + kLitSub];
+  __shared__ uint32_t s_dst[(1u << kDistBits) + kDistSub];  // also hosts the 7-bit code-length table
+  __shared__ uint32_t s_in[kStageWords];
+  __shared__ HuffTab s_tab_lit, s_tab_dist, s_tab_cl;
+  __shared__ uint16_t s_val_lit[288], s_val_dist[32], s_val_cl[20];
+  __shared__ uint8_t s_lens[320 + 16];
+  __shared__ uint32_t s_cnt[16];
+  __shared__ uint32_t s_end[kSplitThreads];   // where every thread's run ended
+  __shared__ uint32_t s_wsum[4];
+  __shared__ uint32_t s_any[2];
+  __shared__ uint32_t s_tterm;
+  // block / superchunk control words written by one thread, read by all
+  __shared__ uint32_t s_c_btype, s_c_final, s_c_st, s_c_stored_len, s_c_term, s_c_endrel;
+  __shared__ uint64_t s_c_pos;
+
+  const uint32_t tid = threadIdx.x;
+  const unsigned lane = zh_lane();
+  const uint32_t sid = blockIdx.x;
+  if (a.status[sid] != ZH_OK) return;  // unwrap already failed this stream
+
+  const ZhBufDesc bd = a.bufs[sid];
+  const uint8_t* src = d_src + bd.src_off;
+  const uint64_t src_len = a.src_len_dev ? a.src_len_dev[sid] : bd.src_len;
+  const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
+  const uint32_t* asrc = reinterpret_cast<const uint32_t*>(src - mis);
+  const uint64_t end = mis + src_len;  // first byte offset (from asrc) past the stream
+  auto load_dword = [&](uint64_t off) -> uint32_t {  // bytes past the end read as zero
+    if (off >= end) return 0u;
+    uint32_t v = asrc[off >> 2];
+    if (off + 4 > end) v &= (1u << (8 * (uint32_t)(end - off))) - 1u;
+    return v;
+  };
+  uint32_t* const tok = tok_pool + tok_off[sid];
+  const uint64_t cap = tok_cap[sid];  // records this stream may write (the end record included)
+
+  uint64_t pos = ((uint64_t)mis + a.body_pos[sid]) * 8;  // stream position in bits (from asrc)
+  uint64_t ntok = 0;
+  int st = ZH_OK;
+  bool final_block = false;
+
+  // ---- one token at superchunk-relative bit p, decoded by the calling lane alone ----
+  // returns the token's bits (0: not a token, see *kind) and its record
+  auto decode_at = [&](uint32_t p, uint32_t* rec, uint32_t* kind) -> uint32_t {
+    const uint32_t wi = p >> 5, sh = p & 31u;
+    const uint32_t d0 = s_in[wi], d1 = s_in[wi + 1u], d2 = s_in[wi + 2u];
+    const uint32_t v_lo = zh_alignbit(d1, d0, sh), v_hi = zh_alignbit(d2, d1, sh);
+    uint32_t e = s_lit[v_lo & ((1u << kLitBits) - 1u)];
+    if (e & 0x400u) e = s_lit[(e >> 16) + ((v_lo >> kLitBits) & ((1u << (e & 15u)) - 1u))];
+    if (e == 0) {  // inflate.nim:67-91 decodeSymbolSlow: longer than the tables reach, or unassigned
+      const uint32_t k = __brev(v_lo) >> 16;
+      uint32_t cl = kLitBits + 1;
+      while (cl < 16 && k >= s_tab_lit.max_codes[cl]) cl++;
+      uint32_t sym = 0xffffu;
+      if (cl < 16)
+        sym = s_val_lit[((k >> (16 - cl)) - s_tab_lit.first_code[cl] + s_tab_lit.first_symbol[cl]) & 0xffffu];
+      e = litlen_entry(sym, cl < 16 ? cl : 0);
+    }
+    const uint32_t L = e & 15u;
+    if (e & 0x8000u) {
+      *kind = 0;
+      *rec = 1u | (1u << 9) | (((e >> 16) & 0xffu) << 16);
+      return L;
+    }
+    const uint32_t k1 = (e >> 8) & 3u;
+    if (k1 != kKindBase) {
+      *kind = k1 == kKindEob ? 1u : (uint32_t)ZH_ERR_INVALID_BUFFER;  // inflate.nim:202-204
+      *rec = 0;
+      return L;
+    }
+    const uint64_t v = (uint64_t)v_lo | ((uint64_t)v_hi << 32);
+    const uint32_t eb = (e >> 4) & 15u;
+    const uint32_t length = (e >> 16) + ((v_lo >> L) & ((1u << eb) - 1u));
+    const uint32_t o2 = L + eb;  // <= 20
+    const uint32_t dv = zh_alignbit(v_hi, v_lo, o2);
+    uint32_t de = s_dst[dv & ((1u << kDistBits) - 1u)];
+    if (de & 0x400u) de = s_dst[(de >> 16) + ((dv >> kDistBits) & ((1u << (de & 15u)) - 1u))];
+    if (de == 0) {
+      const uint32_t k = __brev(dv) >> 16;
+      uint32_t cl = kDistBits + 1;
+      while (cl < 16 && k >= s_tab_dist.max_codes[cl]) cl++;
+      uint32_t sym = 0xffffu;
+      if (cl < 16)
+        sym = s_val_dist[((k >> (16 - cl)) - s_tab_dist.first_code[cl] + s_tab_dist.first_symbol[cl]) & 0xffffu];
+      de = dist_entry(sym, cl < 16 ? cl : 0);
+    }
+    if (((de >> 8) & 3u) != kKindBase) {  // inflate.nim:211-213
+      *kind = (uint32_t)ZH_ERR_INVALID_BUFFER;
+      *rec = 0;
+      return 0;
+    }
+    const uint32_t o3 = o2 + (de & 15u), deb = (de >> 4) & 15u;  // o3 <= 35, the token <= 48 bits
+    const uint32_t dist = (de >> 16) + ((uint32_t)(v >> o3) & ((1u << deb) - 1u));
+    *kind = 0;
+    *rec = length | (dist << 16);
+    return o3 + deb;
+  };
+  // tokens from p up to the first token start at or behind `limit`; `end_rel`: the input's end
+  auto run = [&](uint32_t p, uint32_t limit, uint32_t end_rel, uint32_t* out) -> RunResult {
+    RunResult r;
+    r.n = 0;
+    r.term = 0;
+    while (p < limit) {
+      uint32_t rec, kind;
+      const uint32_t tb = decode_at(p, &rec, &kind);
+      if (kind > 1u) {
+        r.term = kind;
+        break;
+      }
+      p += tb;
+      if (p > end_rel) {  // the token reaches past the input (the role of `bitsBuffered < 0`)
+        r.term = (uint32_t)ZH_ERR_END_OF_BUFFER;
+        break;
+      }
+      if (kind == 1u) {
+        r.term = 1u;
+        break;
+      }
+      if (out) out[r.n] = rec;
+      r.n++;
+    }
+    r.end = p;
+    return r;
+  };
+
+  while (!final_block && st == ZH_OK) {  // inflate.nim:273-289
+    // ---- block header: staged, then read by wave 0 like the serial kernel does ----
+    const uint64_t hbase = pos >> 5;  // dword of the header's first bit
+    __syncthreads();
+    for (uint32_t i = tid; i < kHeaderWords; i += kSplitThreads) s_in[i] = load_dword((hbase + i) * 4);
+    __syncthreads();
+    if (tid < 64) {
+      uint64_t bp = pos & 31u;  // relative to hbase * 32
+      uint64_t hb = 0;
+      uint32_t hc = 0;
+      int hst = ZH_OK;
+      auto fetch = [&]() -> uint64_t {
+        const uint32_t wi = (uint32_t)(bp >> 5), sh = (uint32_t)bp & 31u;
+        const uint32_t d0 = zh_bcast(s_in[wi]), d1 = zh_bcast(s_in[wi + 1u]), d2 = zh_bcast(s_in[wi + 2u]);
+        return (uint64_t)zh_alignbit(d1, d0, sh) | ((uint64_t)zh_alignbit(d2, d1, sh) << 32);
+      };
+      auto need = [&]() {
+        if (hc < 32u) {
+          hb = fetch();
+          hc = 64;
+        }
+      };
+      auto take = [&](uint32_t nbits) -> uint32_t {
+        const uint32_t v = (uint32_t)hb & ((1u << nbits) - 1u);
+        hb >>= nbits;
+        hc -= nbits;
+        bp += nbits;
+        return v;
+      };
+      auto past_end = [&]() -> bool { return hbase * 32 + bp > end * 8; };
+      auto decode_slow = [&](uint32_t bits, uint32_t lut_bits, const HuffTab* tab, const uint16_t* values,
+                             uint32_t* nb) -> uint32_t {
+        const uint32_t k = __brev(bits) >> 16;
+        uint32_t cl = lut_bits + 1;
+        while (cl < 16 && k >= zh_bcast(tab->max_codes[cl])) cl++;
+        *nb = 0;
+        if (cl >= 16) return 0xffffu;
+        const uint32_t id = ((k >> (16 - cl)) - zh_bcast(tab->first_code[cl]) +
+                             zh_bcast(tab->first_symbol[cl])) & 0xffffu;
+        *nb = cl;
+        return zh_bcast(values[id]);
+      };
+      need();
+      const uint32_t bfinal = take(1), btype = take(2);
+      uint32_t stored_len = 0;
+      if (btype == 0) {  // inflate.nim:252-266 inflateNoCompression
+        bp = ((hbase * 32 + bp + 7u) & ~(uint64_t)7) - hbase * 32;
+        hc = 0;
+        need();
+        const uint32_t len = take(16), nlen = take(16);
+        if (len + nlen != 65535u) hst = ZH_ERR_INVALID_BUFFER;
+        else if (((hbase * 32 + bp) >> 3) + len > end) hst = ZH_ERR_END_OF_BUFFER;
+        stored_len = len;
+      } else if (btype == 3) {
+        hst = ZH_ERR_BLOCK_HEADER;
+      } else {
+        uint32_t hlit = 288, hdist = 30;
+        if (btype == 1) {  // fixed codes, inflate.nim:111-113
+          zh_wave_sync();
+          for (uint32_t s = lane; s < 288; s += 64) s_lens[s] = (uint8_t)(s <= 143 ? 8 : s <= 255 ? 9 : s <= 279 ? 7 : 8);
+          if (lane < 30) s_lens[288 + lane] = 5;
+        } else {  // dynamic header, inflate.nim:115-171
+          hlit = take(5) + 257;
+          hdist = take(5) + 1;
+          const uint32_t hclen = take(4) + 4;
+          if (hlit > 286 || hdist > 30) hst = ZH_ERR_INVALID_BUFFER;
+          if (hst == ZH_OK) {
+            zh_wave_sync();
+            if (lane < 20) s_lens[lane] = 0;
+            zh_wave_sync();
+            for (uint32_t i = 0; i < hclen; i++) {
+              need();
+              const uint32_t v = take(3);
+              if (lane == 0) s_lens[c_clcl_order[i]] = (uint8_t)v;
+            }
+            hst = build_table(s_lens, 19, s_dst, 7, 2, &s_tab_cl, s_val_cl, s_cnt);
+          }
+          if (hst == ZH_OK) {
+            uint32_t i = 0;
+            const uint32_t total = hlit + hdist;
+            uint32_t prev = 0;
+            while (i != total) {
+              need();
+              uint32_t sym;
+              const uint32_t e = zh_bcast(s_dst[(uint32_t)hb & 127u]);
+              if (e) {
+                take(e & 15u);
+                sym = e >> 16;
+              } else {
+                uint32_t nb;
+                sym = decode_slow((uint32_t)hb, 7, &s_tab_cl, s_val_cl, &nb);
+                take(nb);
+              }
+              if (past_end()) { hst = ZH_ERR_END_OF_BUFFER; break; }
+              if (sym <= 15) {
+                if (lane == 0) s_lens[i] = (uint8_t)sym;
+                prev = sym;
+                i++;
+              } else if (sym == 16) {
+                if (i == 0) { hst = ZH_ERR_INVALID_BUFFER; break; }
+                const uint32_t rep = take(2) + 3;
+                if (i + rep > 320) { hst = ZH_ERR_INVALID_BUFFER; break; }
+                if (lane < rep) s_lens[i + lane] = (uint8_t)prev;
+                i += rep;
+              } else if (sym == 17 || sym == 18) {
+                const uint32_t rep = sym == 17 ? take(3) + 3 : take(7) + 11;
+                for (uint32_t j = lane; j < rep && i + j < 320 + 16; j += 64) s_lens[i + j] = 0;
+                prev = 0;
+                i += rep;
+              } else {
+                hst = ZH_ERR_INVALID_SYMBOL;
+                break;
+              }
+              if (i > total) { hst = ZH_ERR_INVALID_BUFFER; break; }
+            }
+          }
+        }
+        if (hst == ZH_OK) {
+          const uint32_t dist_at = btype == 1 ? 288u : hlit;
+          hst = build_table(s_lens, hlit, s_lit, kLitBits, 0, &s_tab_lit, s_val_lit, s_cnt, kLitSub);
+          if (hst == ZH_OK)
+            hst = build_table(s_lens + dist_at, hdist, s_dst, kDistBits, 1, &s_tab_dist, s_val_dist, s_cnt, kDistSub);
+        }
+      }
+      if (lane == 0) {
+        s_c_btype = btype;
+        s_c_final = bfinal;
+        s_c_st = (uint32_t)hst;
+        s_c_stored_len = stored_len;
+        s_c_pos = hbase * 32 + bp;  // behind the header (stored: the first raw byte)
+      }
+    }
+    __syncthreads();
+    const uint32_t btype = s_c_btype;
+    st = (int)s_c_st;
+    if (s_c_final) final_block = true;
+    pos = s_c_pos;
+    if (st != ZH_OK) break;
+
+    if (btype == 0) {
+      const uint32_t len = s_c_stored_len;
+      const uint64_t byte_pos = pos >> 3;  // from asrc
+      if (len) {  // (an empty stored block leaves no record: every record group makes output)
+        if (ntok + 3 + 1 > cap) {
+          st = ZH_ERR_DST_TOO_SMALL;
+          break;
+        }
+        if (tid == 0) {
+          const uint64_t off = byte_pos - mis;  // from the stream's first byte
+          tok[ntok] = kRecSpecial | kRecStored | (len << 16);
+          tok[ntok + 1] = (uint32_t)off;
+          tok[ntok + 2] = (uint32_t)(off >> 32);
+        }
+        ntok += 3;
+      }
+      pos = (byte_pos + len) * 8;
+      continue;
+    }
+
+    // ---- the block's codes, a superchunk at a time ----
+    for (;;) {
+      const uint64_t base_bit = pos & ~(uint64_t)31;
+      const uint32_t rel0 = (uint32_t)(pos - base_bit);
+      __syncthreads();  // (everybody is done with the previous contents of s_in)
+      for (uint32_t i = tid; i < kStageWords; i += kSplitThreads) s_in[i] = load_dword(((base_bit >> 5) + i) * 4);
+      if (tid == 0) {
+        s_tterm = kSplitThreads;
+        s_any[0] = 0;
+        s_any[1] = 0;
+      }
+      const uint64_t end_bit = end * 8;
+      const uint32_t end_rel = end_bit > base_bit
+                                   ? (uint32_t)(end_bit - base_bit < 0xfffffff0ull ? end_bit - base_bit : 0xfffffff0ull)
+                                   : 0u;
+      __syncthreads();
+      const uint32_t limit = (tid + 1u) * kSubBits;
+      uint32_t my_start = tid == 0 ? rel0 : tid * kSubBits;
+      bool dirty = true;
+      RunResult r = {0, 0, 0};
+      for (uint32_t turn = 1;; turn++) {
+        if (dirty) {
+          if (my_start == kNoStart) {
+            r.end = kNoStart;
+            r.n = 0;
+            r.term = 0;
+          } else {
+            r = run(my_start, limit, end_rel, nullptr);
+          }
+          s_end[tid] = r.term ? kNoStart : r.end;
+        }
+        __syncthreads();
+        const uint32_t ns = tid == 0 ? rel0 : s_end[tid - 1u];
+        dirty = ns != my_start;
+        my_start = ns;
+        if (dirty) s_any[turn & 1u] = turn;
+        __syncthreads();
+        const bool again = s_any[turn & 1u] == turn;
+        if (!again) break;
+      }
+      // every start is the serial decoder's now.  The first thread (in stream order) that met the
+      // end of the block or an error decides how the superchunk ends.
+      if (my_start != kNoStart && r.term) atomicMin(&s_tterm, tid);
+      __syncthreads();
+      const uint32_t tterm = s_tterm;
+      const bool active = my_start != kNoStart && tid <= tterm;
+      const uint32_t n_eff = active ? r.n : 0u;
+      const uint32_t incl = zh_wave_scan(n_eff);
+      if (lane == 63) s_wsum[tid >> 6] = incl;
+      if (tid == tterm) {
+        s_c_term = r.term;
+        s_c_endrel = r.end;
+      }
+      __syncthreads();
+      uint32_t before = incl - n_eff, total = 0;
+      for (uint32_t w = 0; w < 4; w++) {
+        const uint32_t ws = s_wsum[w];
+        if (w < (tid >> 6)) before += ws;
+        total += ws;
+      }
+      if (ntok + total + 1 > cap) {  // more tokens than output bytes fit the slot
+        st = ZH_ERR_DST_TOO_SMALL;
+        break;
+      }
+      if (active && r.n) (void)run(my_start, limit, end_rel, tok + ntok + before);
+      ntok += total;
+      if (tterm < kSplitThreads) {
+        const uint32_t term = s_c_term;
+        if (term != 1u) st = (int)term;
+        pos = base_bit + s_c_endrel;  // behind the end-of-block code
+        break;
+      }
+      pos = base_bit + s_end[kSplitThreads - 1u];
+    }
+  }
+  if (tid == 0) tok[ntok] = kRecSpecial | kRecEnd | ((uint32_t)st << 16);
+}
+
+// ---------------------------------------------------------------------------
+// Writer: one wave per stream turns the token records into bytes.  Rounds of at most 64 output
+// bytes get one lane per OUTPUT byte (the serial kernel's output wave, zh_inflate.hip).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void zh_inflate_write_kernel(const uint8_t* __restrict__ d_src,
+                                                              uint8_t* __restrict__ d_dst, ZhInflateArgs a,
+                                                              const uint32_t* __restrict__ tok_pool,
+                                                              const uint64_t* __restrict__ tok_off) {
+  constexpr uint32_t kRing = 512;  // token records staged in LDS (a power of two)
+  __shared__ uint32_t s_tok[kRing];
+  __shared__ uint8_t s_map[64];
+  const unsigned lane = zh_lane();
+  const uint32_t sid = blockIdx.x;
+  if (a.status[sid] != ZH_OK) return;
+
+  const ZhBufDesc bd = a.bufs[sid];
+  const uint8_t* src = d_src + bd.src_off;
+  uint8_t* dst = d_dst + bd.dst_off;
+  const uint64_t cap = bd.dst_cap;
+  const uint32_t* tok = tok_pool + tok_off[sid];
+
+  uint64_t op = 0;  // bytes produced
+  int st = ZH_OK;
+  auto own_output_visible = [&]() {
+    zh_wave_sync();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  };
+  auto ld_out = [&](uint64_t at) -> uint32_t {
+    return __hip_atomic_load(dst + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // inflate.nim:224-250: one LZ copy of `length` bytes from `dist` back, at op (wave-uniform)
+  auto lz_copy = [&](uint32_t length, uint32_t dist) {
+    if (dist > op) {  // inflate.nim:224-225
+      st = ZH_ERR_INVALID_BUFFER;
+      return;
+    }
+    if (op + length > cap) {
+      st = ZH_ERR_DST_TOO_SMALL;
+      return;
+    }
+    own_output_visible();
+    const uint64_t sb = op - dist;
+    if (dist >= length) {
+      for (uint32_t i = lane; i < length; i += 64) dst[op + i] = (uint8_t)ld_out(sb + i);
+    } else if (dist == 1) {
+      const uint8_t v = (uint8_t)ld_out(sb);
+      for (uint32_t i = lane; i < length; i += 64) dst[op + i] = v;
+    } else {
+      for (uint32_t i = lane; i < length; i += 64) dst[op + i] = (uint8_t)ld_out(sb + i % dist);
+    }
+    op += length;
+  };
+
+  // records [ti, hi) are in the ring; `pre` holds records [hi, hi + 256) on their way from HBM
+  uint64_t ti = 0, hi = 0;
+  uint32_t pre[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) pre[k] = tok[lane + 64u * k];
+  auto refill = [&]() {
+    zh_wave_sync();
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_tok[(uint32_t)(hi + lane + 64u * k) & (kRing - 1u)] = pre[k];
+    hi += 256;
+#pragma unroll
+    for (int k = 0; k < 4; k++) pre[k] = tok[hi + lane + 64u * k];
+    zh_wave_sync();
+  };
+
+  for (;;) {
+    while (hi < ti + 128u) refill();  // a round looks at 64 records (+ 2 behind a stored-run record)
+    op = zh_bcast64(op);
+    const uint32_t rec = s_tok[(uint32_t)(ti + lane) & (kRing - 1u)];
+    const uint64_t spm = __ballot((rec & kRecSpecial) != 0);
+    const uint32_t first_sp = spm ? (uint32_t)__ffsll((long long)spm) - 1u : 64u;
+    const uint32_t len = lane < first_sp ? rec & 0x1ffu : 0u;
+    const uint32_t incl = zh_wave_scan(len);
+    const uint64_t fit = __ballot(lane < first_sp && incl <= 64u);  // a prefix of the lanes
+    const uint32_t n = (uint32_t)__popcll(fit);
+    if (n == 0) {
+      const uint32_t r0 = __builtin_amdgcn_readlane(rec, 0);
+      if (r0 & kRecSpecial) {
+        if ((r0 & (3u << 11)) == kRecStored) {  // inflate.nim:252-266: raw bytes
+          const uint32_t length = r0 >> 16;
+          const uint64_t off = (uint64_t)s_tok[(uint32_t)(ti + 1u) & (kRing - 1u)] |
+                               ((uint64_t)s_tok[(uint32_t)(ti + 2u) & (kRing - 1u)] << 32);
+          if (op + length > cap) {
+            st = ZH_ERR_DST_TOO_SMALL;
+            break;
+          }
+          for (uint32_t i = lane; i < length; i += 64) dst[op + i] = src[off + i];
+          op += length;
+          ti += 3;
+          continue;
+        }
+        st = (int)(r0 >> 16);  // end of the stream
+        break;
+      }
+      lz_copy(r0 & 0x1ffu, r0 >> 16);  // one copy of more than 64 bytes
+      if (st != ZH_OK) break;
+      ti += 1;
+      continue;
+    }
+    const uint32_t total = __builtin_amdgcn_readlane(incl, n - 1u);
+    const bool in_chain = lane < n;
+    const bool is_lit = (rec >> 9) & 1u;
+    const uint32_t val = rec >> 16;
+    const uint32_t opre = incl - len;
+    const bool is_match = in_chain && !is_lit;
+    // inflate.nim:224-225 `distance > op` (a distance is at most 32768)
+    if (op < 32768u && __ballot(is_match && (uint64_t)val > op + opre)) {
+      st = ZH_ERR_INVALID_BUFFER;
+      break;
+    }
+    if (op + total > cap) {
+      st = ZH_ERR_DST_TOO_SMALL;
+      break;
+    }
+    zh_wave_sync();
+    s_map[lane] = 0;
+    zh_wave_sync();
+    if (in_chain) s_map[opre] = (uint8_t)(lane + 1u);
+    zh_wave_sync();
+    const uint32_t tk = zh_wave_scan_max(s_map[lane]);  // token lane + 1 of output byte `lane`
+    const uint32_t j = (tk - 1u) & 63u;
+    const uint32_t f1 = is_lit ? 0x9000u | val : val;  // a distance (<= 0x8000) as it is, a literal as 0x9000 | byte
+    const uint32_t gd = (uint32_t)__shfl((int)f1, (int)j, 64);
+    const bool live = lane < total;
+    uint32_t v = gd & 0xffu;
+    uint32_t par = lane;  // source byte inside this round (itself: a root)
+    bool far = false;
+    uint32_t back = 0;
+    if (live && gd < 0x9000u) {
+      if (gd <= lane) {
+        par = lane - gd;
+      } else {
+        back = gd - lane;  // bytes before this round's first
+        far = true;
+      }
+    }
+    if (__ballot(far)) {
+      own_output_visible();
+      if (far) v = ld_out(op - back);
+    }
+    if (__ballot(par != lane)) {
+      for (;;) {
+        const uint32_t pp = (uint32_t)__shfl((int)par, (int)par, 64);
+        const bool changed = pp != par;
+        par = pp;
+        if (!__ballot(changed)) break;
+      }
+      v = (uint32_t)__shfl((int)v, (int)par, 64);
+    }
+    if (live) dst[op + lane] = (uint8_t)v;
+    op += total;
+    ti += n;
+  }
+  if (lane == 0) {
+    a.out_len[sid] = op;
+    a.status[sid] = st;
+  }
+}
+
+extern "C" void zh_launch_inflate_tokens(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a,
+                                         uint32_t* tok_pool, const uint64_t* tok_off, const uint64_t* tok_cap) {
+  if (!a.nbufs) return;
+  hipLaunchKernelGGL(zh_inflate_tokens_kernel, dim3(a.nbufs), dim3(kSplitThreads), 0, stream, d_src, a, tok_pool,
+                     tok_off, tok_cap);
+}
+extern "C" void zh_launch_inflate_write(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a,
+                                        const uint32_t* tok_pool, const uint64_t* tok_off) {
+  if (!a.nbufs) return;
+  hipLaunchKernelGGL(zh_inflate_write_kernel, dim3(a.nbufs), dim3(64), 0, stream, d_src, d_dst, a, tok_pool,
+                     tok_off);
+}
