@@ -22,6 +22,7 @@ EMIT = ["flush + loop", "chunk bitmaps", "bitmaps, source, scan, match fields", 
 HUFF = ["histogram sum", "litlen code", "distance code", "run-length coding", "code-length code", "header bits",
         "tables out + fragment sizes", "#waves"]
 INF_O = ["waiting for a round", "working", "#rounds", "#waves", "#long rounds", "#far rounds", "#doubling turns", "#tail matches"]
+TOK = ["header + tables", "staging", "sync turns", "scan", "token pass", "#superchunks", "#turns", "#waves"]
 INF_D = ["waiting for the output wave", "other work", "#rounds", "#waves", "vector decode", "chain walks", "staging",
          "#(unused)"]
 
@@ -43,6 +44,7 @@ def main():
     ap.add_argument("--buffers", type=int, default=1024)
     ap.add_argument("--size", type=int, default=1 << 20)
     ap.add_argument("--kind", default="mix")
+    ap.add_argument("--inflate", type=int, default=-1)
     args = ap.parse_args()
     import torch
     from zippy_amd import api, synth
@@ -53,6 +55,7 @@ def main():
     d_src = torch.from_numpy(host.reshape(-1)).cuda()
     eng = Engine(lib_path, stream=torch.cuda.current_stream().cuda_stream)
     eng.set_gzip_fname_len(0)
+    eng.set_inflate_mode(args.inflate)
     eng.lib.zh_kprof_read.restype = ctypes.c_int
     eng.lib.zh_kprof_read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     cap = size + size // 8 + 2048
@@ -78,6 +81,7 @@ def main():
     show("zh_l1_match_kernel", L1, list(slots[0:16]))
     show("zh_emit_kernel", EMIT, list(slots[32:40]))
     show("zh_huffman_kernel", HUFF, list(slots[40:48]))
+    show("zh_inflate_tokens_kernel (thread 0 of each stream)", TOK, list(slots[48:56]))
     show("zh_inflate_kernel: output wave", INF_O, list(slots[16:24]))
     show("zh_inflate_kernel: decode wave", INF_D, list(slots[24:32]))
 

@@ -38,10 +38,22 @@ namespace {
 constexpr uint32_t kSplitThreads = 256;
 constexpr uint32_t kSubBits = 512;                            // one thread's share of a superchunk
 constexpr uint32_t kSuperBits = kSplitThreads * kSubBits;     // 16 KiB of the stream per turn
-constexpr uint32_t kStageWords = kSuperBits / 32u + 8u;       // + what the last tokens may read
+constexpr uint32_t kSubWords = kSubBits / 32u;                 // 16
+// The staged superchunk is stored transposed: dword w of the superchunk -- the k-th dword (k = w % 16)
+// of subchunk t = w / 16 -- sits at k * kStageRow + t.  Thread t then reads LDS bank (4k + t) % 64
+// whatever its progress k: the 64 lanes of a wave never meet in a bank (in the plain layout they
+// are 16 dwords apart and share four banks, a 16-way conflict on every read).  Row t = 256 holds the
+// dwords the last subchunk's tokens reach into.
+constexpr uint32_t kStageRow = kSplitThreads + 4u;
+constexpr uint32_t kStageWords = kSubWords * kStageRow;
 constexpr uint32_t kHeaderWords = 288;                        // a dynamic header is < 900 bytes
 constexpr uint32_t kDistSub = 256;                            // second-level distance tables
 constexpr uint32_t kNoStart = 0xffffffffu;                    // "the thread before me ended the block"
+constexpr uint32_t kMinTurns = 3;     // speculative turns before the all-starts pass may take over
+constexpr uint32_t kSlowGain = 12;    // ... when a turn added fewer final threads than this
+constexpr uint32_t kMapGroup = 64;    // subchunks mapped per all-starts pass
+constexpr uint32_t kStartSpan = 48;   // a token is at most 48 bits: a subchunk's true start is one of 48
+constexpr uint32_t kMapTerm = 0xffu;  // all-starts map: "ends the block (or fails) in this subchunk"
 
 // token records (uint32): the serial kernel's round record
 //   bits 0-8 output length | bit 9 literal | (bit 10: in chain, set by the writer) | bits 16-31 value
@@ -72,8 +84,10 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
   __shared__ uint32_t s_cnt[16];
   __shared__ uint32_t s_end[kSplitThreads];   // where every thread's run ended
   __shared__ uint32_t s_wsum[4];
-  __shared__ uint32_t s_any[2];
-  __shared__ uint32_t s_tterm;
+  __shared__ uint32_t s_first_dirty[2], s_first_term[2];  // per turn parity
+  // all-starts map of a subchunk: entry i = where the decode that starts i bits into the subchunk
+  // comes out, in bits behind the subchunk's end (or kMapTerm)
+  __shared__ uint8_t s_map[kSplitThreads][kStartSpan];
   // block / superchunk control words written by one thread, read by all
   __shared__ uint32_t s_c_btype, s_c_final, s_c_st, s_c_stored_len, s_c_term, s_c_endrel;
   __shared__ uint64_t s_c_pos;
@@ -100,6 +114,7 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
 
   uint64_t pos = ((uint64_t)mis + a.body_pos[sid]) * 8;  // stream position in bits (from asrc)
   uint64_t ntok = 0;
+  KPROF_DECL(8);  // cycles: 0 header + tables, 1 staging, 2 sync turns, 3 scan, 4 token pass; counts: 5 superchunks, 6 turns, 7 streams
   int st = ZH_OK;
   bool final_block = false;
 
@@ -107,7 +122,8 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
   // returns the token's bits (0: not a token, see *kind) and its record
   auto decode_at = [&](uint32_t p, uint32_t* rec, uint32_t* kind) -> uint32_t {
     const uint32_t wi = p >> 5, sh = p & 31u;
-    const uint32_t d0 = s_in[wi], d1 = s_in[wi + 1u], d2 = s_in[wi + 2u];
+    auto staged = [&](uint32_t w) -> uint32_t { return s_in[(w & (kSubWords - 1u)) * kStageRow + (w >> 4)]; };
+    const uint32_t d0 = staged(wi), d1 = staged(wi + 1u), d2 = staged(wi + 2u);
     const uint32_t v_lo = zh_alignbit(d1, d0, sh), v_hi = zh_alignbit(d2, d1, sh);
     uint32_t e = s_lit[v_lo & ((1u << kLitBits) - 1u)];
     if (e & 0x400u) e = s_lit[(e >> 16) + ((v_lo >> kLitBits) & ((1u << (e & 15u)) - 1u))];
@@ -190,6 +206,7 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
   while (!final_block && st == ZH_OK) {  // inflate.nim:273-289
     // ---- block header: staged, then read by wave 0 like the serial kernel does ----
     const uint64_t hbase = pos >> 5;  // dword of the header's first bit
+    KPROF_MARK(4);
     __syncthreads();
     for (uint32_t i = tid; i < kHeaderWords; i += kSplitThreads) s_in[i] = load_dword((hbase + i) * 4);
     __syncthreads();
@@ -320,6 +337,7 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
       }
     }
     __syncthreads();
+    KPROF_MARK(0);
     const uint32_t btype = s_c_btype;
     st = (int)s_c_st;
     if (s_c_final) final_block = true;
@@ -351,22 +369,47 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
       const uint64_t base_bit = pos & ~(uint64_t)31;
       const uint32_t rel0 = (uint32_t)(pos - base_bit);
       __syncthreads();  // (everybody is done with the previous contents of s_in)
-      for (uint32_t i = tid; i < kStageWords; i += kSplitThreads) s_in[i] = load_dword(((base_bit >> 5) + i) * 4);
+      {
+        constexpr uint32_t kWords = kSuperBits / 32u + kSubWords;  // the superchunk + the row behind it
+        constexpr uint32_t kLoads = (kWords + kSplitThreads - 1u) / kSplitThreads;  // 17 dwords a thread
+        const uint64_t w0 = base_bit >> 5;
+        uint32_t dw[kLoads];
+        if ((w0 + kLoads * kSplitThreads) * 4 <= end) {  // all of it inside the input: plain loads
+#pragma unroll
+          for (uint32_t j = 0; j < kLoads; j++) dw[j] = asrc[w0 + tid + j * kSplitThreads];
+        } else {
+#pragma unroll
+          for (uint32_t j = 0; j < kLoads; j++) dw[j] = load_dword((w0 + tid + j * kSplitThreads) * 4);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kLoads; j++) {
+          const uint32_t w = tid + j * kSplitThreads;
+          if (w < kWords) s_in[(w & (kSubWords - 1u)) * kStageRow + (w >> 4)] = dw[j];
+        }
+      }
       if (tid == 0) {
-        s_tterm = kSplitThreads;
-        s_any[0] = 0;
-        s_any[1] = 0;
+        s_first_dirty[0] = s_first_dirty[1] = kSplitThreads;
+        s_first_term[0] = s_first_term[1] = kSplitThreads;
       }
       const uint64_t end_bit = end * 8;
       const uint32_t end_rel = end_bit > base_bit
                                    ? (uint32_t)(end_bit - base_bit < 0xfffffff0ull ? end_bit - base_bit : 0xfffffff0ull)
                                    : 0u;
       __syncthreads();
+      KPROF_MARK(1);
+      KPROF_COUNT(5, 1);
       const uint32_t limit = (tid + 1u) * kSubBits;
       uint32_t my_start = tid == 0 ? rel0 : tid * kSubBits;
       bool dirty = true;
       RunResult r = {0, 0, 0};
+      // A turn: threads whose start changed decode again; then every thread takes the end of the
+      // thread before it as its start.  Threads below the first one whose start changed ("dirty")
+      // have starts that follow from thread 0's exact one: they are final.  The superchunk is done
+      // when that final prefix reaches its end, or a thread that met the end of the block (or an
+      // error) -- what lies behind that is not this block's code and never settles.
+      uint32_t tterm = kSplitThreads, prev_fd = 0;
       for (uint32_t turn = 1;; turn++) {
+        const uint32_t par = turn & 1u;
         if (dirty) {
           if (my_start == kNoStart) {
             r.end = kNoStart;
@@ -381,16 +424,83 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
         const uint32_t ns = tid == 0 ? rel0 : s_end[tid - 1u];
         dirty = ns != my_start;
         my_start = ns;
-        if (dirty) s_any[turn & 1u] = turn;
+        if (dirty) atomicMin(&s_first_dirty[par], tid);
+        else if (my_start != kNoStart && r.term) atomicMin(&s_first_term[par], tid);
+        if (tid == 0) {  // the other parity's words are free: nobody reads them before the next barrier
+          s_first_dirty[par ^ 1u] = kSplitThreads;
+          s_first_term[par ^ 1u] = kSplitThreads;
+        }
         __syncthreads();
-        const bool again = s_any[turn & 1u] == turn;
-        if (!again) break;
+        KPROF_COUNT(6, 1);
+        const uint32_t fd = s_first_dirty[par], ft = s_first_term[par];
+        if (ft < fd || fd == kSplitThreads) {
+          tterm = ft < fd ? ft : kSplitThreads;
+#ifdef ZH_EMU
+          if (tid == 0 && getenv("ZH_DBG_TURNS")) fprintf(stderr, "superchunk turns %u\n", turn);
+#endif
+          break;
+        }
+        const uint32_t gain = fd - prev_fd;
+        prev_fd = fd;
+        if (turn < kMinTurns || gain >= kSlowGain) continue;
+        // ---- the speculation has not settled (periodic data keeps a wrong start out of step for
+        // ever: the final prefix would grow by one thread a turn).  All-starts pass over the threads
+        // from `fd` on: a wave takes a subchunk, its lanes 64 consecutive bit positions, blocks of
+        // 64 positions from the subchunk's last to its first; every lane decodes the token at its
+        // position, and where that token leads is known already (a later lane of the block, by
+        // pointer doubling, or the block done before).  The first 48 positions' results are the
+        // subchunk's map start -> end.
+        KPROF_COUNT(5, 1u << 16);
+        const uint32_t map_end = fd + kMapGroup < kSplitThreads ? fd + kMapGroup : kSplitThreads;
+        for (uint32_t t = fd + (tid >> 6); t < map_end; t += kSplitThreads / 64u) {
+          const uint32_t t_lim = (t + 1u) * kSubBits;
+          uint32_t next_e = 0;  // block behind this one: lane l = result of position blockEnd + l
+          for (int b = (int)(kSubBits / 64u) - 1; b >= 0; b--) {
+            const uint32_t p = t * kSubBits + (uint32_t)b * 64u + lane, block_end = t * kSubBits + (uint32_t)b * 64u + 64u;
+            uint32_t rec, kind;
+            const uint32_t tb = decode_at(p, &rec, &kind);
+            const uint32_t q = p + tb;
+            // state: 0x100 | result once known, else the lane (of this block) the token leads to
+            uint32_t v;
+            if (kind != 0u || q > end_rel) v = 0x100u | kMapTerm;
+            else if (q >= t_lim) v = 0x100u | (q - t_lim);
+            else if (q >= block_end) v = 0x200u | (q - block_end);  // a lane of the block behind
+            else v = q - (block_end - 64u);
+            const uint32_t from_next = (uint32_t)__shfl((int)next_e, (int)(v & 63u), 64);
+            if (v & 0x200u) v = 0x100u | from_next;
+            while (__ballot(v < 0x100u)) {
+              const uint32_t w = (uint32_t)__shfl((int)v, (int)(v & 63u), 64);
+              if (v < 0x100u) v = w;
+            }
+            next_e = v & 0xffu;
+          }
+          if (lane < kStartSpan) s_map[t][lane] = (uint8_t)next_e;
+        }
+        __syncthreads();
+        if (tid == 0) {  // follow the maps from the last final end
+          uint32_t sp = s_end[fd - 1u];  // (thread 0 is never dirty: fd >= 1)
+          for (uint32_t t = fd; t < map_end; t++) {
+            uint32_t e = kNoStart;
+            if (sp != kNoStart) {
+              const uint32_t m = s_map[t][sp - t * kSubBits];
+              if (m != kMapTerm) e = (t + 1u) * kSubBits + m;
+            }
+            s_end[t] = e;
+            sp = e;
+          }
+        }
+        __syncthreads();
+        {  // the mapped threads (and the one behind them) take their exact starts; whoever's start
+           // changed decodes again in the next turn, which also settles what lies behind the group
+          const uint32_t ns2 = tid == 0 ? rel0 : s_end[tid - 1u];
+          if (ns2 != my_start) {
+            my_start = ns2;
+            dirty = true;
+          }
+        }
+        prev_fd = map_end - 1u;  // (the group is final after the next turn: judge its gain from there)
       }
-      // every start is the serial decoder's now.  The first thread (in stream order) that met the
-      // end of the block or an error decides how the superchunk ends.
-      if (my_start != kNoStart && r.term) atomicMin(&s_tterm, tid);
-      __syncthreads();
-      const uint32_t tterm = s_tterm;
+      KPROF_MARK(2);
       const bool active = my_start != kNoStart && tid <= tterm;
       const uint32_t n_eff = active ? r.n : 0u;
       const uint32_t incl = zh_wave_scan(n_eff);
@@ -410,7 +520,9 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
         st = ZH_ERR_DST_TOO_SMALL;
         break;
       }
+      KPROF_MARK(3);
       if (active && r.n) (void)run(my_start, limit, end_rel, tok + ntok + before);
+      KPROF_MARK(4);
       ntok += total;
       if (tterm < kSplitThreads) {
         const uint32_t term = s_c_term;
@@ -422,6 +534,8 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
     }
   }
   if (tid == 0) tok[ntok] = kRecSpecial | kRecEnd | ((uint32_t)st << 16);
+  KPROF_COUNT(7, 1);
+  if (tid == 0) KPROF_FLUSH(48, 8);
 }
 
 // ---------------------------------------------------------------------------

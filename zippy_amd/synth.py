@@ -109,6 +109,16 @@ def gen_batch(kind, n_buffers, size, first_index=0):
             out[i] = np.random.default_rng(SEED_BASE + idx).integers(0, 256, size, dtype=np.uint8)
         elif kind == "zero":
             out[i] = 0
+        elif kind == "text":  # only the text class of G-mix (tuning aid: no incompressible stretches)
+            rng = np.random.default_rng(SEED_BASE + idx)
+            pos = 0
+            while pos < size:
+                files = _CLASSES[0][1]
+                data = np.frombuffer(corpus_file(files[int(rng.integers(len(files)))]), dtype=np.uint8)
+                take = min(int(rng.integers(4096, 65537)), size - pos, data.size)
+                off = int(rng.integers(0, data.size - take + 1))
+                out[i, pos:pos + take] = data[off:off + take]
+                pos += take
         else:
             raise ValueError(kind)
     return out
