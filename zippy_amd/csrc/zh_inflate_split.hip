@@ -39,13 +39,12 @@ constexpr uint32_t kSplitThreads = 256;
 constexpr uint32_t kSubBits = 512;                            // one thread's share of a superchunk
 constexpr uint32_t kSuperBits = kSplitThreads * kSubBits;     // 16 KiB of the stream per turn
 constexpr uint32_t kSubWords = kSubBits / 32u;                 // 16
-// The staged superchunk is stored transposed: dword w of the superchunk -- the k-th dword (k = w % 16)
-// of subchunk t = w / 16 -- sits at k * kStageRow + t.  Thread t then reads LDS bank (4k + t) % 64
-// whatever its progress k: the 64 lanes of a wave never meet in a bank (in the plain layout they
-// are 16 dwords apart and share four banks, a 16-way conflict on every read).  Row t = 256 holds the
-// dwords the last subchunk's tokens reach into.
-constexpr uint32_t kStageRow = kSplitThreads + 4u;
-constexpr uint32_t kStageWords = kSubWords * kStageRow;
+// The staged superchunk gives every subchunk 19 dwords: its own 16 and a copy of the next three
+// (a token that starts in the subchunk reads at most that far), so dword w of the superchunk sits
+// at w + 3 * (w / 16) and a token's three dwords are consecutive.  19 is odd: the lanes of a wave,
+// one subchunk apart, read 64 different banks (16 apart they would share four).
+constexpr uint32_t kSubStride = kSubWords + 3u;
+constexpr uint32_t kStageWords = (kSplitThreads + 1u) * kSubStride;
 constexpr uint32_t kHeaderWords = 288;                        // a dynamic header is < 900 bytes
 constexpr uint32_t kDistSub = 256;                            // second-level distance tables
 constexpr uint32_t kNoStart = 0xffffffffu;                    // "the thread before me ended the block"
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
   __shared__ uint32_t s_first_dirty[2], s_first_term[2];  // per turn parity
   // all-starts map of a subchunk: entry i = where the decode that starts i bits into the subchunk
   // comes out, in bits behind the subchunk's end (or kMapTerm)
-  __shared__ uint8_t s_map[kSplitThreads][kStartSpan];
+  __shared__ uint8_t s_map[kMapGroup][kStartSpan];
   // block / superchunk control words written by one thread, read by all
   __shared__ uint32_t s_c_btype, s_c_final, s_c_st, s_c_stored_len, s_c_term, s_c_endrel;
   __shared__ uint64_t s_c_pos;
@@ -122,8 +121,8 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
   // returns the token's bits (0: not a token, see *kind) and its record
   auto decode_at = [&](uint32_t p, uint32_t* rec, uint32_t* kind) -> uint32_t {
     const uint32_t wi = p >> 5, sh = p & 31u;
-    auto staged = [&](uint32_t w) -> uint32_t { return s_in[(w & (kSubWords - 1u)) * kStageRow + (w >> 4)]; };
-    const uint32_t d0 = staged(wi), d1 = staged(wi + 1u), d2 = staged(wi + 2u);
+    const uint32_t si = wi + 3u * (p / kSubBits);
+    const uint32_t d0 = s_in[si], d1 = s_in[si + 1u], d2 = s_in[si + 2u];
     const uint32_t v_lo = zh_alignbit(d1, d0, sh), v_hi = zh_alignbit(d2, d1, sh);
     uint32_t e = s_lit[v_lo & ((1u << kLitBits) - 1u)];
     if (e & 0x400u) e = s_lit[(e >> 16) + ((v_lo >> kLitBits) & ((1u << (e & 15u)) - 1u))];
@@ -384,7 +383,11 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
 #pragma unroll
         for (uint32_t j = 0; j < kLoads; j++) {
           const uint32_t w = tid + j * kSplitThreads;
-          if (w < kWords) s_in[(w & (kSubWords - 1u)) * kStageRow + (w >> 4)] = dw[j];
+          if (w < kWords) {
+            const uint32_t at = w + 3u * (w / kSubWords);
+            s_in[at] = dw[j];
+            if ((w & (kSubWords - 1u)) < 3u && w >= kSubWords) s_in[at - 3u] = dw[j];  // the copy behind the subchunk before
+          }
         }
       }
       if (tid == 0) {
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
             }
             next_e = v & 0xffu;
           }
-          if (lane < kStartSpan) s_map[t][lane] = (uint8_t)next_e;
+          if (lane < kStartSpan) s_map[t - fd][lane] = (uint8_t)next_e;
         }
         __syncthreads();
         if (tid == 0) {  // follow the maps from the last final end
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
           for (uint32_t t = fd; t < map_end; t++) {
             uint32_t e = kNoStart;
             if (sp != kNoStart) {
-              const uint32_t m = s_map[t][sp - t * kSubBits];
+              const uint32_t m = s_map[t - fd][sp - t * kSubBits];
               if (m != kMapTerm) e = (t + 1u) * kSubBits + m;
             }
             s_end[t] = e;
@@ -521,6 +524,8 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
         break;
       }
       KPROF_MARK(3);
+      // (parking every run's records in HBM and copying them into place here was tried: the
+      // scattered 4-byte stores of the speculative turns cost more than this second decode)
       if (active && r.n) (void)run(my_start, limit, end_rel, tok + ntok + before);
       KPROF_MARK(4);
       ntok += total;
