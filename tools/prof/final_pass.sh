@@ -1,15 +1,26 @@
 #!/bin/bash
 # The per-round evidence under profiles/ (run on the GPU box from the repo root):
-#   bash tools/prof/final_pass.sh r01_g
-# -> gpurun_out/<tag>_bench.json, _kernel_stats.csv, _pytest_gpu.log, _c5.json, _host_api.json, hbm_traffic.json
-R=$(pwd); T=${1:-r01}
+#   bash tools/prof/final_pass.sh r02_a
+# -> gpurun_out/<tag>_bench.json (BASELINE metric), _c2/_c3/_c3own/_c4/_c4share/_c5 .json (the other
+#    BASELINE configs), _kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same bench command),
+#    _pytest_gpu.log, _host_api.json, _single_call.json, hbm_traffic.json (two --pmc passes)
+R=$(pwd); T=${1:-r02}
 O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -q > $O/${T}_pytest_gpu.log 2>&1
-timeout 600 python bench.py --steps 5 --warmup 1 2>/dev/null | tail -1 > $O/${T}_bench.json
+timeout 900 python -m pytest tests -m gpu -q > $O/${T}_pytest_gpu.log 2>&1
+timeout 600 python bench.py --steps 10 --warmup 2 2>/dev/null | tail -1 > $O/${T}_bench.json
+# config 2: 1024 x 64 KiB compress BestSpeed; config 3: 4096 x 1 MiB uncompress only (own streams, and
+# the foreign set: gzip members made by system zlib level 6); config 4: DefaultCompression, the whole
+# batch on one GPU and one GPU's share of eight (512 x 1 MiB); config 5: tools/bench_c5.py
+timeout 300 python bench.py --buffers 1024 --size 65536 --compress-only --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c2.json
+timeout 600 python bench.py --uncompress-only --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c3own.json
+timeout 900 python bench.py --foreign 6 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c3.json
+timeout 600 python bench.py --level -1 --compress-only --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c4.json
+timeout 600 python bench.py --level -1 --buffers 512 --compress-only --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c4share.json
 timeout 300 python tools/bench_c5.py --plain 2>/dev/null | tail -1 > $O/${T}_c5.json
 timeout 300 python tools/bench_c5.py --level -1 --steps 2 2>/dev/null | tail -1 >> $O/${T}_c5.json
 timeout 300 python tools/bench_host_api.py --reps 2 2>/dev/null | tail -1 > $O/${T}_host_api.json
+timeout 300 python tools/bench_single_call.py 2>/dev/null | tail -1 > $O/${T}_single_call.json
 cd /tmp
 rm -rf /tmp/kt /tmp/pf /tmp/pw
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${T}_rocprof_bench.log 2>&1
@@ -18,4 +29,4 @@ timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o pw -- python
 cd $R
 python tools/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) > $O/${T}_kernel_stats.csv 2>$O/${T}_summary.err
 python tools/pmc_traffic.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) --buffers 4096 --size 1048576 > $O/hbm_traffic.json 2>>$O/${T}_summary.err
-tail -2 $O/${T}_pytest_gpu.log; cat $O/${T}_bench.json | cut -c1-400; head -8 $O/${T}_kernel_stats.csv
+tail -2 $O/${T}_pytest_gpu.log; for f in bench c2 c3own c3 c4 c4share; do echo "== $f"; cut -c1-700 $O/${T}_$f.json; done; head -12 $O/${T}_kernel_stats.csv
