@@ -137,5 +137,39 @@ def main(first, count):
     return bad
 
 
+def mutations(count, seed=20260926):
+    """tests/fuzz.nim:16-33 at the reference's scale: `count` single-byte mutations of the reference's
+    own .gz fixtures plus the same streams truncated at the mutated byte (2 x count blobs), through
+    BOTH inflate paths; accept/reject decision and bytes must equal the oracle's."""
+    import parity_cases as pc
+    eng = api.engine()
+    blobs = pc.mutated_fixtures(count, seed=seed)
+    want = []
+    for b in blobs:
+        try:
+            want.append(oracle.uncompress(b, oracle.dfDetect))
+        except oracle.ZippyError:
+            want.append(None)
+    bad = 0
+    for mode, name in ((0, "split"), (1, "serial")):
+        eng.set_inflate_mode(mode)
+        accepted = 0
+        for lo in range(0, len(blobs), 4000):
+            outs, sts = eng.uncompress_batch(blobs[lo:lo + 4000], oracle.dfDetect)
+            for k, (o, st) in enumerate(zip(outs, sts)):
+                w = want[lo + k]
+                accepted += st == 0
+                if (st == 0) != (w is not None) or (st == 0 and o != w):
+                    bad += 1
+                    print("MUTATION MISMATCH", name, lo + k, len(blobs[lo + k]), st)
+        print("gpu_fuzz mutations: inflate=%s blobs %d (flip + truncate of %d mutations) accepted %d rejected %d "
+              "mismatches so far %d" % (name, len(blobs), count, accepted, len(blobs) - accepted, bad), flush=True)
+    eng.set_inflate_mode(-1)
+    print("gpu_fuzz mutations: oracle accepted %d of %d; bad %d" % (sum(w is not None for w in want), len(blobs), bad))
+    return bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--mutations":
+        sys.exit(1 if mutations(int(sys.argv[2]) if len(sys.argv) > 2 else 10000) else 0)
     sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 4) else 0)
