@@ -38,7 +38,7 @@ void zh_launch_inflate_write(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, 
                              const uint32_t* tok_pool, const uint64_t* tok_off);
 void zh_launch_segments_reduce(hipStream_t, ZhInflateArgs seg, ZhInflateArgs whole);
 void zh_launch_l1_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int huffman_only,
-                        uint16_t* table_pool);
+                        uint16_t* table_pool, uint32_t* next_frag);
 uint32_t zh_l1_table_slots(void);
 void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint16_t* head_scratch,
                           uint64_t* prevw);
@@ -226,6 +226,7 @@ struct zh_plan {
   uint16_t* head_scratch = nullptr;  // chain levels: `head` per block, previous-position links and
   size_t head_bytes = 0;             // best match per position (zh_chain_match.hip)
   uint16_t* l1_tables = nullptr;  // BestSpeed: pool of per-wave hash tables (zh_l1_match.hip)
+  uint32_t* l1_counter = nullptr; // ... and the counter its waves draw fragments from
   uint64_t* chain_prev = nullptr;
   uint32_t* chain_best = nullptr;
   uint64_t dst_lo = 0, dst_hi = 0;  // byte range of d_dst covered by the slots
@@ -409,6 +410,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   const size_t o_head = ar.reserve(p->head_bytes);
   // one 32 KiB hash table per persistent matcher wave (zh_launch_l1_match: min(fragments, slots) waves)
   const size_t o_l1tab = ar.reserve(level == 1 ? std::min<size_t>(nf, zh_l1_table_slots()) * 32768 : 0);
+  const size_t o_l1ctr = ar.reserve(256);
   const size_t o_cprev = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 8 : 0);
   const size_t o_cbest = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 4 : 0);
   ar.reserve(256);
@@ -478,6 +480,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   a.status = p->status = carve<int32_t>(base, o_st);
   p->head_scratch = carve<uint16_t>(base, o_head);
   p->l1_tables = carve<uint16_t>(base, o_l1tab);
+  p->l1_counter = carve<uint32_t>(base, o_l1ctr);
   p->chain_prev = carve<uint64_t>(base, o_cprev);
   p->chain_best = carve<uint32_t>(base, o_cbest);
   p->h_bufs.swap(bufs);
@@ -767,7 +770,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     }
     if (p->level == 1 || p->level == -2) {
       prof_mark(p, "zh_l1_match_kernel");
-      zh_launch_l1_match(s, d_src, a, p->level == -2, p->l1_tables);
+      zh_launch_l1_match(s, d_src, a, p->level == -2, p->l1_tables, p->l1_counter);
     } else if (p->level != 0) {
       const int* cfg = kChainConfig[p->level == -1 ? 6 : p->level];
       prof_mark(p, "memset_head");
@@ -1800,7 +1803,7 @@ extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int lev
   hipStream_t s = ctx->stream;
   const ZhCompressArgs& a = p->ca;
   if (level == 1 || level == -2) {
-    zh_launch_l1_match(s, d_src.p, a, level == -2, p->l1_tables);
+    zh_launch_l1_match(s, d_src.p, a, level == -2, p->l1_tables, p->l1_counter);
   } else {
     const int* cfg = kChainConfig[level == -1 ? 6 : level];
     ZH_HIP(ctx, hipMemsetAsync(p->head_scratch, 0, p->head_bytes, s));

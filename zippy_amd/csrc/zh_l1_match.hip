@@ -37,7 +37,8 @@ struct __attribute__((packed)) Bytes16 {
 
 __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restrict__ d_src,
                                                          ZhCompressArgs a, int huffman_only,
-                                                         uint16_t* __restrict__ table_pool) {
+                                                         uint16_t* __restrict__ table_pool,
+                                                         uint32_t* __restrict__ next_frag) {
   __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
   // parse: 4096 byte-wide counters (4 per dword) of the probes per table slot in one step,
   // all zero between steps; afterwards the first 4 KiB are the coverage bitmap (bit p set:
@@ -53,7 +54,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   // this wave's hash table (u16 x 16384, snappy.nim:7) in the L2/MALL-resident pool: read with
   // L1-bypassing loads, written through, re-zeroed for every fragment the wave takes
   uint16_t* const s_table = table_pool + (size_t)blockIdx.x * 16384u;
-  for (uint32_t f = blockIdx.x; f < a.nfrags; f += gridDim.x) {
+  // fragments are handed out first come, first served (`next_frag` starts at gridDim.x): they cost
+  // very different amounts of time, and a fixed share per wave leaves the last ones running alone
+  for (uint32_t f = blockIdx.x; f < a.nfrags;) {
   KPROF_DECL(16);  // cycles: 0 stage-in, 1 vector part, 2 fast walk, 3 slow walk, 4 inserts, 5 stats; counts: 6..12
   const ZhFragDesc fd = a.frags[f];
   const uint32_t n = fd.len;
@@ -530,6 +533,11 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   KPROF_COUNT(11, 1);
   KPROF_FLUSH(0, 16);
   zh_wave_sync();
+  {
+    uint32_t nf = 0;
+    if (lane == 0) nf = atomicAdd(next_frag, 1u);
+    f = zh_bcast(nf);
+  }
   }  // next fragment of this wave
 }
 
@@ -543,10 +551,13 @@ extern "C" uint32_t zh_l1_table_slots(void) {
   return slots;
 }
 
+__global__ void zh_l1_set_counter_kernel(uint32_t* next_frag, uint32_t v) { *next_frag = v; }
+
 extern "C" void zh_launch_l1_match(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
-                                   int huffman_only, uint16_t* table_pool) {
+                                   int huffman_only, uint16_t* table_pool, uint32_t* next_frag) {
   if (!a.nfrags) return;
   const uint32_t grid = a.nfrags < zh_l1_table_slots() ? a.nfrags : zh_l1_table_slots();
+  hipLaunchKernelGGL(zh_l1_set_counter_kernel, dim3(1), dim3(1), 0, stream, next_frag, grid);
   hipLaunchKernelGGL(zh_l1_match_kernel, dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
-                     table_pool);
+                     table_pool, next_frag);
 }
