@@ -544,16 +544,39 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
 }
 
 // ---------------------------------------------------------------------------
-// Writer: one wave per stream turns the token records into bytes.  Rounds of at most 64 output
-// bytes get one lane per OUTPUT byte (the serial kernel's output wave, zh_inflate.hip).
+// Writer: four waves per stream turn the token records into bytes, up to 1024 output bytes a
+// round; a thread owns FOUR consecutive output bytes (one unaligned dword store).  A round takes up
+// to 512 records (two per thread) whose output fits: a prefix sum places them, their starts are
+// scattered into a byte -> record map in LDS and a running maximum tells every byte its record.  A
+// byte is a literal, a copy of a byte before the round (read back through L2: the LZ window is the
+// output itself), or a copy of a byte of this round -- those chase their source by pointer
+// doubling in LDS, which is inflate.nim:227-250's byte-sequential copy semantics (overlapping
+// copies included) without a loop over the tokens.  A stream is a chain of rounds, each a chain of
+// LDS and L2 round trips: wide rounds are what shortens it (64-byte rounds by one wave: 13 ms for
+// a 1 MiB stream whatever the batch).  A single copy that does not fit a round goes alone.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void zh_inflate_write_kernel(const uint8_t* __restrict__ d_src,
-                                                              uint8_t* __restrict__ d_dst, ZhInflateArgs a,
-                                                              const uint32_t* __restrict__ tok_pool,
-                                                              const uint64_t* __restrict__ tok_off) {
-  constexpr uint32_t kRing = 512;  // token records staged in LDS (a power of two)
-  __shared__ uint32_t s_tok[kRing];
-  __shared__ uint8_t s_map[64];
+namespace {
+constexpr uint32_t kWrThreads = 256;
+constexpr uint32_t kWrWaves = kWrThreads / 64u;
+constexpr uint32_t kWrRound = kWrThreads * 4u;  // output bytes per round
+constexpr uint32_t kWrRecs = kWrThreads * 2u;   // records looked at per round
+constexpr uint32_t kWrRing = 2048;              // token records staged in LDS (a power of two)
+}  // namespace
+
+__global__ __launch_bounds__(256) void zh_inflate_write_kernel(const uint8_t* __restrict__ d_src,
+                                                               uint8_t* __restrict__ d_dst, ZhInflateArgs a,
+                                                               const uint32_t* __restrict__ tok_pool,
+                                                               const uint64_t* __restrict__ tok_off) {
+  __shared__ uint32_t s_tok[kWrRing];
+  __shared__ uint32_t s_map32[kWrRound / 2];  // u16 per byte: (index in the round of the record that starts there) + 1
+  __shared__ uint32_t s_par32[kWrRound / 2];  // u16 per byte: the byte of this round it copies (itself: a root)
+  __shared__ uint32_t s_val32[kWrRound / 4];  // u8 per byte: its value (valid for roots)
+  __shared__ uint32_t s_w[6][kWrWaves];       // per-wave partial results
+  __shared__ uint32_t s_flag[4];              // round-wide flags (see below)
+  uint16_t* const s_map = reinterpret_cast<uint16_t*>(s_map32);
+  uint16_t* const s_par = reinterpret_cast<uint16_t*>(s_par32);
+  uint8_t* const s_val = reinterpret_cast<uint8_t*>(s_val32);
+  const uint32_t tid = threadIdx.x, wv = tid >> 6;
   const unsigned lane = zh_lane();
   const uint32_t sid = blockIdx.x;
   if (a.status[sid] != ZH_OK) return;
@@ -564,16 +587,19 @@ __global__ __launch_bounds__(64) void zh_inflate_write_kernel(const uint8_t* __r
   const uint64_t cap = bd.dst_cap;
   const uint32_t* tok = tok_pool + tok_off[sid];
 
-  uint64_t op = 0;  // bytes produced
+  uint64_t op = 0;  // bytes produced (the same in every thread)
   int st = ZH_OK;
-  auto own_output_visible = [&]() {
-    zh_wave_sync();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  };
   auto ld_out = [&](uint64_t at) -> uint32_t {
     return __hip_atomic_load(dst + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  // inflate.nim:224-250: one LZ copy of `length` bytes from `dist` back, at op (wave-uniform)
+  // every thread's stores have reached L2 and every thread knows it: match sources are read back
+  // past this CU's L1 (which may hold a stale copy of a line the workgroup has since extended)
+  auto output_visible = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+  };
+  // inflate.nim:224-250: one LZ copy of `length` bytes from `dist` back, at op (uniform arguments;
+  // the output written so far is visible)
   auto lz_copy = [&](uint32_t length, uint32_t dist) {
     if (dist > op) {  // inflate.nim:224-225
       st = ZH_ERR_INVALID_BUFFER;
@@ -583,76 +609,118 @@ __global__ __launch_bounds__(64) void zh_inflate_write_kernel(const uint8_t* __r
       st = ZH_ERR_DST_TOO_SMALL;
       return;
     }
-    own_output_visible();
     const uint64_t sb = op - dist;
     if (dist >= length) {
-      for (uint32_t i = lane; i < length; i += 64) dst[op + i] = (uint8_t)ld_out(sb + i);
+      for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = (uint8_t)ld_out(sb + i);
     } else if (dist == 1) {
       const uint8_t v = (uint8_t)ld_out(sb);
-      for (uint32_t i = lane; i < length; i += 64) dst[op + i] = v;
+      for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = v;
     } else {
-      for (uint32_t i = lane; i < length; i += 64) dst[op + i] = (uint8_t)ld_out(sb + i % dist);
+      for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = (uint8_t)ld_out(sb + i % dist);
     }
     op += length;
   };
 
-  // records [ti, hi) are in the ring; `pre` holds records [hi, hi + 256) on their way from HBM
+  // records [ti, hi) are in the ring; `pre` holds records [hi, hi + 1024) on their way from HBM
   uint64_t ti = 0, hi = 0;
   uint32_t pre[4];
+  auto fetch_ahead = [&]() {
 #pragma unroll
-  for (int k = 0; k < 4; k++) pre[k] = tok[lane + 64u * k];
-  auto refill = [&]() {
-    zh_wave_sync();
-#pragma unroll
-    for (int k = 0; k < 4; k++) s_tok[(uint32_t)(hi + lane + 64u * k) & (kRing - 1u)] = pre[k];
-    hi += 256;
-#pragma unroll
-    for (int k = 0; k < 4; k++) pre[k] = tok[hi + lane + 64u * k];
-    zh_wave_sync();
+    for (int k = 0; k < 4; k++) pre[k] = tok[hi + tid + kWrThreads * k];
   };
+  auto commit_ahead = [&]() {  // (callers keep a barrier between this and the ring's readers)
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_tok[(uint32_t)(hi + tid + kWrThreads * k) & (kWrRing - 1u)] = pre[k];
+    hi += 4u * kWrThreads;
+  };
+  fetch_ahead();
+  if (tid < 4) s_flag[tid] = 0;
 
-  for (;;) {
-    while (hi < ti + 128u) refill();  // a round looks at 64 records (+ 2 behind a stored-run record)
-    op = zh_bcast64(op);
-    const uint32_t rec = s_tok[(uint32_t)(ti + lane) & (kRing - 1u)];
-    const uint64_t spm = __ballot((rec & kRecSpecial) != 0);
-    const uint32_t first_sp = spm ? (uint32_t)__ffsll((long long)spm) - 1u : 64u;
-    const uint32_t len = lane < first_sp ? rec & 0x1ffu : 0u;
-    const uint32_t incl = zh_wave_scan(len);
-    const uint64_t fit = __ballot(lane < first_sp && incl <= 64u);  // a prefix of the lanes
-    const uint32_t n = (uint32_t)__popcll(fit);
+  for (uint32_t round = 0;; round++) {
+    if (hi < ti + kWrRecs + 128u) {  // a round looks at 512 records (+ 2 behind a stored-run record)
+      commit_ahead();
+      fetch_ahead();
+    }
+    __syncthreads();
+    const uint32_t i0 = 2u * tid;
+    const uint32_t r0 = s_tok[(uint32_t)(ti + i0) & (kWrRing - 1u)], r1 = s_tok[(uint32_t)(ti + i0 + 1u) & (kWrRing - 1u)];
+    // ---- records up to the first special one ----
+    {
+      const uint64_t sp0 = __ballot((r0 & kRecSpecial) != 0), sp1 = __ballot((r1 & kRecSpecial) != 0);
+      const uint32_t f0 = sp0 ? 2u * ((uint32_t)__ffsll((long long)sp0) - 1u) : 128u;
+      const uint32_t f1 = sp1 ? 2u * ((uint32_t)__ffsll((long long)sp1) - 1u) + 1u : 128u;
+      const uint32_t fw = f0 < f1 ? f0 : f1;
+      if (lane == 0) s_w[0][wv] = fw < 128u ? wv * 128u + fw : kWrRecs;
+    }
+    __syncthreads();
+    uint32_t fs = kWrRecs;
+#pragma unroll
+    for (uint32_t w = 0; w < kWrWaves; w++) fs = min(fs, s_w[0][w]);
+    const uint32_t len0 = i0 < fs ? r0 & 0x1ffu : 0u, len1 = i0 + 1u < fs ? r1 & 0x1ffu : 0u;
+    const uint32_t incl = zh_wave_scan(len0 + len1);
+    if (lane == 63) s_w[1][wv] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kWrWaves; w++)
+      if (w < wv) before += s_w[1][w];
+    // where the records' output starts in the round
+    const uint32_t o0 = before + incl - len0 - len1, o1 = o0 + len0;
+    const bool fit0 = i0 < fs && o0 + len0 <= kWrRound, fit1 = i0 + 1u < fs && o1 + len1 <= kWrRound;
+    const bool lit0 = (r0 >> 9) & 1u, lit1 = (r1 >> 9) & 1u;
+    {
+      const uint64_t b0 = __ballot(fit0), b1 = __ballot(fit1);  // prefixes of the lanes (the sums grow)
+      const uint32_t endl = fit1 ? o1 + len1 : fit0 ? o0 + len0 : 0u;
+      const uint32_t nfit = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
+      const uint32_t wend = b0 ? (uint32_t)__builtin_amdgcn_readlane(endl, (uint32_t)__popcll(b0) - 1u) : 0u;
+      if (lane == 0) {
+        s_w[2][wv] = nfit;
+        s_w[3][wv] = wend;
+      }
+      // inflate.nim:224-225 `distance > op` (a distance is at most 32768)
+      if (op < 32768u && ((fit0 && !lit0 && (uint64_t)(r0 >> 16) > op + o0) ||
+                          (fit1 && !lit1 && (uint64_t)(r1 >> 16) > op + o1)))
+        s_flag[round & 1u] = 1;  // (flag words alternate between rounds; the idle one is cleared below)
+    }
+    __syncthreads();
+    uint32_t n = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kWrWaves; w++) {
+      n += s_w[2][w];
+      total = max(total, s_w[3][w]);
+    }
+    const bool bad_dist = s_flag[round & 1u] != 0;
+    if (tid == 0) {
+      s_flag[(round & 1u) ^ 1u] = 0;
+      s_flag[2u + ((round & 1u) ^ 1u)] = 0;
+    }
     if (n == 0) {
-      const uint32_t r0 = __builtin_amdgcn_readlane(rec, 0);
-      if (r0 & kRecSpecial) {
-        if ((r0 & (3u << 11)) == kRecStored) {  // inflate.nim:252-266: raw bytes
-          const uint32_t length = r0 >> 16;
-          const uint64_t off = (uint64_t)s_tok[(uint32_t)(ti + 1u) & (kRing - 1u)] |
-                               ((uint64_t)s_tok[(uint32_t)(ti + 2u) & (kRing - 1u)] << 32);
+      const uint32_t q0 = s_tok[(uint32_t)ti & (kWrRing - 1u)];
+      if (q0 & kRecSpecial) {
+        if ((q0 & (3u << 11)) == kRecStored) {  // inflate.nim:252-266: raw bytes
+          const uint32_t length = q0 >> 16;
+          const uint64_t off = (uint64_t)s_tok[(uint32_t)(ti + 1u) & (kWrRing - 1u)] |
+                               ((uint64_t)s_tok[(uint32_t)(ti + 2u) & (kWrRing - 1u)] << 32);
           if (op + length > cap) {
             st = ZH_ERR_DST_TOO_SMALL;
             break;
           }
-          for (uint32_t i = lane; i < length; i += 64) dst[op + i] = src[off + i];
+          for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = src[off + i];
           op += length;
           ti += 3;
+          output_visible();
           continue;
         }
-        st = (int)(r0 >> 16);  // end of the stream
+        st = (int)(q0 >> 16);  // end of the stream
         break;
       }
-      lz_copy(r0 & 0x1ffu, r0 >> 16);  // one copy of more than 64 bytes
+      lz_copy(q0 & 0x1ffu, q0 >> 16);  // one copy that does not fit a round
       if (st != ZH_OK) break;
       ti += 1;
+      output_visible();
       continue;
     }
-    const uint32_t total = __builtin_amdgcn_readlane(incl, n - 1u);
-    const bool in_chain = lane < n;
-    const bool is_lit = (rec >> 9) & 1u;
-    const uint32_t val = rec >> 16;
-    const uint32_t opre = incl - len;
-    const bool is_match = in_chain && !is_lit;
-    // inflate.nim:224-225 `distance > op` (a distance is at most 32768)
-    if (op < 32768u && __ballot(is_match && (uint64_t)val > op + opre)) {
+    if (bad_dist) {
       st = ZH_ERR_INVALID_BUFFER;
       break;
     }
@@ -660,46 +728,94 @@ __global__ __launch_bounds__(64) void zh_inflate_write_kernel(const uint8_t* __r
       st = ZH_ERR_DST_TOO_SMALL;
       break;
     }
-    zh_wave_sync();
-    s_map[lane] = 0;
-    zh_wave_sync();
-    if (in_chain) s_map[opre] = (uint8_t)(lane + 1u);
-    zh_wave_sync();
-    const uint32_t tk = zh_wave_scan_max(s_map[lane]);  // token lane + 1 of output byte `lane`
-    const uint32_t j = (tk - 1u) & 63u;
-    const uint32_t f1 = is_lit ? 0x9000u | val : val;  // a distance (<= 0x8000) as it is, a literal as 0x9000 | byte
-    const uint32_t gd = (uint32_t)__shfl((int)f1, (int)j, 64);
-    const bool live = lane < total;
-    uint32_t v = gd & 0xffu;
-    uint32_t par = lane;  // source byte inside this round (itself: a root)
-    bool far = false;
-    uint32_t back = 0;
-    if (live && gd < 0x9000u) {
-      if (gd <= lane) {
-        par = lane - gd;
-      } else {
-        back = gd - lane;  // bytes before this round's first
-        far = true;
+    // ---- byte -> record ----
+    s_map32[2u * tid] = 0;
+    s_map32[2u * tid + 1u] = 0;
+    __syncthreads();
+    if (fit0) s_map[o0] = (uint16_t)(i0 + 1u);
+    if (fit1) s_map[o1] = (uint16_t)(i0 + 2u);
+    __syncthreads();
+    uint32_t t[4];
+    {
+      const uint32_t m01 = s_map32[2u * tid], m23 = s_map32[2u * tid + 1u];
+      t[0] = m01 & 0xffffu;
+      t[1] = max(t[0], m01 >> 16);
+      t[2] = max(t[1], m23 & 0xffffu);
+      t[3] = max(t[2], m23 >> 16);
+    }
+    const uint32_t run = zh_wave_scan_max(t[3]);
+    if (lane == 63) s_w[4][wv] = run;
+    uint32_t carry = (uint32_t)__shfl_up((int)run, 1, 64);
+    if (lane == 0) carry = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t w = 0; w < kWrWaves; w++)
+      if (w < wv) carry = max(carry, s_w[4][w]);
+    // ---- every byte: literal, copy from before the round (far), or from inside it (near) ----
+    uint32_t par[4], val[4];
+    bool any_near = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t pb = 4u * tid + (uint32_t)j;  // byte of the round
+      const uint32_t tk = max(carry, t[j]);       // its record + 1 (>= 1 for every live byte)
+      const uint32_t rec = s_tok[(uint32_t)(ti + tk - 1u) & (kWrRing - 1u)];
+      par[j] = pb;
+      val[j] = (rec >> 16) & 0xffu;
+      if (pb < total && !((rec >> 9) & 1u)) {
+        const uint32_t dist = rec >> 16;
+        if (dist <= pb) {
+          par[j] = pb - dist;
+          any_near = true;
+        } else {
+          val[j] = ld_out(op + pb - dist);  // (written before this round: visible since its start)
+        }
       }
     }
-    if (__ballot(far)) {
-      own_output_visible();
-      if (far) v = ld_out(op - back);
-    }
-    if (__ballot(par != lane)) {
-      for (;;) {
-        const uint32_t pp = (uint32_t)__shfl((int)par, (int)par, 64);
-        const bool changed = pp != par;
-        par = pp;
-        if (!__ballot(changed)) break;
+    if (any_near) s_flag[2u + (round & 1u)] = 1;
+    s_par32[2u * tid] = par[0] | (par[1] << 16);
+    s_par32[2u * tid + 1u] = par[2] | (par[3] << 16);
+    s_val32[tid] = (val[0] & 0xffu) | ((val[1] & 0xffu) << 8) | ((val[2] & 0xffu) << 16) | (val[3] << 24);
+    __syncthreads();
+    if (s_flag[2u + (round & 1u)]) {
+      // par <- par[par] until every byte points at a root.  s_w[5][k & 1] counts the threads that
+      // moved in step k (cleared two steps ahead by thread 0, between the barriers).
+      if (tid == 0) s_w[5][0] = s_w[5][1] = 0;
+      __syncthreads();
+      for (uint32_t k = 0;; k++) {
+        bool changed = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t q = s_par[par[j]];
+          changed |= q != par[j];
+          par[j] = q;
+        }
+        if (changed) s_w[5][k & 1u] = 1;
+        __syncthreads();
+        const bool again = s_w[5][k & 1u] != 0;
+        if (!again) break;
+        s_par32[2u * tid] = par[0] | (par[1] << 16);
+        s_par32[2u * tid + 1u] = par[2] | (par[3] << 16);
+        if (tid == 0) s_w[5][(k & 1u) ^ 1u] = 0;
+        __syncthreads();
       }
-      v = (uint32_t)__shfl((int)v, (int)par, 64);
+#pragma unroll
+      for (int j = 0; j < 4; j++) val[j] = s_val[par[j]];
     }
-    if (live) dst[op + lane] = (uint8_t)v;
+    const uint32_t w = (val[0] & 0xffu) | ((val[1] & 0xffu) << 8) | ((val[2] & 0xffu) << 16) | (val[3] << 24);
+    const uint32_t pb0 = 4u * tid;
+    if (pb0 + 4u <= total) {
+      struct __attribute__((packed)) U32 { uint32_t v; };
+      reinterpret_cast<U32*>(dst + op + pb0)->v = w;  // (gfx950 global stores need no alignment)
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (pb0 + (uint32_t)j < total) dst[op + pb0 + (uint32_t)j] = (uint8_t)(w >> (8 * j));
+    }
     op += total;
     ti += n;
+    output_visible();
   }
-  if (lane == 0) {
+  if (tid == 0) {
     a.out_len[sid] = op;
     a.status[sid] = st;
   }
@@ -714,6 +830,6 @@ extern "C" void zh_launch_inflate_tokens(hipStream_t stream, const uint8_t* d_sr
 extern "C" void zh_launch_inflate_write(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a,
                                         const uint32_t* tok_pool, const uint64_t* tok_off) {
   if (!a.nbufs) return;
-  hipLaunchKernelGGL(zh_inflate_write_kernel, dim3(a.nbufs), dim3(64), 0, stream, d_src, d_dst, a, tok_pool,
+  hipLaunchKernelGGL(zh_inflate_write_kernel, dim3(a.nbufs), dim3(kWrThreads), 0, stream, d_src, d_dst, a, tok_pool,
                      tok_off);
 }
