@@ -26,7 +26,12 @@ def per_kernel(db_path, counter):
     rows = db.execute(
         "select k.name, count(*), sum(p.value) from counters_collection p join kernels k "
         "on k.dispatch_id = p.dispatch_id where p.counter_name = ? group by k.name", (counter,)).fetchall()
-    return {r[0].split("(")[0]: (r[1], r[2]) for r in rows}
+    out = {}
+    for name, calls, total in rows:  # "void zh_x_kernel<true>(...)" -> "zh_x_kernel"
+        key = name.split("(")[0].split("<")[0].replace("void ", "").strip()
+        c, t = out.get(key, (0, 0))
+        out[key] = (c + calls, t + total)
+    return out
 
 
 def main():

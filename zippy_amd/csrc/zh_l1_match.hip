@@ -18,6 +18,7 @@
 // u16 SoA), the litlen/distance histograms (u16 x 320), literal count and the
 // sum of extra bits -- everything the Huffman and emission kernels need.
 #include <cstdlib>
+#include <cstring>
 
 #include "zh_common.h"
 #include "zh_kprof.h"
@@ -35,6 +36,10 @@ struct __attribute__((packed)) Bytes16 {
 
 }  // namespace
 
+// kLdsTable: the wave's hash table in LDS (32 KiB: four waves per CU, no table traffic at all)
+// instead of the HBM pool.  A measurement aid for the trade DESIGN.md 4.1 describes -- with one
+// wave per fragment the pooled form is the faster one by far -- selected with ZH_L1_TABLE=lds.
+template <bool kLdsTable>
 __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restrict__ d_src,
                                                          ZhCompressArgs a, int huffman_only,
                                                          uint16_t* __restrict__ table_pool,
@@ -53,7 +58,8 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   const unsigned lane = zh_lane();
   // this wave's hash table (u16 x 16384, snappy.nim:7) in the L2/MALL-resident pool: read with
   // L1-bypassing loads, written through, re-zeroed for every fragment the wave takes
-  uint16_t* const s_table = table_pool + (size_t)blockIdx.x * 16384u;
+  __shared__ uint16_t s_table_lds[kLdsTable ? 16384 : 2];
+  uint16_t* const s_table = kLdsTable ? s_table_lds : table_pool + (size_t)blockIdx.x * 16384u;
   // fragments are handed out first come, first served (`next_frag` starts at gridDim.x): they cost
   // very different amounts of time, and a fixed share per wave leaves the last ones running alone
   for (uint32_t f = blockIdx.x; f < a.nfrags;) {
@@ -152,7 +158,8 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         // read back together with the candidate bytes
         uint32_t oldw = e0;
         if (valid && ((s_bits[h >> 5] >> (h & 31u)) & 1u))
-          oldw = __hip_atomic_load(s_table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          oldw = kLdsTable ? (uint32_t)s_table[h]
+                           : (uint32_t)__hip_atomic_load(s_table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t old = oldw & 0x7fffu;
         const bool fetch = valid && (oldw >> 15) == tag;  // equal bytes have equal tags
         const uint32_t ck = (h & (kCntWords * 4u - 1u)) >> 2, cs = (h & 3u) * 8u;
@@ -556,8 +563,17 @@ __global__ void zh_l1_set_counter_kernel(uint32_t* next_frag, uint32_t v) { *nex
 extern "C" void zh_launch_l1_match(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
                                    int huffman_only, uint16_t* table_pool, uint32_t* next_frag) {
   if (!a.nfrags) return;
-  const uint32_t grid = a.nfrags < zh_l1_table_slots() ? a.nfrags : zh_l1_table_slots();
+  static const bool lds = [] {
+    const char* e = getenv("ZH_L1_TABLE");
+    return e && strcmp(e, "lds") == 0;
+  }();
+  const uint32_t slots = lds ? 1024u : zh_l1_table_slots();  // (39.4 KiB of LDS: four waves per CU)
+  const uint32_t grid = a.nfrags < slots ? a.nfrags : slots;
   hipLaunchKernelGGL(zh_l1_set_counter_kernel, dim3(1), dim3(1), 0, stream, next_frag, grid);
-  hipLaunchKernelGGL(zh_l1_match_kernel, dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
-                     table_pool, next_frag);
+  if (lds)
+    hipLaunchKernelGGL(zh_l1_match_kernel<true>, dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
+                       table_pool, next_frag);
+  else
+    hipLaunchKernelGGL(zh_l1_match_kernel<false>, dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
+                       table_pool, next_frag);
 }
