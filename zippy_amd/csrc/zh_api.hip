@@ -1428,6 +1428,114 @@ static int host_detect(const uint8_t* s, size_t len, int fmt) {
 // size_hints: expected output sizes (ZIP central directory, gzip.nim:72-76 trustSize): they
 // replace the sizing pass of streams that carry no size; a stream that outgrows its hint falls
 // back to the deflate expansion bound.  crcs: CRC-32 of every output (whatever the container).
+// The uncompress counterpart of compress_batch_pipelined, for batches whose output sizes are all
+// known up front (gzip members: ISIZE; ZIP entries: the central directory): groups of about
+// ZH_PIPE_GROUP bytes of OUTPUT take turns, so that one group's kernels run while the group
+// before it goes home and the next one comes in.  kPipeFallback: run the batch the plain way
+// (does not split, no memory for the second set of buffers, or a stream outgrew its promise --
+// a member of 4 GiB and more, or a damaged one -- which the plain path knows how to retry).
+static int uncompress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
+                                      int data_format, const std::vector<uint64_t>& cap, void** dsts,
+                                      size_t* dst_lens, int32_t* statuses, uint32_t* crcs) {
+  uint64_t out_total = 0;
+  for (size_t i = 0; i < n; i++) out_total += cap[i];
+  const uint64_t group_bytes = std::max<uint64_t>(pipe_group_bytes(ctx), out_total / 16);
+  std::vector<size_t> cut{0};
+  uint64_t acc = 0;
+  for (size_t i = 0; i < n; i++) {
+    acc += cap[i];
+    if (acc >= group_bytes) {
+      cut.push_back(i + 1);
+      acc = 0;
+    }
+  }
+  if (cut.back() != n) cut.push_back(n);
+  const size_t G = cut.size() - 1;
+  if (G < 2) return kPipeFallback;
+  if (!ctx->copy_stream) ZH_HIP(ctx, hipStreamCreate(&ctx->copy_stream));
+  hipStream_t cs = ctx->copy_stream, ks = ctx->stream;
+  Trace tr;
+  std::vector<PipeGroup> gs(G);
+  int st;
+  for (size_t g = 0; g < G; g++) {  // every allocation up front: hipMalloc / hipFree would serialise the pipeline
+    PipeGroup& q = gs[g];
+    q.i0 = cut[g];
+    q.n = cut[g + 1] - cut[g];
+    q.src_total = layout_slices(lens + q.i0, q.n, q.soff, q.slen);
+    q.doff.resize(q.n);
+    q.dcap.resize(q.n);
+    for (size_t i = 0; i < q.n; i++) {
+      q.doff[i] = q.dst_total;
+      q.dcap[i] = cap[q.i0 + i];
+      q.dst_total += (q.dcap[i] + 255) & ~(uint64_t)255;
+    }
+    if (hipMalloc(&q.d_src.p, q.src_total + 256) != hipSuccess ||
+        hipMalloc(&q.d_dst.p, q.dst_total + 256) != hipSuccess ||
+        hipMalloc(&q.d_pack.p, q.dst_total + 256) != hipSuccess) {
+      (void)hipGetLastError();
+      return kPipeFallback;
+    }
+    ZH_HIP(ctx, hipEventCreate(&q.uploaded));
+    ZH_HIP(ctx, hipEventCreate(&q.packed));
+    st = zh_plan_uncompress(ctx, q.n, q.soff.data(), q.slen.data(), q.doff.data(), q.dcap.data(), data_format,
+                            &q.pg.p);
+    if (st == ZH_ERR_NOMEM) return kPipeFallback;
+    if (st) return st;
+    if (inflate_split_enabled(ctx)) (void)plan_token_pool(q.pg.p);  // (now, not in the middle of the pipeline)
+    if (crcs) zh_plan_request_crc32(q.pg.p, 1);
+  }
+  ZH_HIP(ctx, hipStreamSynchronize(ks));  // the plans' descriptors are in place
+  auto up = [&](size_t g) -> int {
+    PipeGroup& q = gs[g];
+    int e = upload_slices(ctx, cs, srcs + q.i0, q.soff, q.slen, q.src_total, q.d_src.p);
+    if (e) return e;
+    ZH_HIP(ctx, hipEventRecord(q.uploaded, cs));
+    return ZH_OK;
+  };
+  auto run = [&](size_t g) -> int {
+    PipeGroup& q = gs[g];
+    ZH_HIP(ctx, hipStreamWaitEvent(ks, q.uploaded, 0));
+    return zh_plan_run(q.pg.p, q.d_src.p, q.d_dst.p);
+  };
+  auto give_up = [&](int code) -> int {  // nothing is handed out from a failed call
+    (void)hipStreamSynchronize(cs);
+    (void)hipStreamSynchronize(ks);
+    for (int k = 0; k < 2; k++) ctx->pin_busy[k] = false;
+    for (size_t i = 0; i < n; i++) {
+      free(dsts[i]);
+      dsts[i] = nullptr;
+      dst_lens[i] = 0;
+      statuses[i] = ZH_OK;
+    }
+    return code;
+  };
+  if ((st = up(0)) || (st = run(0))) return give_up(st);
+  for (size_t g = 0; g < G; g++) {
+    PipeGroup& q = gs[g];
+    if (g + 1 < G && (st = up(g + 1))) return give_up(st);  // while group g's kernels run
+    std::vector<uint64_t> olen(q.n);
+    std::vector<int32_t> ost(q.n);
+    if ((st = zh_plan_results(q.pg.p, olen.data(), ost.data()))) return give_up(st);
+    if (crcs && (st = zh_plan_crc32(q.pg.p, crcs + q.i0))) return give_up(st);
+    std::vector<char> take(q.n);
+    for (size_t i = 0; i < q.n; i++) {
+      if (ost[i] == ZH_ERR_DST_TOO_SMALL) return give_up(kPipeFallback);
+      statuses[q.i0 + i] = ost[i];
+      take[i] = ost[i] == ZH_OK;
+    }
+    st = download_pack(ctx, ks, q.dl, q.d_dst.p, q.n, q.doff, olen, take, q.d_pack.p, dsts + q.i0,
+                       dst_lens + q.i0, statuses + q.i0);
+    if (st) return give_up(st);
+    if (hipEventRecord(q.packed, ks) != hipSuccess) return give_up(ZH_ERR_DEVICE);
+    if (g + 1 < G && (st = run(g + 1))) return give_up(st);  // next kernels behind the pack
+    if (hipStreamWaitEvent(cs, q.packed, 0) != hipSuccess) return give_up(ZH_ERR_DEVICE);
+    if ((st = download_fetch(ctx, cs, q.dl, dsts + q.i0))) return give_up(st);
+  }
+  ZH_HIP(ctx, hipStreamSynchronize(cs));
+  tr.mark(ctx, "uncompress: pipelined groups");
+  return ZH_OK;
+}
+
 static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
                                  int data_format, const uint64_t* size_hints, void** dsts,
                                  size_t* dst_lens, int32_t* statuses, uint32_t* crcs) {
@@ -1446,9 +1554,7 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
   DevBuf d_src;
   std::vector<uint64_t> soff, slen;
   Trace tr;
-  int st = upload(ctx, srcs, lens, n, d_src, soff, slen);
-  if (st) return st;
-  tr.mark(ctx, "uncompress: upload");
+  int st;
 
   // Output sizes: gzip members carry ISIZE (gzip.nim:64-66, trusted only as a capacity hint and
   // verified afterwards); zlib / raw streams carry nothing: they get a guess (4x their size,
@@ -1472,6 +1578,21 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
       }
     }
   }
+  {
+    // every size known and a batch worth splitting: pipelined groups
+    uint64_t out_total = 0;
+    bool known = true;
+    for (size_t i = 0; i < n; i++) {
+      known = known && !guessed[i];
+      out_total += cap[i];
+    }
+    if (known && out_total >= pipe_min_bytes(ctx)) {
+      const int ps = uncompress_batch_pipelined(ctx, srcs, lens, n, data_format, cap, dsts, dst_lens, statuses, crcs);
+      if (ps != kPipeFallback) return ps;
+    }
+  }
+  if ((st = upload(ctx, srcs, lens, n, d_src, soff, slen))) return st;
+  tr.mark(ctx, "uncompress: upload");
   // pass 1: decode.  Streams that need more room than they were given run again -- after pass 0
   // (sizing of the guessed ones) -- in pass 2; gzip members get the expansion bound there (more
   // data than ISIZE promised: a >= 4 GiB member, ISIZE being mod 2^32, or a corrupt stream).

@@ -39,13 +39,7 @@ struct __attribute__((packed)) Bytes16 {
 // kLdsTable: the wave's hash table in LDS (32 KiB: four waves per CU, no table traffic at all)
 // instead of the HBM pool.  A measurement aid for the trade DESIGN.md 4.1 describes -- with one
 // wave per fragment the pooled form is the faster one by far -- selected with ZH_L1_TABLE=lds.
-// kCacheBits: pooled form only -- a direct-mapped write-back cache of 2^kCacheBits table entries in
-// LDS (valid | slot | value).  The step's probes and inserts touch 50-odd random 2-byte entries of a
-// 32 KiB table, i.e. most of its 256 lines every few steps, and with hundreds of tables per XCD
-// none of them stays in L2: the fabric carries every line there and back again and again (DESIGN.md
-// 4.1).  An insert goes to the cache and sends the entry it displaces to the table; a probe that
-// finds its slot in the cache needs no load.
-template <bool kLdsTable, int kCacheBits>
+template <bool kLdsTable>
 __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restrict__ d_src,
                                                          ZhCompressArgs a, int huffman_only,
                                                          uint16_t* __restrict__ table_pool,
@@ -65,8 +59,6 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   // this wave's hash table (u16 x 16384, snappy.nim:7) in the L2/MALL-resident pool: read with
   // L1-bypassing loads, written through, re-zeroed for every fragment the wave takes
   __shared__ uint16_t s_table_lds[kLdsTable ? 16384 : 2];
-  constexpr uint32_t kCacheN = kCacheBits ? 1u << kCacheBits : 1u;
-  __shared__ uint32_t s_cache[kCacheN];  // bit 31 valid | bits 16-29 table slot | bits 0-15 entry
   uint16_t* const s_table = kLdsTable ? s_table_lds : table_pool + (size_t)blockIdx.x * 16384u;
   // fragments are handed out first come, first served (`next_frag` starts at gridDim.x): they cost
   // very different amounts of time, and a fixed share per wave leaves the last ones running alone
@@ -103,8 +95,6 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   // traffic is made of).  "Empty" is the reference's zero = position 0, with position 0's tag (e0).
   const uint32_t e0 = (!huffman_only && n >= 4) ? (((ld32(0) * kHashMul) >> 17) & 1u) << 15 : 0u;
   for (uint32_t i = lane; i < 512; i += 64) s_bits[i] = 0;
-  if (kCacheBits)
-    for (uint32_t i = lane; i < kCacheN; i += 64) s_cache[i] = 0;
   zh_wave_sync();
   KPROF_MARK(0);
 
@@ -167,14 +157,9 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         // round trip 2: the table slot; every lane also ticks a counter of its (folded) hash,
         // read back together with the candidate bytes
         uint32_t oldw = e0;
-        if (valid && ((s_bits[h >> 5] >> (h & 31u)) & 1u)) {
-          uint32_t ce = 0;
-          if (kCacheBits) ce = s_cache[h & (kCacheN - 1u)];
-          if (kCacheBits && (ce >> 16) == (0x8000u | h)) oldw = ce & 0xffffu;
-          else
-            oldw = kLdsTable ? (uint32_t)s_table[h]
-                             : (uint32_t)__hip_atomic_load(s_table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (valid && ((s_bits[h >> 5] >> (h & 31u)) & 1u))
+          oldw = kLdsTable ? (uint32_t)s_table[h]
+                           : (uint32_t)__hip_atomic_load(s_table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t old = oldw & 0x7fffu;
         const bool fetch = valid && (oldw >> 15) == tag;  // equal bytes have equal tags
         const uint32_t ck = (h & (kCntWords * 4u - 1u)) >> 2, cs = (h & 3u) * 8u;
@@ -491,25 +476,13 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         if (finished) break;  // nothing reads the table any more
         // ---- table inserts of the probes that really happened, in probe order ----
         const bool mine = (ins >> lane) & 1ull;
-        auto insert = [&]() {
-          const uint32_t v = pos | (tag << 15);
-          if (kCacheBits) {
-            // lanes that meet in a cache entry with different slots may land in any order: one
-            // value stays in the cache, the other goes to its table slot
-            const uint32_t was = atomicExch(&s_cache[h & (kCacheN - 1u)], 0x80000000u | (h << 16) | v);
-            const uint32_t ws = (was >> 16) & 0x3fffu;
-            if ((was >> 31) && ws != h) s_table[ws] = (uint16_t)was;
-          } else {
-            s_table[h] = (uint16_t)v;
-          }
-        };
         if (mine) atomicOr(&s_bits[h >> 5], 1u << (h & 31u));
-        if (mine && !((C >> lane) & 1ull)) insert();
+        if (mine && !((C >> lane) & 1ull)) s_table[h] = (uint16_t)(pos | (tag << 15));
         uint64_t cc = ins & C;
         while (cc) {  // probes that share a slot write one by one (the later one wins)
           const uint32_t jx = (uint32_t)__ffsll((long long)cc) - 1u;
           cc &= cc - 1;
-          if (lane == jx) insert();
+          if (lane == jx) s_table[h] = (uint16_t)(pos | (tag << 15));
         }
         zh_wave_sync();
         KPROF_MARK(4);
@@ -597,21 +570,10 @@ extern "C" void zh_launch_l1_match(hipStream_t stream, const uint8_t* d_src, ZhC
   const uint32_t slots = lds ? 1024u : zh_l1_table_slots();  // (39.4 KiB of LDS: four waves per CU)
   const uint32_t grid = a.nfrags < slots ? a.nfrags : slots;
   hipLaunchKernelGGL(zh_l1_set_counter_kernel, dim3(1), dim3(1), 0, stream, next_frag, grid);
-  static const int cache_bits = [] {
-    const char* e = getenv("ZH_L1_CACHE");
-    const int v = e ? atoi(e) : 9;  // (4096 x 1 MiB: none 64.2 ms, 512 entries 62.2 ms, 1024 entries -- 14 waves per CU -- 73.7 ms)
-    return v == 9 || v == 10 ? v : 0;
-  }();
   if (lds)
-    hipLaunchKernelGGL((zh_l1_match_kernel<true, 0>), dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
-                       table_pool, next_frag);
-  else if (cache_bits == 9)
-    hipLaunchKernelGGL((zh_l1_match_kernel<false, 9>), dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
-                       table_pool, next_frag);
-  else if (cache_bits == 10)
-    hipLaunchKernelGGL((zh_l1_match_kernel<false, 10>), dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
+    hipLaunchKernelGGL(zh_l1_match_kernel<true>, dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
                        table_pool, next_frag);
   else
-    hipLaunchKernelGGL((zh_l1_match_kernel<false, 0>), dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
+    hipLaunchKernelGGL(zh_l1_match_kernel<false>, dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
                        table_pool, next_frag);
 }
