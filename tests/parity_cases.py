@@ -503,3 +503,61 @@ def check_plan_slots_with_gaps(eng, upload, download, alloc):
     assert all(got[i] == 0xAB for i in range(total) if not inside[i]), "bytes outside the slots changed"
     with pytest.raises(ZippyError):
         plan.run(d_src, d_dst + 1)
+
+
+def split_inflate_edge_streams():
+    """Streams that exercise the corners of the parallel token decode (csrc/zh_inflate_split.hip):
+    periodic data (wrong starts never fall in step: the all-starts pass), hundreds of tiny blocks
+    with empty stored blocks between them (Z_FULL_FLUSH), fixed-Huffman blocks, long distance codes,
+    block ends near subchunk / superchunk borders, stored + compressed blocks mixed."""
+    rnd = random.Random(77)
+    out = []
+
+    def z(data, level=6, wbits=31, strategy=zlib.Z_DEFAULT_STRATEGY, flush_every=0):
+        c = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strategy)
+        if not flush_every:
+            return c.compress(data) + c.flush()
+        parts = []
+        for o in range(0, len(data), flush_every):
+            parts.append(c.compress(data[o:o + flush_every]))
+            parts.append(c.flush(zlib.Z_FULL_FLUSH if (o // flush_every) % 3 else zlib.Z_SYNC_FLUSH))
+        parts.append(c.flush())
+        return b"".join(parts)
+
+    text = synth.corpus_file("alice29.txt")
+    geo = synth.corpus_file("geo.protodata")
+    for per in (1, 2, 3, 7, 8, 9, 31, 32, 33, 255, 256, 257, 258, 259, 1000):
+        pat = rnd.randbytes(per)
+        data = (pat * (300000 // per + 1))[:300000]
+        out.append((z(data, rnd.choice((1, 6, 9))), data))
+    out.append((z(b"\0" * 3000000, 6), b"\0" * 3000000))
+    out.append((z(text, 6, flush_every=100), text))                  # ~1500 blocks
+    out.append((z(geo, 9, flush_every=1777), geo))
+    out.append((z(text[:70000], 6, strategy=zlib.Z_FIXED), text[:70000]))
+    out.append((z(geo, 1, strategy=zlib.Z_HUFFMAN_ONLY), geo))
+    out.append((z(text, 1, strategy=zlib.Z_RLE), text))
+    big = text + rnd.randbytes(200000) + geo + bytes(100000) + text[::-1] + rnd.randbytes(70000)
+    for lvl in (1, 6, 9):
+        out.append((z(big, lvl), big))
+    out.append((z(big, 6, wbits=15), big))
+    out.append((z(big, 6, wbits=-15), big))
+    # block ends walked across every bit position of a subchunk border: prefix lengths of one text
+    for n in range(16370, 16400):
+        out.append((z(text[:n], 6), text[:n]))
+    return out
+
+
+def check_split_inflate_edges(eng):
+    """Both inflate paths return the input for every stream above, and the same statuses when the
+    output slot is one byte short (device plan API is exercised by check_plan_slots_with_gaps)."""
+    cases = split_inflate_edge_streams()
+    gz = [c for c in cases if c[0][:2] == b"\x1f\x8b"]
+    outs, sts = eng.uncompress_batch([c[0] for c in gz], oracle.dfGzip)
+    for (blob, want), got, st in zip(gz, outs, sts):
+        assert st == 0 and got == want, (len(blob), len(want), st)
+        assert oracle.uncompress(blob, oracle.dfGzip) == want
+    zl = [c for c in cases if c[0][:2] != b"\x1f\x8b"]
+    for blob, want in zl:
+        fmt = oracle.dfZlib if (blob[0] & 0x0f) == 8 and (blob[0] * 256 + blob[1]) % 31 == 0 else oracle.dfDeflate
+        got, st = eng.uncompress_batch([blob], fmt)
+        assert st == [0] and got[0] == want, (len(blob), fmt, st)

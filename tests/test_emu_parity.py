@@ -137,3 +137,7 @@ def test_emu_plan_slots_with_gaps(eng):
         buf = ctypes.create_string_buffer(bytes([fill]) * n, n)
         return ctypes.addressof(buf), buf
     pc.check_plan_slots_with_gaps(eng, upload, lambda keep: keep.raw, alloc)
+
+
+def test_emu_split_inflate_edges(eng, inflate_mode):
+    pc.check_split_inflate_edges(eng)

@@ -308,3 +308,7 @@ def test_gpu_plan_slots_with_gaps(eng):
         t = torch.full((n,), fill, dtype=torch.uint8, device="cuda")
         return t.data_ptr(), t
     pc.check_plan_slots_with_gaps(eng, upload, lambda t: t.cpu().numpy().tobytes(), alloc)
+
+
+def test_gpu_split_inflate_edges(eng, inflate_mode):
+    pc.check_split_inflate_edges(eng)
