@@ -22,6 +22,9 @@
 //
 // zh_frag_stats_kernel then derives the per-fragment histograms from the match
 // list (the addLiteral/addCopy bookkeeping of lz77.nim:19-50).
+#include <cstdlib>
+#include <cstring>
+
 #include "zh_common.h"
 #include "zh_tables.h"
 
@@ -225,6 +228,138 @@ __global__ __launch_bounds__(64) void zh_chain_select_kernel(ZhCompressArgs a,
   close_frags_until(bd.nfrag);
 }
 
+// ---- 3b. the same greedy parse, parallel inside a block ----
+// The per-position results are static, so the parse is a walk p -> p + (len ? len : 1) over fixed
+// data, and such walks fall in step with each other quickly whatever position they start from
+// (the same property the inflate tokens kernel uses, zh_inflate_split.hip).  One workgroup per
+// block takes a fragment (32768 positions, their match lengths staged in LDS as bytes) at a time, a
+// thread per 128-position chunk: every thread walks its chunk from a guessed start (the chunk's
+// first position) to the first visited position behind it, ends are handed on as the next chunk's
+// start, and threads whose start changed walk again until no start changes -- thread 0's start
+// (where the walk entered the fragment) is exact, so by induction all of them then are.  Data
+// whose walks never meet (a run parsed into back-to-back maximal matches) makes the final prefix
+// grow one chunk a turn: thread 0 then simply finishes the walk through LDS alone.  Counts are
+// prefix-summed and a last walk files the matches.  Same match list as zh_chain_select_kernel.
+__global__ __launch_bounds__(256) void zh_chain_select_par_kernel(ZhCompressArgs a,
+                                                                  const uint32_t* __restrict__ best) {
+  constexpr uint32_t kT = 256, kChunk = ZH_FRAG_SIZE / kT;  // 128 positions per thread
+  __shared__ uint8_t s_len[ZH_FRAG_SIZE];  // 0: literal, else match length - 4 (5..258 -> 1..254)
+  __shared__ uint32_t s_end[kT];
+  __shared__ uint32_t s_first_dirty[2];
+  __shared__ uint32_t s_wsum[kT / 64];
+  const uint32_t tid = threadIdx.x;
+  const unsigned lane = zh_lane();
+  const uint32_t b = blockIdx.x;
+  const ZhBlockDesc bd = a.blocks[b];
+  const uint32_t block_len = (uint32_t)bd.len;
+  const uint32_t* bst = best + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  // lz77.nim:54-56,74-76: the last four positions (and blocks of <= 4 bytes) are literals
+  const uint32_t nmain = block_len > 4u ? block_len - 4u : 0u;
+  uint32_t entry = 0;  // block-relative position at which the walk enters the next fragment
+
+  for (uint32_t frag = 0; frag < bd.nfrag; frag++) {
+    const uint32_t base = frag * ZH_FRAG_SIZE;
+    const uint32_t npos = nmain > base ? (nmain - base < ZH_FRAG_SIZE ? nmain - base : ZH_FRAG_SIZE) : 0u;
+    __syncthreads();  // (the previous fragment's walks are done with s_len)
+    for (uint32_t i = tid; i < ZH_FRAG_SIZE; i += kT) {
+      const uint32_t len = i < npos ? bst[base + i] & 0xffffu : 0u;
+      s_len[i] = (uint8_t)(len ? len - 4u : 0u);
+    }
+    if (tid == 0) s_first_dirty[0] = s_first_dirty[1] = kT;
+    __syncthreads();
+    // walks are in fragment-relative positions; one that enters behind the fragment passes through
+    const uint32_t rel0 = entry > base ? entry - base : 0u;
+    const uint32_t limit = (tid + 1u) * kChunk;
+    auto walk = [&](uint32_t p, uint32_t* nmatch) -> uint32_t {
+      uint32_t n = 0;
+      while (p < limit && p < npos) {
+        const uint32_t l = s_len[p];
+        n += l != 0u;
+        p += l ? l + 4u : 1u;
+      }
+      *nmatch = n;
+      return p < limit && p >= npos ? limit : p;  // (behind the last walkable position: literals to the end)
+    };
+    uint32_t my_start = tid == 0 ? rel0 : tid * kChunk, my_end = 0, my_n = 0, prev_fd = 0;
+    bool dirty = true;
+    for (uint32_t turn = 1;; turn++) {
+      const uint32_t par = turn & 1u;
+      if (dirty) {
+        my_end = my_start < limit ? walk(my_start, &my_n) : (my_n = 0, my_start);
+        s_end[tid] = my_end;
+      }
+      __syncthreads();
+      const uint32_t ns = tid == 0 ? rel0 : s_end[tid - 1u];
+      dirty = ns != my_start;
+      my_start = ns;
+      if (dirty) atomicMin(&s_first_dirty[par], tid);
+      if (tid == 0) s_first_dirty[par ^ 1u] = kT;
+      __syncthreads();
+      const uint32_t fd = s_first_dirty[par];
+      if (fd == kT) break;
+      const uint32_t gain = fd - prev_fd;
+      prev_fd = fd;
+      if (turn < 3u || gain >= 4u) continue;
+      // the walks do not meet here: thread 0 carries the exact walk on from the last final end through
+      // the next 16 chunks alone; what lies behind them may well be in step already
+      const uint32_t upto = fd + 16u < kT ? fd + 16u : kT;
+      if (tid == 0) {
+        uint32_t p = s_end[fd - 1u];  // (thread 0 is never dirty: fd >= 1)
+        for (uint32_t t = fd; t < upto; t++) {
+          const uint32_t lim = (t + 1u) * kChunk;
+          while (p < lim && p < npos) {
+            const uint32_t l = s_len[p];
+            p += l ? l + 4u : 1u;
+          }
+          if (p < lim) p = lim;  // (behind the last walkable position)
+          s_end[t] = p;
+        }
+      }
+      __syncthreads();
+      const uint32_t ns2 = tid == 0 ? rel0 : s_end[tid - 1u];
+      if (ns2 != my_start) {
+        my_start = ns2;
+        dirty = true;
+      }
+      prev_fd = upto - 1u;
+    }
+    // every start is exact: file the matches of this fragment in order
+    const uint32_t incl = zh_wave_scan(my_n);
+    if (lane == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = incl - my_n, total = 0;
+    for (uint32_t w = 0; w < kT / 64u; w++) {
+      const uint32_t ws = s_wsum[w];
+      if (w < (tid >> 6)) before += ws;
+      total += ws;
+    }
+    const uint32_t f = bd.first_frag + frag;
+    if (tid == 0) a.f_nmatch[f] = total;
+    {
+      const size_t slot0 = (size_t)f * ZH_MAX_MATCHES_PER_FRAG + before;
+      uint32_t k = 0, p = my_start;
+      while (p < limit && p < npos) {
+        const uint32_t l = s_len[p];
+        if (l) {
+          const uint32_t len = l + 4u;
+          a.m_pos[slot0 + k] = (uint16_t)p;
+          a.m_len[slot0 + k] = (uint16_t)len;
+          a.m_off[slot0 + k] = (uint16_t)(bst[base + p] >> 16);
+          k++;
+          const uint32_t end = p + len;  // a match that reaches into the next fragment (lz77.nim's
+          if (end > ZH_FRAG_SIZE && frag + 1u < bd.nfrag) a.f_spill[f + 1u] = end - ZH_FRAG_SIZE;  // spill)
+          p = end;
+        } else {
+          p++;
+        }
+      }
+    }
+    entry = base + s_end[kT - 1u];
+    if (frag == 0 && tid == 0) a.f_spill[f] = 0;
+    if (tid == 1 && frag + 1u < bd.nfrag && entry <= base + ZH_FRAG_SIZE) a.f_spill[f + 1u] = 0;
+  }
+}
+
 // Per-fragment statistics from a match list: litlen/distance histograms,
 // literal count, sum of extra bits (lz77.nim:19-50 / snappy.nim:33-64).
 __global__ __launch_bounds__(64) void zh_frag_stats_kernel(const uint8_t* __restrict__ d_src,
@@ -307,7 +442,12 @@ extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src,
 }
 extern "C" void zh_launch_chain_select(hipStream_t stream, ZhCompressArgs a, const uint32_t* best) {
   if (!a.nblocks) return;
-  hipLaunchKernelGGL(zh_chain_select_kernel, dim3(a.nblocks), dim3(64), 0, stream, a, best);
+  static const bool serial = [] {
+    const char* e = getenv("ZH_CHAIN_SELECT");
+    return e && strcmp(e, "serial") == 0;
+  }();
+  if (serial) hipLaunchKernelGGL(zh_chain_select_kernel, dim3(a.nblocks), dim3(64), 0, stream, a, best);
+  else hipLaunchKernelGGL(zh_chain_select_par_kernel, dim3(a.nblocks), dim3(256), 0, stream, a, best);
 }
 extern "C" void zh_launch_frag_stats(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a) {
   if (!a.nfrags) return;
