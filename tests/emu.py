@@ -24,6 +24,9 @@ def engine():
         # and batches of more than one group's worth of input run as pipelined groups
         os.environ.setdefault("ZH_PIPE_MIN", "1")
         os.environ.setdefault("ZH_PIPE_GROUP", "150000")
+        # batches of up to three streams decode with the wide (1024-thread) inflate kernels, larger
+        # ones with the narrow (256-thread) ones: the tests' batches cover both
+        os.environ.setdefault("ZH_INFLATE_WIDE", "3")
         _engine = Engine(build_emu.build())
         _engine.set_gzip_fname_len(0)
     return _engine

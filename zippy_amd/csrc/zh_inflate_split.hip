@@ -28,6 +28,8 @@
 // Same checks, same accept/reject decision and the same bytes as zh_inflate_kernel (the tests
 // run both against the oracle).  Algorithmic traffic: C read + N written, plus the token
 // records (4 bytes per token, written once and read once).
+#include <cstdlib>
+
 #include "zh_common.h"
 #include "zh_kprof.h"
 #include "zh_tables.h"
@@ -35,16 +37,13 @@
 
 namespace {
 
-constexpr uint32_t kSplitThreads = 256;
 constexpr uint32_t kSubBits = 512;                            // one thread's share of a superchunk
-constexpr uint32_t kSuperBits = kSplitThreads * kSubBits;     // 16 KiB of the stream per turn
 constexpr uint32_t kSubWords = kSubBits / 32u;                 // 16
 // The staged superchunk gives every subchunk 19 dwords: its own 16 and a copy of the next three
 // (a token that starts in the subchunk reads at most that far), so dword w of the superchunk sits
 // at w + 3 * (w / 16) and a token's three dwords are consecutive.  19 is odd: the lanes of a wave,
 // one subchunk apart, read 64 different banks (16 apart they would share four).
 constexpr uint32_t kSubStride = kSubWords + 3u;
-constexpr uint32_t kStageWords = (kSplitThreads + 1u) * kSubStride;
 constexpr uint32_t kHeaderWords = 288;                        // a dynamic header is < 900 bytes
 constexpr uint32_t kDistSub = 256;                            // second-level distance tables
 constexpr uint32_t kNoStart = 0xffffffffu;                    // "the thread before me ended the block"
@@ -69,11 +68,18 @@ struct RunResult {
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* __restrict__ d_src,
+// kSplitThreads: 256 (a superchunk of 16 KiB of the stream, five workgroups per CU: batches) or
+// 1024 (64 KiB, one workgroup per CU: a handful of streams, where the chain of a stream's
+// superchunks is what takes the time).
+template <uint32_t kSplitThreads>
+__global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(const uint8_t* __restrict__ d_src,
                                                                 ZhInflateArgs a,
                                                                 uint32_t* __restrict__ tok_pool,
                                                                 const uint64_t* __restrict__ tok_off,
                                                                 const uint64_t* __restrict__ tok_cap) {
+  constexpr uint32_t kSuperBits = kSplitThreads * kSubBits;
+  constexpr uint32_t kStageWords = (kSplitThreads + 1u) * kSubStride;
+  constexpr uint32_t kWaves = kSplitThreads / 64u;
   __shared__ uint32_t s_lit[(1u << kLitBits) + kLitSub];
   __shared__ uint32_t s_dst[(1u << kDistBits) + kDistSub];  // also hosts the 7-bit code-length table
   __shared__ uint32_t s_in[kStageWords];
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
   __shared__ uint8_t s_lens[320 + 16];
   __shared__ uint32_t s_cnt[16];
   __shared__ uint32_t s_end[kSplitThreads];   // where every thread's run ended
-  __shared__ uint32_t s_wsum[4];
+  __shared__ uint32_t s_wsum[kWaves];
   __shared__ uint32_t s_first_dirty[2], s_first_term[2];  // per turn parity
   // all-starts map of a subchunk: entry i = where the decode that starts i bits into the subchunk
   // comes out, in bits behind the subchunk's end (or kMapTerm)
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
       }
       __syncthreads();
       uint32_t before = incl - n_eff, total = 0;
-      for (uint32_t w = 0; w < 4; w++) {
+      for (uint32_t w = 0; w < kWaves; w++) {
         const uint32_t ws = s_wsum[w];
         if (w < (tid >> 6)) before += ws;
         total += ws;
@@ -555,18 +561,16 @@ __global__ __launch_bounds__(256) void zh_inflate_tokens_kernel(const uint8_t* _
 // LDS and L2 round trips: wide rounds are what shortens it (64-byte rounds by one wave: 13 ms for
 // a 1 MiB stream whatever the batch).  A single copy that does not fit a round goes alone.
 // ---------------------------------------------------------------------------
-namespace {
-constexpr uint32_t kWrThreads = 256;
-constexpr uint32_t kWrWaves = kWrThreads / 64u;
-constexpr uint32_t kWrRound = kWrThreads * 4u;  // output bytes per round
-constexpr uint32_t kWrRecs = kWrThreads * 2u;   // records looked at per round
-constexpr uint32_t kWrRing = 2048;              // token records staged in LDS (a power of two)
-}  // namespace
-
-__global__ __launch_bounds__(256) void zh_inflate_write_kernel(const uint8_t* __restrict__ d_src,
+// kWrThreads: 256 (rounds of 1024 bytes: batches) or 1024 (rounds of 4096 bytes: a handful of streams).
+template <uint32_t kWrThreads>
+__global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint8_t* __restrict__ d_src,
                                                                uint8_t* __restrict__ d_dst, ZhInflateArgs a,
                                                                const uint32_t* __restrict__ tok_pool,
                                                                const uint64_t* __restrict__ tok_off) {
+  constexpr uint32_t kWrWaves = kWrThreads / 64u;
+  constexpr uint32_t kWrRound = kWrThreads * 4u;  // output bytes per round
+  constexpr uint32_t kWrRecs = kWrThreads * 2u;   // records looked at per round
+  constexpr uint32_t kWrRing = kWrThreads * 8u;   // token records staged in LDS (a power of two)
   __shared__ uint32_t s_tok[kWrRing];
   __shared__ uint32_t s_map32[kWrRound / 2];  // u16 per byte: (index in the round of the record that starts there) + 1
   __shared__ uint32_t s_par32[kWrRound / 2];  // u16 per byte: the byte of this round it copies (itself: a root)
@@ -821,15 +825,34 @@ __global__ __launch_bounds__(256) void zh_inflate_write_kernel(const uint8_t* __
   }
 }
 
+// Few streams: one wide workgroup each (a stream is a chain of superchunks and of rounds, and wide
+// ones shorten it); many: narrow workgroups, several per CU (ZH_INFLATE_WIDE = largest batch that
+// still gets the wide form).
+static bool zh_inflate_wide(uint32_t nbufs) {
+  static const uint32_t upto = [] {
+    const char* e = getenv("ZH_INFLATE_WIDE");
+    return e ? (uint32_t)atoi(e) : 512u;  // (512 x 1 MiB: wide 7.4 ms, narrow 9.5; 1024: 14.2 against 10.3)
+  }();
+  return nbufs <= upto;
+}
+
 extern "C" void zh_launch_inflate_tokens(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a,
                                          uint32_t* tok_pool, const uint64_t* tok_off, const uint64_t* tok_cap) {
   if (!a.nbufs) return;
-  hipLaunchKernelGGL(zh_inflate_tokens_kernel, dim3(a.nbufs), dim3(kSplitThreads), 0, stream, d_src, a, tok_pool,
-                     tok_off, tok_cap);
+  if (zh_inflate_wide(a.nbufs))
+    hipLaunchKernelGGL(zh_inflate_tokens_kernel<1024>, dim3(a.nbufs), dim3(1024), 0, stream, d_src, a, tok_pool,
+                       tok_off, tok_cap);
+  else
+    hipLaunchKernelGGL(zh_inflate_tokens_kernel<256>, dim3(a.nbufs), dim3(256), 0, stream, d_src, a, tok_pool,
+                       tok_off, tok_cap);
 }
 extern "C" void zh_launch_inflate_write(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a,
                                         const uint32_t* tok_pool, const uint64_t* tok_off) {
   if (!a.nbufs) return;
-  hipLaunchKernelGGL(zh_inflate_write_kernel, dim3(a.nbufs), dim3(kWrThreads), 0, stream, d_src, d_dst, a, tok_pool,
-                     tok_off);
+  if (zh_inflate_wide(a.nbufs))
+    hipLaunchKernelGGL(zh_inflate_write_kernel<1024>, dim3(a.nbufs), dim3(1024), 0, stream, d_src, d_dst, a,
+                       tok_pool, tok_off);
+  else
+    hipLaunchKernelGGL(zh_inflate_write_kernel<256>, dim3(a.nbufs), dim3(256), 0, stream, d_src, d_dst, a,
+                       tok_pool, tok_off);
 }
