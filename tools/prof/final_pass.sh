@@ -24,6 +24,7 @@ timeout 300 python tools/bench_single_call.py 2>/dev/null | tail -1 > $O/${T}_si
 # one GPU's share of the batch when eight GPUs split it (strong scaling, 512 x 1 MiB)
 timeout 300 python bench.py --buffers 512 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_share512.json
 timeout 300 python tools/bench_host_api.py --reps 2 --buffers 4096 2>/dev/null | tail -1 > $O/${T}_host_api_4096.json
+timeout 600 python tools/bench_one_stream.py 2>/dev/null | tail -1 > $O/${T}_one_stream.json
 cd /tmp
 rm -rf /tmp/kt /tmp/pf /tmp/pw
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${T}_rocprof_bench.log 2>&1

@@ -16,7 +16,7 @@ for path in sorted(glob.glob(sys.argv[1] + "/**/*.db", recursive=True)):
         print(path, e)
         continue
     for name, ctr, n, v in rows:
-        name = name.split("(")[0]
+        name = name.split("(")[0].split("<")[0].replace("void ", "").strip()
         if name.startswith("zh_"):
             vals[name][ctr] = v / n
 for name in sorted(vals):
