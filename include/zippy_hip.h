@@ -200,9 +200,10 @@ int zh_plan_uncompress(zh_ctx *ctx, size_t n, const uint64_t *src_off, const uin
  * Both directions read whole aligned 32-bit words around a source buffer, i.e. up to 3 bytes
  * before src_off and after src_off + src_len: those bytes must be mapped (true inside any
  * hipMalloc allocation, which is 256-byte aligned and padded); their values are ignored.
- * Uncompress plans: on ZH_ERR_DST_TOO_SMALL out_len is the number of bytes written before the
- * token that did not fit (out_len <= dst_cap), not the required size; callers that need the
- * size use the host-buffer calls (which size and retry) or a larger slot. */
+ * Uncompress plans: on ZH_ERR_DST_TOO_SMALL out_len is the number of leading bytes of the slot
+ * that hold valid output (out_len <= dst_cap; 0 for a large stream decoded segment-wise, which
+ * writes nothing once it knows the slot is too small), not the required size; callers that need
+ * the size use the host-buffer calls (which size and retry) or a larger slot. */
 int zh_plan_run(zh_plan *plan, const void *d_src, void *d_dst);
 /* Wait for the stream and fetch per-buffer output lengths and statuses. */
 int zh_plan_results(zh_plan *plan, uint64_t *out_lens, int32_t *statuses);

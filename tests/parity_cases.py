@@ -561,3 +561,71 @@ def check_split_inflate_edges(eng):
         fmt = oracle.dfZlib if (blob[0] & 0x0f) == 8 and (blob[0] * 256 + blob[1]) % 31 == 0 else oracle.dfDeflate
         got, st = eng.uncompress_batch([blob], fmt)
         assert st == [0] and got[0] == want, (len(blob), fmt, st)
+
+
+def segmented_streams(scale):
+    """Foreign streams for the segment-wise decoder (zh_inflate_seg.hip): many blocks each, the
+    kinds of block boundaries it has to cope with.  -> [(blob, format, plain)]"""
+    rng = random.Random(77)
+    text = synth.gen_batch("text", 1, 96 * scale, first_index=5)[0].tobytes()
+    mix = synth.gen_batch("mix", 1, 64 * scale, first_index=6)[0].tobytes()
+    runs = synth.gen_batch("runs", 1, 192 * scale, first_index=7)[0].tobytes()
+    noise = bytes(rng.getrandbits(8) for _ in range(8 * scale))
+
+    def blocks(plain, level, wbits, flushes, every, strategy=zlib.Z_DEFAULT_STRATEGY):
+        c = zlib.compressobj(level, zlib.DEFLATED, wbits, 8, strategy)
+        parts = []
+        for k, o in enumerate(range(0, len(plain), every)):
+            parts.append(c.compress(plain[o:o + every]))
+            parts.append(c.flush(flushes[k % len(flushes)]))
+        parts.append(c.flush())
+        return b"".join(parts)
+
+    out = [(zlib.compress(text, 6), oracle.dfZlib, text)]  # two blocks: one decoder does it all
+    # blocks that end anywhere in a byte (Z_BLOCK) and copies that reach back across them
+    out.append((blocks(text + mix, 6, -15, [zlib.Z_BLOCK], 2500), oracle.dfDeflate, text + mix))
+    out.append((blocks(mix + text, 1, 15, [zlib.Z_BLOCK, zlib.Z_SYNC_FLUSH, zlib.Z_BLOCK, zlib.Z_FULL_FLUSH], 3000),
+                oracle.dfZlib, mix + text))
+    # fixed-code blocks only: no block start is ever found
+    out.append((blocks(mix, 6, -15, [zlib.Z_BLOCK], 3000, zlib.Z_FIXED), oracle.dfDeflate, mix))
+    # stored blocks (incompressible stretches) between compressed ones; a zlib stream inside, whose
+    # block headers sit byte-aligned in stored blocks of the outer stream
+    inner = blocks(text[: 24 * scale], 6, 15, [zlib.Z_BLOCK], 2000)
+    plain = text[: 20 * scale] + noise + inner + mix[: 20 * scale] + noise + inner + text[20 * scale: 40 * scale]
+    out.append((blocks(plain, 6, 31, [zlib.Z_BLOCK], 4000), oracle.dfGzip, plain))
+    # long runs: a few bits per token, back-to-back maximal matches
+    plain = b"\0" * (64 * scale) + text[: 8 * scale] + b"ab" * (32 * scale) + runs
+    out.append((blocks(plain, 6, 15, [zlib.Z_BLOCK], 20000), oracle.dfZlib, plain))
+    return out
+
+
+def check_segmented(eng, scale, monkeypatch, seg_bytes):
+    """Large streams on many workgroups: same bytes and statuses as the one-workgroup decode, for
+    whole streams, streams cut short and streams with a flipped bit."""
+    monkeypatch.setenv("ZH_SEG_MIN", str(4 * seg_bytes))
+    monkeypatch.setenv("ZH_SEG_BYTES", str(seg_bytes))
+    cases = segmented_streams(scale)
+    for blob, fmt, plain in cases:
+        assert len(blob) >= 4 * seg_bytes, len(blob)
+        outs, sts = eng.uncompress_batch([blob], fmt)
+        assert sts == [0] and outs[0] == plain, (fmt, len(blob), sts)
+    # a batch of them at once (same format): zlib streams
+    zl = [c for c in cases if c[1] == oracle.dfZlib]
+    outs, sts = eng.uncompress_batch([c[0] for c in zl], oracle.dfZlib)
+    assert sts == [0] * len(zl) and all(o == c[2] for o, c in zip(outs, zl))
+    # damage: the statuses are those of the ordinary decoder
+    rng = random.Random(3)
+    blob, fmt, plain = cases[1]
+    bad = [blob[: len(blob) * 2 // 3], blob[:-5]]
+    for _ in range(10):
+        b = bytearray(blob)
+        b[rng.randrange(8, len(b) - 8)] ^= 1 << rng.randrange(8)
+        bad.append(bytes(b))
+    monkeypatch.setenv("ZH_SEG", "0")
+    want = [eng.uncompress_batch([b], fmt) for b in bad]
+    monkeypatch.setenv("ZH_SEG", "1")
+    got = [eng.uncompress_batch([b], fmt) for b in bad]
+    for b, w, g_ in zip(bad, want, got):
+        assert w[1] == g_[1], (len(b), w[1], g_[1])
+        if w[1] == [0]:
+            assert w[0] == g_[0]

@@ -141,3 +141,7 @@ def test_emu_plan_slots_with_gaps(eng):
 
 def test_emu_split_inflate_edges(eng, inflate_mode):
     pc.check_split_inflate_edges(eng)
+
+
+def test_emu_segmented_streams(eng, monkeypatch):
+    pc.check_segmented(eng, 1024, monkeypatch, 2048)

@@ -312,3 +312,9 @@ def test_gpu_plan_slots_with_gaps(eng):
 
 def test_gpu_split_inflate_edges(eng, inflate_mode):
     pc.check_split_inflate_edges(eng)
+
+
+def test_gpu_segmented_streams(eng, monkeypatch):
+    """Large streams on many workgroups (zh_inflate_seg.hip), small segments and the default ones."""
+    pc.check_segmented(eng, 1024, monkeypatch, 2048)
+    pc.check_segmented(eng, 32 * 1024, monkeypatch, 65536)

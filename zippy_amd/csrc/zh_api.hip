@@ -37,6 +37,12 @@ void zh_launch_inflate_tokens(hipStream_t, const uint8_t* d_src, ZhInflateArgs a
 void zh_launch_inflate_write(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a,
                              const uint32_t* tok_pool, const uint64_t* tok_off);
 void zh_launch_segments_reduce(hipStream_t, ZhInflateArgs seg, ZhInflateArgs whole);
+void zh_launch_seg_find(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g);
+void zh_launch_seg_tokens(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, uint32_t* tok_pool, ZhSegArgs g);
+void zh_launch_seg_chain(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
+void zh_launch_seg_write(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, const uint32_t* tok_pool, ZhSegArgs g);
+void zh_launch_seg_windows(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
+void zh_launch_seg_finish(hipStream_t, uint8_t* d_dst, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_l1_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int huffman_only,
                         uint16_t* table_pool, uint32_t* next_frag);
 uint32_t zh_l1_table_slots(void);
@@ -248,6 +254,14 @@ struct zh_plan {
   bool tok_failed = false;
   ZhInflateArgs seg{};
   uint8_t* seg_arena = nullptr;
+  // large streams decoded segment-wise (zh_inflate_seg.hip); the symbol and window buffers come
+  // with the token pool
+  bool segmented = false;
+  ZhSegArgs sg{};
+  uint8_t* sg_arena = nullptr;
+  uint16_t* sg_sym = nullptr;
+  uint8_t* sg_windows = nullptr;
+  uint64_t sg_sym_count = 0;
   // profiling
   bool profiling = false;
   std::vector<const char*> k_names;
@@ -298,6 +312,9 @@ extern "C" void zh_plan_destroy(zh_plan* p) {
   if (p->arena) (void)hipFree(p->arena);
   if (p->seg_arena) (void)hipFree(p->seg_arena);
   if (p->tok_pool) (void)hipFree(p->tok_pool);
+  if (p->sg_arena) (void)hipFree(p->sg_arena);
+  if (p->sg_sym) (void)hipFree(p->sg_sym);
+  if (p->sg_windows) (void)hipFree(p->sg_windows);
   for (auto e : p->k_events) (void)hipEventDestroy(e);
   delete p;
 }
@@ -536,6 +553,115 @@ extern "C" int zh_plan_block_index(zh_plan* p, size_t buf, zh_block_entry** inde
   return ZH_OK;
 }
 
+// Large streams are decoded segment-wise (zh_inflate_seg.hip) when a batch is a handful of them:
+// ZH_SEG=0 turns that off, ZH_SEG_MIN is the smallest stream (compressed bytes, default 256 KiB),
+// ZH_SEG_BYTES the segment length (default 64 KiB).
+struct SegConfig {
+  bool on = true;
+  uint64_t min_stream = 262144, seg_bytes = 65536;
+  size_t max_streams = 64;
+};
+static SegConfig seg_config() {  // (read per plan: the tests switch it)
+  SegConfig v;
+  if (const char* e = getenv("ZH_SEG")) v.on = strcmp(e, "0") != 0;
+  if (const char* e = getenv("ZH_SEG_MIN")) v.min_stream = strtoull(e, nullptr, 10);
+  if (const char* e = getenv("ZH_SEG_BYTES")) v.seg_bytes = std::max<uint64_t>(64, strtoull(e, nullptr, 10));
+  return v;
+}
+
+// Cuts the plan's streams into segments and uploads the geometry; token regions of the segments
+// are appended to the plan's token pool (`twords` is the pool's size so far).  Failure leaves the
+// plan unsegmented.
+static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64_t* twords) {
+  const SegConfig c = seg_config();
+  zh_ctx* ctx = p->ctx;
+  const size_t n = bufs.size();
+  if (!c.on || !n || n > c.max_streams) return;
+  for (const ZhBufDesc& b : bufs)
+    if (b.src_len < c.min_stream || b.src_len < 2 * c.seg_bytes || b.src_len > (~0ull >> 4)) return;
+  std::vector<uint32_t> parent, first_seg(n + 1);
+  std::vector<uint64_t> nominal, search, toff, tcap, sym_base(n);
+  uint64_t nsym = 0;
+  for (size_t i = 0; i < n; i++) {
+    const ZhBufDesc& b = bufs[i];
+    const uint64_t ns = std::min<uint64_t>(std::max<uint64_t>(b.src_len / c.seg_bytes, 2), 4096);
+    const uint64_t seg_bits = (b.src_len * 8 + ns - 1) / ns, seg_len = (seg_bits + 7) / 8;
+    first_seg[i] = (uint32_t)parent.size();
+    for (uint64_t k = 0; k < ns; k++) {
+      parent.push_back((uint32_t)i);
+      nominal.push_back(k * seg_bits);
+      search.push_back(seg_bits);
+      // room for six tokens per compressed byte of a nominal segment: a dozen segments' worth of
+      // ordinary data, should the decoder have to carry on through segments without a block start
+      // (a slot of no bytes is a sizing pass: the tokens are counted, never written out)
+      const uint64_t cap = (b.dst_cap ? std::min<uint64_t>(b.dst_cap, 6 * seg_len) : 6 * seg_len) + 2 * (seg_len / 5 + 1) + 16;
+      tcap.push_back(cap);
+      toff.push_back(*twords);
+      *twords += cap + 1024;
+    }
+    sym_base[i] = nsym;
+    nsym += b.dst_cap;
+  }
+  first_seg[n] = (uint32_t)parent.size();
+  const size_t ns = parent.size();
+  if (ns > 0x7fffffffu) return;
+  Arena ar;
+  const size_t o_parent = ar.reserve(ns * 4), o_first = ar.reserve((n + 1) * 4), o_nom = ar.reserve(ns * 8),
+               o_search = ar.reserve(ns * 8), o_toff = ar.reserve(ns * 8), o_tcap = ar.reserve(ns * 8),
+               o_symb = ar.reserve(n * 8), o_start = ar.reserve(ns * 8), o_end = ar.reserve(ns * 8),
+               o_final = ar.reserve(ns * 4), o_sst = ar.reserve(ns * 4), o_sout = ar.reserve(ns * 8),
+               o_wlen = ar.reserve(ns * 8), o_valid = ar.reserve(ns * 4), o_prev = ar.reserve(ns * 4),
+               o_ostart = ar.reserve(ns * 8), o_sok = ar.reserve(n * 4);
+  ar.reserve(256);
+  if (hipMalloc(&p->sg_arena, ar.size) != hipSuccess) {
+    (void)hipGetLastError();
+    p->sg_arena = nullptr;
+    return;
+  }
+  uint8_t* base = p->sg_arena;
+  hipStream_t s = ctx->stream;
+  hipError_t up = hipMemsetAsync(base, 0, ar.size, s);
+  auto put = [&](size_t off, const void* src, size_t bytes) {
+    if (up == hipSuccess) up = hipMemcpyAsync(base + off, src, bytes, hipMemcpyHostToDevice, s);
+  };
+  put(o_parent, parent.data(), ns * 4);
+  put(o_first, first_seg.data(), (n + 1) * 4);
+  put(o_nom, nominal.data(), ns * 8);
+  put(o_search, search.data(), ns * 8);
+  put(o_toff, toff.data(), ns * 8);
+  put(o_tcap, tcap.data(), ns * 8);
+  put(o_symb, sym_base.data(), n * 8);
+  if (up == hipSuccess) up = hipStreamSynchronize(s);
+  if (up != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p->sg_arena);
+    p->sg_arena = nullptr;
+    return;
+  }
+  ZhSegArgs& g = p->sg;
+  g.nsegs = (uint32_t)ns;
+  g.nstreams = (uint32_t)n;
+  g.parent = carve<uint32_t>(base, o_parent);
+  g.first_seg = carve<uint32_t>(base, o_first);
+  g.nominal_bit = carve<uint64_t>(base, o_nom);
+  g.search_bits = carve<uint64_t>(base, o_search);
+  g.tok_off = carve<uint64_t>(base, o_toff);
+  g.tok_cap = carve<uint64_t>(base, o_tcap);
+  g.sym_base = carve<uint64_t>(base, o_symb);
+  g.start_bit = carve<uint64_t>(base, o_start);
+  g.end_bit = carve<uint64_t>(base, o_end);
+  g.final_block = carve<uint32_t>(base, o_final);
+  g.seg_status = carve<int32_t>(base, o_sst);
+  g.seg_out = carve<uint64_t>(base, o_sout);
+  g.wr_len = carve<uint64_t>(base, o_wlen);
+  g.valid = carve<uint32_t>(base, o_valid);
+  g.prev = carve<uint32_t>(base, o_prev);
+  g.out_start = carve<uint64_t>(base, o_ostart);
+  g.stream_ok = carve<uint32_t>(base, o_sok);
+  p->sg_sym_count = nsym + 64;
+  p->segmented = true;
+}
+
 extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off,
                                   const uint64_t* src_len, const uint64_t* dst_off,
                                   const uint64_t* dst_cap, int data_format, zh_plan** out) {
@@ -587,6 +713,7 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
     toff[i] = twords;
     twords += tcap[i] + 1024;  // (the writer reads whole batches of records, up to 640 behind the last)
   }
+  plan_segments(p, bufs, &twords);
   p->tok_words = twords + 16384;  // (... and stages them up to 4096 at a time, two stagings ahead)
   hipError_t up = hipMemcpyAsync(base + o_toff, toff.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
   if (up == hipSuccess) up = hipMemcpyAsync(base + o_tcap, tcap.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
@@ -624,6 +751,7 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
   a.status = p->status = carve<int32_t>(base, o_st);
   a.start_bit = nullptr;
   a.single_block = 0;
+  a.skip = nullptr;
   *out = p;
   return ZH_OK;
 }
@@ -720,6 +848,19 @@ static bool plan_token_pool(zh_plan* p) {
     p->tok_failed = true;
     return false;
   }
+  if (p->segmented) {  // without its buffers the plan simply is not segmented
+    if (hipMalloc(&p->sg_sym, p->sg_sym_count * 2) != hipSuccess ||
+        hipMalloc(&p->sg_windows, (size_t)p->sg.nsegs * 32768u) != hipSuccess) {
+      (void)hipGetLastError();
+      if (p->sg_sym) (void)hipFree(p->sg_sym);
+      p->sg_sym = nullptr;
+      p->sg_windows = nullptr;
+      p->segmented = false;
+    } else {
+      p->sg.sym = p->sg_sym;
+      p->sg.windows = p->sg_windows;
+    }
+  }
   return true;
 }
 
@@ -803,9 +944,31 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     const ZhInflateArgs& a = p->ia;
     prof_mark(p, "zh_unwrap_kernel");
     zh_launch_unwrap(s, d_src, a);
-    const bool split = !p->indexed && !a.count_only && inflate_split_enabled(ctx) && plan_token_pool(p);
-    if (!split) prof_mark(p, "zh_inflate_kernel");
+    const bool split_ok = !p->indexed && inflate_split_enabled(ctx) && plan_token_pool(p);
+    const bool split = split_ok && !a.count_only;
+    ZhInflateArgs a1 = a;
+    if (split_ok && p->segmented) {
+      // a handful of large streams: many workgroups per stream (zh_inflate_seg.hip); streams whose
+      // chain of segments does not hold are left to the ordinary kernels below.  A sizing pass
+      // stops behind the chain kernel, which knows the output size by then.
+      prof_mark(p, "zh_seg_find_kernel");
+      zh_launch_seg_find(s, d_src, a, p->sg);
+      prof_mark(p, "zh_seg_tokens_kernel");
+      zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg);
+      prof_mark(p, "zh_seg_chain_kernel");
+      zh_launch_seg_chain(s, a, p->sg);
+      if (!a.count_only) {
+        prof_mark(p, "zh_seg_write_kernel");
+        zh_launch_seg_write(s, d_src, a, p->tok_pool, p->sg);
+        prof_mark(p, "zh_seg_windows_kernel");
+        zh_launch_seg_windows(s, a, p->sg);
+        prof_mark(p, "zh_seg_finish_kernel");
+        zh_launch_seg_finish(s, d_dst, a, p->sg);
+      }
+      a1.skip = p->sg.stream_ok;
+    }
     if (p->indexed) {
+      prof_mark(p, "zh_inflate_kernel");
       ZH_HIP(ctx, hipMemsetAsync(p->seg.status, 0, (size_t)p->seg.nbufs * 4, s));
       zh_launch_inflate(s, d_src, d_dst, p->seg);
       prof_mark(p, "zh_segments_reduce_kernel");
@@ -813,11 +976,12 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     } else if (split) {
       // two kernels: tokens (parallel over each stream), then bytes (zh_inflate_split.hip)
       prof_mark(p, "zh_inflate_tokens_kernel");
-      zh_launch_inflate_tokens(s, d_src, a, p->tok_pool, p->tok_off, p->tok_cap);
+      zh_launch_inflate_tokens(s, d_src, a1, p->tok_pool, p->tok_off, p->tok_cap);
       prof_mark(p, "zh_inflate_write_kernel");
-      zh_launch_inflate_write(s, d_src, d_dst, a, p->tok_pool, p->tok_off);
+      zh_launch_inflate_write(s, d_src, d_dst, a1, p->tok_pool, p->tok_off);
     } else {
-      zh_launch_inflate(s, d_src, d_dst, a);
+      prof_mark(p, "zh_inflate_kernel");
+      zh_launch_inflate(s, d_src, d_dst, a1);
     }
     if (!a.count_only) {
       // both checksums: with dfDetect the format is only known per stream on the device

@@ -110,6 +110,38 @@ struct ZhInflateArgs {
   // block-parallel decode (zh_plan_uncompress_indexed): every "stream" is one deflate block
   const uint64_t* start_bit;     // bit position of the block in its compressed buffer, or null
   int32_t single_block;          // stop after one block whatever BFINAL says
+  // split decode: streams whose flag is set were decoded segment-wise (ZhSegArgs) and are left alone
+  const uint32_t* skip;
+};
+
+// One large stream decoded by many workgroups (zh_inflate_seg.hip).  The compressed bytes are cut
+// into segments; a segment's decoder starts at the first deflate block found at or behind the
+// segment's nominal first bit and stops at the block boundary where the next segment's begins.
+constexpr uint64_t kSegNone = ~0ull;
+struct ZhSegArgs {
+  uint32_t nsegs, nstreams;
+  const uint32_t* parent;       // [nsegs] the stream a segment belongs to
+  const uint32_t* first_seg;    // [nstreams + 1] a stream's segments are first_seg[i] .. first_seg[i + 1] - 1
+  const uint64_t* nominal_bit;  // [nsegs] where the search for the segment's first block starts (bits from the stream's first byte)
+  const uint64_t* search_bits;  // [nsegs] ... and how far it goes
+  const uint64_t* tok_off;      // [nsegs] token region of the segment in the plan's token pool
+  const uint64_t* tok_cap;
+  const uint64_t* sym_base;     // [nstreams] first symbol of the stream's output in `sym`
+  // find / tokens results
+  uint64_t* start_bit;          // [nsegs] first bit of the segment's first block, or kSegNone
+  uint64_t* end_bit;            // [nsegs] the block boundary the tokens kernel stopped at
+  uint32_t* final_block;        // [nsegs] ... which was the end of the stream
+  int32_t* seg_status;          // [nsegs] tokens kernel, then writer
+  uint64_t* seg_out;            // [nsegs] output bytes of the segment's tokens
+  uint64_t* wr_len;             // [nsegs] bytes the writer made (equal to seg_out unless it failed)
+  // chain results
+  uint32_t* valid;              // [nsegs] the segment lies on the stream's chain of blocks
+  uint32_t* prev;               // [nsegs] the chain segment before it (0xffffffff: none)
+  uint64_t* out_start;          // [nsegs] first output byte of the segment in its stream
+  uint32_t* stream_ok;          // [nstreams] the chain holds: the stream is decoded segment-wise
+  // 16-bit output symbols (a byte, or 0x8000 | index into the 32 KiB window before the segment)
+  uint16_t* sym;
+  uint8_t* windows;             // [nsegs][32768] the last 32 KiB of output at the end of a chain segment
 };
 
 // ---- wave helpers (single-wave workgroups; lockstep execution on gfx950) ----

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(128, 8) void zh_inflate_kernel(const uint8_t* __res
   const bool decoder = threadIdx.x < 64;
   const uint32_t sid = blockIdx.x;
   if (a.status[sid] != ZH_OK) return;  // unwrap already failed this stream (both waves leave)
+  if (a.skip && a.skip[sid]) return;  // decoded (or sized) segment-wise, zh_inflate_seg.hip
 
   const ZhBufDesc bd = a.bufs[sid];
   const uint8_t* src = d_src + bd.src_off;

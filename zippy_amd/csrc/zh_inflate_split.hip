@@ -29,6 +29,7 @@
 // run both against the oracle).  Algorithmic traffic: C read + N written, plus the token
 // records (4 bytes per token, written once and read once).
 #include <cstdlib>
+#include <type_traits>
 
 #include "zh_common.h"
 #include "zh_kprof.h"
@@ -61,9 +62,10 @@ constexpr uint32_t kMapTerm = 0xffu;  // all-starts map: "ends the block (or fai
 constexpr uint32_t kRecSpecial = 0x8000u, kRecStored = 1u << 11, kRecEnd = 2u << 11;
 
 struct RunResult {
-  uint32_t end;   // bit position (superchunk-relative) behind the last token taken
-  uint32_t n;     // tokens
-  uint32_t term;  // 0 none, 1 end of block, else a ZH_ERR_* status
+  uint32_t end;    // bit position (superchunk-relative) behind the last token taken
+  uint32_t n;      // tokens
+  uint32_t term;   // 0 none, 1 end of block, else a ZH_ERR_* status
+  uint32_t bytes;  // output bytes of the tokens written (segment mode)
 };
 
 }  // namespace
@@ -71,12 +73,16 @@ struct RunResult {
 // kSplitThreads: 256 (a superchunk of 16 KiB of the stream, five workgroups per CU: batches) or
 // 1024 (64 KiB, one workgroup per CU: a handful of streams, where the chain of a stream's
 // superchunks is what takes the time).
-template <uint32_t kSplitThreads>
+// kSeg: a workgroup takes a SEGMENT of a stream (ZhSegArgs, zh_inflate_seg.hip): it starts at the
+// block the segment's search found, stops at the first block boundary at or behind the next found
+// start, and reports where that was, how many bytes its tokens make and whether the stream ended.
+template <uint32_t kSplitThreads, bool kSeg>
 __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(const uint8_t* __restrict__ d_src,
                                                                 ZhInflateArgs a,
                                                                 uint32_t* __restrict__ tok_pool,
                                                                 const uint64_t* __restrict__ tok_off,
-                                                                const uint64_t* __restrict__ tok_cap) {
+                                                                const uint64_t* __restrict__ tok_cap,
+                                                                ZhSegArgs g) {
   constexpr uint32_t kSuperBits = kSplitThreads * kSubBits;
   constexpr uint32_t kStageWords = (kSplitThreads + 1u) * kSubStride;
   constexpr uint32_t kWaves = kSplitThreads / 64u;
@@ -99,12 +105,26 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
 
   const uint32_t tid = threadIdx.x;
   const unsigned lane = zh_lane();
-  const uint32_t sid = blockIdx.x;
-  if (a.status[sid] != ZH_OK) return;  // unwrap already failed this stream
+  const uint32_t sid = blockIdx.x;                    // token region (a stream, or a segment of one)
+  const uint32_t bid = kSeg ? g.parent[sid] : sid;   // the stream
+  if (a.status[bid] != ZH_OK) return;  // unwrap already failed this stream
+  if (!kSeg && a.skip && a.skip[sid]) return;  // decoded segment-wise
+  uint64_t seg_start = 0, seg_target = kSegNone;
+  if (kSeg) {
+    seg_start = g.start_bit[sid];
+    if (seg_start == kSegNone) return;  // no block starts in this segment: the one before carries on through it
+    for (uint32_t j = sid + 1u, last = g.first_seg[bid + 1u]; j < last; j++) {
+      const uint64_t sj = g.start_bit[j];
+      if (sj != kSegNone) {
+        seg_target = sj;
+        break;
+      }
+    }
+  }
 
-  const ZhBufDesc bd = a.bufs[sid];
+  const ZhBufDesc bd = a.bufs[bid];
   const uint8_t* src = d_src + bd.src_off;
-  const uint64_t src_len = a.src_len_dev ? a.src_len_dev[sid] : bd.src_len;
+  const uint64_t src_len = a.src_len_dev ? a.src_len_dev[bid] : bd.src_len;
   const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
   const uint32_t* asrc = reinterpret_cast<const uint32_t*>(src - mis);
   const uint64_t end = mis + src_len;  // first byte offset (from asrc) past the stream
@@ -114,11 +134,13 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
     if (off + 4 > end) v &= (1u << (8 * (uint32_t)(end - off))) - 1u;
     return v;
   };
-  uint32_t* const tok = tok_pool + tok_off[sid];
-  const uint64_t cap = tok_cap[sid];  // records this stream may write (the end record included)
+  uint32_t* const tok = tok_pool + (kSeg ? g.tok_off[sid] : tok_off[sid]);
+  const uint64_t cap = kSeg ? g.tok_cap[sid] : tok_cap[sid];  // records this stream may write (the end record included)
+  __shared__ uint32_t s_wbytes[kWaves];
 
-  uint64_t pos = ((uint64_t)mis + a.body_pos[sid]) * 8;  // stream position in bits (from asrc)
-  uint64_t ntok = 0;
+  // stream position in bits (from asrc)
+  uint64_t pos = kSeg ? (uint64_t)mis * 8 + seg_start : ((uint64_t)mis + a.body_pos[sid]) * 8;
+  uint64_t ntok = 0, out_bytes = 0;
   KPROF_DECL(8);  // cycles: 0 header + tables, 1 staging, 2 sync turns, 3 scan, 4 token pass; counts: 5 superchunks, 6 turns, 7 streams
   int st = ZH_OK;
   bool final_block = false;
@@ -185,6 +207,7 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
     RunResult r;
     r.n = 0;
     r.term = 0;
+    r.bytes = 0;
     while (p < limit) {
       uint32_t rec, kind;
       const uint32_t tb = decode_at(p, &rec, &kind);
@@ -201,7 +224,10 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
         r.term = 1u;
         break;
       }
-      if (out) out[r.n] = rec;
+      if (out) {
+        out[r.n] = rec;
+        if (kSeg) r.bytes += rec & 0x1ffu;
+      }
       r.n++;
     }
     r.end = p;
@@ -209,6 +235,7 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
   };
 
   while (!final_block && st == ZH_OK) {  // inflate.nim:273-289
+    if (kSeg && pos - (uint64_t)mis * 8 >= seg_target) break;  // the next segment's decoder takes over
     // ---- block header: staged, then read by wave 0 like the serial kernel does ----
     const uint64_t hbase = pos >> 5;  // dword of the header's first bit
     KPROF_MARK(4);
@@ -344,6 +371,10 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
     __syncthreads();
     KPROF_MARK(0);
     const uint32_t btype = s_c_btype;
+#ifdef ZH_EMU
+    if (tid == 0 && getenv("ZH_DBG_BLOCKS"))
+      fprintf(stderr, "block at bit %llu type %u (region %u)\n", (unsigned long long)(hbase * 32 + (pos & 31u) - mis * 8), btype, sid);
+#endif
     st = (int)s_c_st;
     if (s_c_final) final_block = true;
     pos = s_c_pos;
@@ -364,6 +395,7 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
           tok[ntok + 2] = (uint32_t)(off >> 32);
         }
         ntok += 3;
+        out_bytes += len;
       }
       pos = (byte_pos + len) * 8;
       continue;
@@ -410,7 +442,7 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
       const uint32_t limit = (tid + 1u) * kSubBits;
       uint32_t my_start = tid == 0 ? rel0 : tid * kSubBits;
       bool dirty = true;
-      RunResult r = {0, 0, 0};
+      RunResult r = {0, 0, 0, 0};
       // A turn: threads whose start changed decode again; then every thread takes the end of the
       // thread before it as its start.  Threads below the first one whose start changed ("dirty")
       // have starts that follow from thread 0's exact one: they are final.  The superchunk is done
@@ -532,7 +564,14 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
       KPROF_MARK(3);
       // (parking every run's records in HBM and copying them into place here was tried: the
       // scattered 4-byte stores of the speculative turns cost more than this second decode)
-      if (active && r.n) (void)run(my_start, limit, end_rel, tok + ntok + before);
+      uint32_t made = 0;
+      if (active && r.n) made = run(my_start, limit, end_rel, tok + ntok + before).bytes;
+      if (kSeg) {
+        made = zh_wave_sum(made);
+        if (lane == 0) s_wbytes[tid >> 6] = made;
+        __syncthreads();
+        for (uint32_t w = 0; w < kWaves; w++) out_bytes += s_wbytes[w];
+      }
       KPROF_MARK(4);
       ntok += total;
       if (tterm < kSplitThreads) {
@@ -544,7 +583,15 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
       pos = base_bit + s_end[kSplitThreads - 1u];
     }
   }
-  if (tid == 0) tok[ntok] = kRecSpecial | kRecEnd | ((uint32_t)st << 16);
+  if (tid == 0) {
+    tok[ntok] = kRecSpecial | kRecEnd | ((uint32_t)st << 16);
+    if (kSeg) {
+      g.end_bit[sid] = pos - (uint64_t)mis * 8;
+      g.final_block[sid] = final_block ? 1u : 0u;
+      g.seg_status[sid] = st;
+      g.seg_out[sid] = out_bytes;
+    }
+  }
   KPROF_COUNT(7, 1);
   if (tid == 0) KPROF_FLUSH(48, 8);
 }
@@ -562,11 +609,17 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
 // a 1 MiB stream whatever the batch).  A single copy that does not fit a round goes alone.
 // ---------------------------------------------------------------------------
 // kWrThreads: 256 (rounds of 1024 bytes: batches) or 1024 (rounds of 4096 bytes: a handful of streams).
-template <uint32_t kWrThreads>
+// kSeg: a workgroup writes a chain SEGMENT of a stream (zh_inflate_seg.hip) as 16-bit symbols into
+// g.sym: a byte, or -- for a byte copied from the 32 KiB before the segment, which some other
+// workgroup is writing at the same time -- 0x8000 | its index in that window.  Copies of symbols are
+// copies whatever the symbol is; zh_seg_windows_kernel / zh_seg_finish_kernel turn them into bytes.
+template <uint32_t kWrThreads, bool kSeg>
 __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint8_t* __restrict__ d_src,
                                                                uint8_t* __restrict__ d_dst, ZhInflateArgs a,
                                                                const uint32_t* __restrict__ tok_pool,
-                                                               const uint64_t* __restrict__ tok_off) {
+                                                               const uint64_t* __restrict__ tok_off,
+                                                               ZhSegArgs g) {
+  typedef typename std::conditional<kSeg, uint16_t, uint8_t>::type Sym;
   constexpr uint32_t kWrWaves = kWrThreads / 64u;
   constexpr uint32_t kWrRound = kWrThreads * 4u;  // output bytes per round
   constexpr uint32_t kWrRecs = kWrThreads * 2u;   // records looked at per round
@@ -574,26 +627,30 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
   __shared__ uint32_t s_tok[kWrRing];
   __shared__ uint32_t s_map32[kWrRound / 2];  // u16 per byte: (index in the round of the record that starts there) + 1
   __shared__ uint32_t s_par32[kWrRound / 2];  // u16 per byte: the byte of this round it copies (itself: a root)
-  __shared__ uint32_t s_val32[kWrRound / 4];  // u8 per byte: its value (valid for roots)
+  __shared__ uint32_t s_val32[kWrRound * sizeof(Sym) / 4];  // a symbol per byte: its value (valid for roots)
   __shared__ uint32_t s_w[6][kWrWaves];       // per-wave partial results
   __shared__ uint32_t s_flag[4];              // round-wide flags (see below)
   uint16_t* const s_map = reinterpret_cast<uint16_t*>(s_map32);
   uint16_t* const s_par = reinterpret_cast<uint16_t*>(s_par32);
-  uint8_t* const s_val = reinterpret_cast<uint8_t*>(s_val32);
+  Sym* const s_val = reinterpret_cast<Sym*>(s_val32);
   const uint32_t tid = threadIdx.x, wv = tid >> 6;
   const unsigned lane = zh_lane();
   const uint32_t sid = blockIdx.x;
-  if (a.status[sid] != ZH_OK) return;
+  const uint32_t bid = kSeg ? g.parent[sid] : sid;
+  if (a.status[bid] != ZH_OK) return;
+  if (kSeg ? !g.valid[sid] : (a.skip && a.skip[sid])) return;
 
-  const ZhBufDesc bd = a.bufs[sid];
+  const ZhBufDesc bd = a.bufs[bid];
   const uint8_t* src = d_src + bd.src_off;
-  uint8_t* dst = d_dst + bd.dst_off;
-  const uint64_t cap = bd.dst_cap;
-  const uint32_t* tok = tok_pool + tok_off[sid];
+  const uint64_t gbase = kSeg ? g.out_start[sid] : 0;  // output bytes of the stream before this workgroup's
+  Sym* dst = kSeg ? reinterpret_cast<Sym*>(g.sym + g.sym_base[bid] + gbase) : reinterpret_cast<Sym*>(d_dst + bd.dst_off);
+  const uint64_t cap = bd.dst_cap - gbase;
+  const uint32_t* tok = tok_pool + (kSeg ? g.tok_off[sid] : tok_off[sid]);
 
   uint64_t op = 0;  // bytes produced (the same in every thread)
   int st = ZH_OK;
-  auto ld_out = [&](uint64_t at) -> uint32_t {
+  auto ld_out = [&](int64_t at) -> uint32_t {
+    if (kSeg && at < 0) return 0x8000u | (uint32_t)(32768 + at);  // (a distance is at most 32768)
     return __hip_atomic_load(dst + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // every thread's stores have reached L2 and every thread knows it: match sources are read back
@@ -605,7 +662,7 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
   // inflate.nim:224-250: one LZ copy of `length` bytes from `dist` back, at op (uniform arguments;
   // the output written so far is visible)
   auto lz_copy = [&](uint32_t length, uint32_t dist) {
-    if (dist > op) {  // inflate.nim:224-225
+    if (dist > gbase + op) {  // inflate.nim:224-225
       st = ZH_ERR_INVALID_BUFFER;
       return;
     }
@@ -613,14 +670,14 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
       st = ZH_ERR_DST_TOO_SMALL;
       return;
     }
-    const uint64_t sb = op - dist;
+    const int64_t sb = (int64_t)op - dist;
     if (dist >= length) {
-      for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = (uint8_t)ld_out(sb + i);
+      for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = (Sym)ld_out(sb + i);
     } else if (dist == 1) {
-      const uint8_t v = (uint8_t)ld_out(sb);
+      const Sym v = (Sym)ld_out(sb);
       for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = v;
     } else {
-      for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = (uint8_t)ld_out(sb + i % dist);
+      for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = (Sym)ld_out(sb + i % dist);
     }
     op += length;
   };
@@ -682,8 +739,8 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
         s_w[3][wv] = wend;
       }
       // inflate.nim:224-225 `distance > op` (a distance is at most 32768)
-      if (op < 32768u && ((fit0 && !lit0 && (uint64_t)(r0 >> 16) > op + o0) ||
-                          (fit1 && !lit1 && (uint64_t)(r1 >> 16) > op + o1)))
+      if (gbase + op < 32768u && ((fit0 && !lit0 && (uint64_t)(r0 >> 16) > gbase + op + o0) ||
+                                  (fit1 && !lit1 && (uint64_t)(r1 >> 16) > gbase + op + o1)))
         s_flag[round & 1u] = 1;  // (flag words alternate between rounds; the idle one is cleared below)
     }
     __syncthreads();
@@ -709,7 +766,7 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
             st = ZH_ERR_DST_TOO_SMALL;
             break;
           }
-          for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = src[off + i];
+          for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = (Sym)src[off + i];
           op += length;
           ti += 3;
           output_visible();
@@ -771,14 +828,19 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
           par[j] = pb - dist;
           any_near = true;
         } else {
-          val[j] = ld_out(op + pb - dist);  // (written before this round: visible since its start)
+          val[j] = ld_out((int64_t)(op + pb) - dist);  // (written before this round: visible since its start)
         }
       }
     }
     if (any_near) s_flag[2u + (round & 1u)] = 1;
     s_par32[2u * tid] = par[0] | (par[1] << 16);
     s_par32[2u * tid + 1u] = par[2] | (par[3] << 16);
-    s_val32[tid] = (val[0] & 0xffu) | ((val[1] & 0xffu) << 8) | ((val[2] & 0xffu) << 16) | (val[3] << 24);
+    if (kSeg) {
+      s_val32[2u * tid] = (val[0] & 0xffffu) | (val[1] << 16);
+      s_val32[2u * tid + 1u] = (val[2] & 0xffffu) | (val[3] << 16);
+    } else {
+      s_val32[tid] = (val[0] & 0xffu) | ((val[1] & 0xffu) << 8) | ((val[2] & 0xffu) << 16) | (val[3] << 24);
+    }
     __syncthreads();
     if (s_flag[2u + (round & 1u)]) {
       // par <- par[par] until every byte points at a root.  s_w[5][k & 1] counts the threads that
@@ -805,23 +867,40 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
 #pragma unroll
       for (int j = 0; j < 4; j++) val[j] = s_val[par[j]];
     }
-    const uint32_t w = (val[0] & 0xffu) | ((val[1] & 0xffu) << 8) | ((val[2] & 0xffu) << 16) | (val[3] << 24);
     const uint32_t pb0 = 4u * tid;
-    if (pb0 + 4u <= total) {
-      struct __attribute__((packed)) U32 { uint32_t v; };
-      reinterpret_cast<U32*>(dst + op + pb0)->v = w;  // (gfx950 global stores need no alignment)
-    } else {
+    if (kSeg) {
+      if (pb0 + 4u <= total) {
+        struct __attribute__((packed)) U64 { uint64_t v; };
+        reinterpret_cast<U64*>(dst + op + pb0)->v = (uint64_t)((val[0] & 0xffffu) | (val[1] << 16)) |
+                                                    ((uint64_t)((val[2] & 0xffffu) | (val[3] << 16)) << 32);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (pb0 + (uint32_t)j < total) dst[op + pb0 + (uint32_t)j] = (uint8_t)(w >> (8 * j));
+        for (int j = 0; j < 4; j++)
+          if (pb0 + (uint32_t)j < total) dst[op + pb0 + (uint32_t)j] = (Sym)val[j];
+      }
+    } else {
+      const uint32_t w = (val[0] & 0xffu) | ((val[1] & 0xffu) << 8) | ((val[2] & 0xffu) << 16) | (val[3] << 24);
+      if (pb0 + 4u <= total) {
+        struct __attribute__((packed)) U32 { uint32_t v; };
+        reinterpret_cast<U32*>(dst + op + pb0)->v = w;  // (gfx950 global stores need no alignment)
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (pb0 + (uint32_t)j < total) dst[op + pb0 + (uint32_t)j] = (Sym)(w >> (8 * j));
+      }
     }
     op += total;
     ti += n;
     output_visible();
   }
   if (tid == 0) {
-    a.out_len[sid] = op;
-    a.status[sid] = st;
+    if (kSeg) {
+      g.wr_len[sid] = op;
+      if (st != ZH_OK) g.seg_status[sid] = st;
+    } else {
+      a.out_len[sid] = op;
+      a.status[sid] = st;
+    }
   }
 }
 
@@ -840,19 +919,39 @@ extern "C" void zh_launch_inflate_tokens(hipStream_t stream, const uint8_t* d_sr
                                          uint32_t* tok_pool, const uint64_t* tok_off, const uint64_t* tok_cap) {
   if (!a.nbufs) return;
   if (zh_inflate_wide(a.nbufs))
-    hipLaunchKernelGGL(zh_inflate_tokens_kernel<1024>, dim3(a.nbufs), dim3(1024), 0, stream, d_src, a, tok_pool,
-                       tok_off, tok_cap);
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<1024, false>), dim3(a.nbufs), dim3(1024), 0, stream, d_src, a,
+                       tok_pool, tok_off, tok_cap, ZhSegArgs{});
   else
-    hipLaunchKernelGGL(zh_inflate_tokens_kernel<256>, dim3(a.nbufs), dim3(256), 0, stream, d_src, a, tok_pool,
-                       tok_off, tok_cap);
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, false>), dim3(a.nbufs), dim3(256), 0, stream, d_src, a,
+                       tok_pool, tok_off, tok_cap, ZhSegArgs{});
+}
+extern "C" void zh_launch_seg_tokens(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a, uint32_t* tok_pool,
+                                     ZhSegArgs g) {
+  if (!g.nsegs) return;
+  if (zh_inflate_wide(g.nsegs))
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<1024, true>), dim3(g.nsegs), dim3(1024), 0, stream, d_src, a,
+                       tok_pool, nullptr, nullptr, g);
+  else
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, true>), dim3(g.nsegs), dim3(256), 0, stream, d_src, a,
+                       tok_pool, nullptr, nullptr, g);
+}
+extern "C" void zh_launch_seg_write(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a, const uint32_t* tok_pool,
+                                    ZhSegArgs g) {
+  if (!g.nsegs) return;
+  if (zh_inflate_wide(g.nsegs))
+    hipLaunchKernelGGL((zh_inflate_write_kernel<1024, true>), dim3(g.nsegs), dim3(1024), 0, stream, d_src, nullptr, a,
+                       tok_pool, nullptr, g);
+  else
+    hipLaunchKernelGGL((zh_inflate_write_kernel<256, true>), dim3(g.nsegs), dim3(256), 0, stream, d_src, nullptr, a,
+                       tok_pool, nullptr, g);
 }
 extern "C" void zh_launch_inflate_write(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a,
                                         const uint32_t* tok_pool, const uint64_t* tok_off) {
   if (!a.nbufs) return;
   if (zh_inflate_wide(a.nbufs))
-    hipLaunchKernelGGL(zh_inflate_write_kernel<1024>, dim3(a.nbufs), dim3(1024), 0, stream, d_src, d_dst, a,
-                       tok_pool, tok_off);
+    hipLaunchKernelGGL((zh_inflate_write_kernel<1024, false>), dim3(a.nbufs), dim3(1024), 0, stream, d_src, d_dst, a,
+                       tok_pool, tok_off, ZhSegArgs{});
   else
-    hipLaunchKernelGGL(zh_inflate_write_kernel<256>, dim3(a.nbufs), dim3(256), 0, stream, d_src, d_dst, a,
-                       tok_pool, tok_off);
+    hipLaunchKernelGGL((zh_inflate_write_kernel<256, false>), dim3(a.nbufs), dim3(256), 0, stream, d_src, d_dst, a,
+                       tok_pool, tok_off, ZhSegArgs{});
 }
