@@ -169,7 +169,48 @@ def mutations(count, seed=20260926):
     return bad
 
 
+def seg_mutations(count, seed=20260927):
+    """The segment-wise decode of large streams (zh_inflate_seg.hip) under damage: `count` mutations
+    (a flipped bit, or the stream cut short) of multi-block foreign streams, eight to a call so that
+    every call takes the segment path; accept/reject decision and bytes must equal the oracle's."""
+    import parity_cases as pc
+    os.environ["ZH_SEG_BYTES"] = "2048"
+    os.environ["ZH_SEG_MIN"] = "8192"
+    eng = api.engine()
+    rnd = random.Random(seed)
+    cases = pc.segmented_streams(1024)
+    bad = accepted = 0
+    per_fmt = {}
+    for _ in range(count):
+        blob, fmt, _plain = cases[rnd.randrange(len(cases))]
+        if rnd.random() < 0.25:
+            m = blob[:rnd.randrange(len(blob) // 2, len(blob))]
+        else:
+            b = bytearray(blob)
+            for _k in range(rnd.choice((1, 1, 1, 2, 3))):
+                b[rnd.randrange(2, len(b))] ^= 1 << rnd.randrange(8)
+            m = bytes(b)
+        per_fmt.setdefault(fmt, []).append(m)
+    for fmt, blobs in per_fmt.items():
+        for lo in range(0, len(blobs), 8):
+            part = blobs[lo:lo + 8]
+            outs, sts = eng.uncompress_batch(part, fmt)
+            for blob, o, st in zip(part, outs, sts):
+                try:
+                    w = oracle.uncompress(blob, fmt)
+                except oracle.ZippyError:
+                    w = None
+                accepted += st == 0
+                if (st == 0) != (w is not None) or (st == 0 and o != w):
+                    bad += 1
+                    print("SEGMENT MUTATION MISMATCH fmt", fmt, len(blob), st)
+    print("gpu_fuzz segment mutations: %d blobs accepted %d rejected %d bad %d" % (count, accepted, count - accepted, bad))
+    return bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--seg-mutations":
+        sys.exit(1 if seg_mutations(int(sys.argv[2]) if len(sys.argv) > 2 else 4000) else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "--mutations":
         sys.exit(1 if mutations(int(sys.argv[2]) if len(sys.argv) > 2 else 10000) else 0)
     sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 4) else 0)

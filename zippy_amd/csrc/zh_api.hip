@@ -38,6 +38,7 @@ void zh_launch_inflate_write(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, 
                              const uint32_t* tok_pool, const uint64_t* tok_off);
 void zh_launch_segments_reduce(hipStream_t, ZhInflateArgs seg, ZhInflateArgs whole);
 void zh_launch_seg_find(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g);
+void zh_launch_seg_check(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_seg_tokens(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, uint32_t* tok_pool, ZhSegArgs g);
 void zh_launch_seg_chain(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_seg_write(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, const uint32_t* tok_pool, ZhSegArgs g);
@@ -261,6 +262,7 @@ struct zh_plan {
   uint8_t* sg_arena = nullptr;
   uint16_t* sg_sym = nullptr;
   uint8_t* sg_windows = nullptr;
+  uint16_t* sg_winsym = nullptr;
   uint64_t sg_sym_count = 0;
   // profiling
   bool profiling = false;
@@ -315,6 +317,7 @@ extern "C" void zh_plan_destroy(zh_plan* p) {
   if (p->sg_arena) (void)hipFree(p->sg_arena);
   if (p->sg_sym) (void)hipFree(p->sg_sym);
   if (p->sg_windows) (void)hipFree(p->sg_windows);
+  if (p->sg_winsym) (void)hipFree(p->sg_winsym);
   for (auto e : p->k_events) (void)hipEventDestroy(e);
   delete p;
 }
@@ -554,11 +557,11 @@ extern "C" int zh_plan_block_index(zh_plan* p, size_t buf, zh_block_entry** inde
 }
 
 // Large streams are decoded segment-wise (zh_inflate_seg.hip) when a batch is a handful of them:
-// ZH_SEG=0 turns that off, ZH_SEG_MIN is the smallest stream (compressed bytes, default 256 KiB),
-// ZH_SEG_BYTES the segment length (default 64 KiB).
+// ZH_SEG=0 turns that off, ZH_SEG_MIN is the smallest stream (compressed bytes, default 128 KiB),
+// ZH_SEG_BYTES the segment length (default 32 KiB).
 struct SegConfig {
   bool on = true;
-  uint64_t min_stream = 262144, seg_bytes = 65536;
+  uint64_t min_stream = 131072, seg_bytes = 32768;
   size_t max_streams = 64;
 };
 static SegConfig seg_config() {  // (read per plan: the tests switch it)
@@ -579,7 +582,7 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   if (!c.on || !n || n > c.max_streams) return;
   for (const ZhBufDesc& b : bufs)
     if (b.src_len < c.min_stream || b.src_len < 2 * c.seg_bytes || b.src_len > (~0ull >> 4)) return;
-  std::vector<uint32_t> parent, first_seg(n + 1);
+  std::vector<uint32_t> parent, first_seg(n + 1), find_seg, find_batch;
   std::vector<uint64_t> nominal, search, toff, tcap, sym_base(n);
   uint64_t nsym = 0;
   for (size_t i = 0; i < n; i++) {
@@ -588,6 +591,14 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
     const uint64_t seg_bits = (b.src_len * 8 + ns - 1) / ns, seg_len = (seg_bits + 7) / 8;
     first_seg[i] = (uint32_t)parent.size();
     for (uint64_t k = 0; k < ns; k++) {
+      for (uint64_t bt = 0; k && bt * 65536 < seg_bits; bt++) {  // (the first segment's start is known)
+        find_seg.push_back((uint32_t)parent.size());
+        find_batch.push_back((uint32_t)bt);
+      }
+      if (!k) {
+        find_seg.push_back((uint32_t)parent.size());
+        find_batch.push_back(0);
+      }
       parent.push_back((uint32_t)i);
       nominal.push_back(k * seg_bits);
       search.push_back(seg_bits);
@@ -611,7 +622,11 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
                o_symb = ar.reserve(n * 8), o_start = ar.reserve(ns * 8), o_end = ar.reserve(ns * 8),
                o_final = ar.reserve(ns * 4), o_sst = ar.reserve(ns * 4), o_sout = ar.reserve(ns * 8),
                o_wlen = ar.reserve(ns * 8), o_valid = ar.reserve(ns * 4), o_prev = ar.reserve(ns * 4),
-               o_ostart = ar.reserve(ns * 8), o_sok = ar.reserve(n * 4);
+               o_ostart = ar.reserve(ns * 8), o_sok = ar.reserve(n * 4), o_order = ar.reserve(ns * 4),
+               o_nchain = ar.reserve(n * 4), o_ordinal = ar.reserve(ns * 4);
+  const size_t nfind = find_seg.size();
+  const size_t o_fseg = ar.reserve(nfind * 4), o_fbatch = ar.reserve(nfind * 4), o_cn = ar.reserve(nfind * 4),
+               o_coff = ar.reserve(nfind * 64 * 4);
   ar.reserve(256);
   if (hipMalloc(&p->sg_arena, ar.size) != hipSuccess) {
     (void)hipGetLastError();
@@ -631,6 +646,8 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   put(o_toff, toff.data(), ns * 8);
   put(o_tcap, tcap.data(), ns * 8);
   put(o_symb, sym_base.data(), n * 8);
+  put(o_fseg, find_seg.data(), nfind * 4);
+  put(o_fbatch, find_batch.data(), nfind * 4);
   if (up == hipSuccess) up = hipStreamSynchronize(s);
   if (up != hipSuccess) {
     (void)hipGetLastError();
@@ -658,6 +675,14 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   g.prev = carve<uint32_t>(base, o_prev);
   g.out_start = carve<uint64_t>(base, o_ostart);
   g.stream_ok = carve<uint32_t>(base, o_sok);
+  g.order = carve<uint32_t>(base, o_order);
+  g.nchain = carve<uint32_t>(base, o_nchain);
+  g.ordinal = carve<uint32_t>(base, o_ordinal);
+  g.nfind = (uint32_t)nfind;
+  g.find_seg = carve<uint32_t>(base, o_fseg);
+  g.find_batch = carve<uint32_t>(base, o_fbatch);
+  g.cand_n = carve<uint32_t>(base, o_cn);
+  g.cand_off = carve<uint32_t>(base, o_coff);
   p->sg_sym_count = nsym + 64;
   p->segmented = true;
 }
@@ -850,15 +875,19 @@ static bool plan_token_pool(zh_plan* p) {
   }
   if (p->segmented) {  // without its buffers the plan simply is not segmented
     if (hipMalloc(&p->sg_sym, p->sg_sym_count * 2) != hipSuccess ||
-        hipMalloc(&p->sg_windows, (size_t)p->sg.nsegs * 32768u) != hipSuccess) {
+        hipMalloc(&p->sg_windows, (size_t)p->sg.nsegs * 32768u) != hipSuccess ||
+        hipMalloc(&p->sg_winsym, (size_t)p->sg.nsegs * 65536u) != hipSuccess) {
       (void)hipGetLastError();
       if (p->sg_sym) (void)hipFree(p->sg_sym);
+      if (p->sg_windows) (void)hipFree(p->sg_windows);
       p->sg_sym = nullptr;
       p->sg_windows = nullptr;
+      p->sg_winsym = nullptr;
       p->segmented = false;
     } else {
       p->sg.sym = p->sg_sym;
       p->sg.windows = p->sg_windows;
+      p->sg.winsym = p->sg_winsym;
     }
   }
   return true;
@@ -953,6 +982,8 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       // stops behind the chain kernel, which knows the output size by then.
       prof_mark(p, "zh_seg_find_kernel");
       zh_launch_seg_find(s, d_src, a, p->sg);
+      prof_mark(p, "zh_seg_check_kernel");
+      zh_launch_seg_check(s, d_src, a, p->sg);
       prof_mark(p, "zh_seg_tokens_kernel");
       zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg);
       prof_mark(p, "zh_seg_chain_kernel");

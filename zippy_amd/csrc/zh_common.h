@@ -127,6 +127,12 @@ struct ZhSegArgs {
   const uint64_t* tok_off;      // [nsegs] token region of the segment in the plan's token pool
   const uint64_t* tok_cap;
   const uint64_t* sym_base;     // [nstreams] first symbol of the stream's output in `sym`
+  // the search for block starts: one workgroup per batch of 65536 bit positions of a segment
+  uint32_t nfind;
+  const uint32_t* find_seg;     // [nfind]
+  const uint32_t* find_batch;   // [nfind]
+  uint32_t* cand_n;             // [nfind] positions of the batch that passed the cheap tests ...
+  uint32_t* cand_off;           // [nfind][64] ... as offsets into the batch
   // find / tokens results
   uint64_t* start_bit;          // [nsegs] first bit of the segment's first block, or kSegNone
   uint64_t* end_bit;            // [nsegs] the block boundary the tokens kernel stopped at
@@ -139,9 +145,14 @@ struct ZhSegArgs {
   uint32_t* prev;               // [nsegs] the chain segment before it (0xffffffff: none)
   uint64_t* out_start;          // [nsegs] first output byte of the segment in its stream
   uint32_t* stream_ok;          // [nstreams] the chain holds: the stream is decoded segment-wise
+  uint32_t* order;              // [nsegs] a stream's chain segments in order, from first_seg[i] on
+  uint32_t* nchain;             // [nstreams] ... and how many they are
+  uint32_t* ordinal;            // [nsegs] a chain segment's place in that order
   // 16-bit output symbols (a byte, or 0x8000 | index into the 32 KiB window before the segment)
   uint16_t* sym;
-  uint8_t* windows;             // [nsegs][32768] the last 32 KiB of output at the end of a chain segment
+  uint16_t* winsym;             // [nsegs][32768] the last 32 KiB of output at the end of a chain segment as symbols
+                                //   (0x8000 | k here also stands for byte k of the window before a short segment)
+  uint8_t* windows;             // [nsegs][32768] ... and as bytes
 };
 
 // ---- wave helpers (single-wave workgroups; lockstep execution on gfx950) ----

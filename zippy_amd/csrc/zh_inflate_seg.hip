@@ -5,14 +5,17 @@
 // one before it has been decoded, which ties a stream to one workgroup however large it is (a
 // tar.gz, a 128 MiB zlib stream).  This file removes that chain the way parallel gzip readers do:
 //
-//   zh_seg_find_kernel     the compressed bytes are cut into segments of equal length; a workgroup
-//                          per segment looks for the first bit position at or behind the segment's
-//                          nominal start that reads as the header of a dynamic-Huffman block
-//                          (inflate.nim:115-171): BTYPE = 2, HLIT/HDIST in range, a complete
-//                          code-length code, code lengths that decode to exactly HLIT + HDIST
-//                          entries and describe a complete literal/length code with an
-//                          end-of-block symbol and a usable distance code.  A position that passes
-//                          is almost certainly a block start, but it is only a GUESS;
+//   zh_seg_find_kernel     the compressed bytes are cut into segments of equal length, and every
+//   zh_seg_check_kernel    bit position is asked whether it reads as the header of a dynamic-
+//                          Huffman block (inflate.nim:115-171).  The find kernel takes the cheap
+//                          questions, a thread per 64 positions: BFINAL = 0, BTYPE = 2, HLIT and
+//                          HDIST in range (all 64 at once, bitwise), then a complete code-length
+//                          code (one position in 4 500 of random bits survives: they are queued);
+//                          the check kernel, a thread per survivor, decodes the code lengths: exactly
+//                          HLIT + HDIST of them, a complete literal/length code with an end-of-block
+//                          symbol, a usable distance code.  The lowest position of a segment that
+//                          passes is the segment's start: almost certainly a block start, but only
+//                          a GUESS;
 //   tokens (segment form)  decode from the found start to the first block boundary at or behind the
 //                          next found start, all segments at once;
 //   zh_seg_chain_kernel    the proof: walking the stream's segments in order, every decoder must
@@ -36,20 +39,29 @@
 #include <cstdlib>
 
 #include "zh_common.h"
+#include "zh_kprof.h"
 #include "zh_tables.h"
 #include "zh_inflate_tables.h"
 
 namespace {
 
-constexpr uint32_t kFindThreads = 1024;
-constexpr uint32_t kFindPer = 64;                         // bit positions per thread and batch
-constexpr uint32_t kFindBatch = kFindThreads * kFindPer;  // 65536 positions
+constexpr uint32_t kFindThreads = 256;
+constexpr uint32_t kFindBatch = 65536;  // bit positions a workgroup of the search takes
+constexpr uint32_t kFindSlots = 64;     // candidates it can hand on
 constexpr uint32_t kWin = 32768;
 
-// the 32 bits at bit position p of the stream (bits past the end read as zero)
-__device__ __forceinline__ uint32_t seg_peek(const uint8_t* src, uint64_t len, uint64_t p) {
+// A batch of the search: 65536 bit positions and the 74 bits of header behind the last of them,
+// staged in LDS as dwords.
+constexpr uint32_t kFindStage = kFindBatch / 32u + 8u;
+
+// the 32 bits at bit `rel` of the staged bytes
+__device__ __forceinline__ uint32_t seg_peek(const uint32_t* s_buf, uint32_t rel) {
+  const uint32_t i = rel >> 5;
+  return zh_alignbit(s_buf[i + 1u], s_buf[i], rel);
+}
+// the 32 bits at bit p of the stream itself (bits behind its end read as zero)
+__device__ __forceinline__ uint32_t seg_peek_stream(const uint8_t* src, uint64_t len, uint64_t p) {
   const uint64_t b = p >> 3;
-  const uint32_t sh = (uint32_t)p & 7u;
   uint64_t v = 0;
   if (b + 8 <= len) {
     struct __attribute__((packed)) U64 { uint64_t v; };
@@ -58,57 +70,104 @@ __device__ __forceinline__ uint32_t seg_peek(const uint8_t* src, uint64_t len, u
     for (uint32_t i = 0; i < 8; i++)
       if (b + i < len) v |= (uint64_t)src[b + i] << (8 * i);
   }
-  return (uint32_t)(v >> sh);
+  return (uint32_t)(v >> ((uint32_t)p & 7u));
 }
 
-// Does a dynamic-Huffman block header start at bit p?  (The cheap tests first.)
-__device__ bool seg_header_at(const uint8_t* src, uint64_t len, uint64_t p) {
-  const uint32_t h = seg_peek(src, len, p);
-  if ((h & 7u) != 4u) return false;  // BFINAL = 0, BTYPE = 2 (the last block is left to the decoder before it)
-  const uint32_t hlit = ((h >> 3) & 31u) + 257u, hdist = ((h >> 8) & 31u) + 1u, hclen = ((h >> 13) & 15u) + 4u;
-  if (hlit > 286u || hdist > 30u) return false;
-  // the code-length code: 3 bits per entry in c_clcl_order; it must be complete
-  uint64_t cl = 0;  // 3 bits per symbol 0..18
+// The code-length code of a dynamic header at staged bit p (whose first 13 bits have passed): 3
+// bits per entry, HCLEN + 4 entries; it must be complete.  Branch-free: most candidates end here.
+__device__ __forceinline__ bool seg_precode_complete(const uint32_t* s_buf, uint32_t p) {
+  const uint32_t hclen = ((seg_peek(s_buf, p + 13u) & 15u) + 4u) * 3u;  // bits
+  uint32_t w0 = seg_peek(s_buf, p + 17u), w1 = seg_peek(s_buf, p + 47u);  // entries 0-9, 10-18
+  w0 &= hclen >= 30u ? 0x3fffffffu : (1u << hclen) - 1u;
+  w1 &= hclen > 30u ? (1u << (hclen - 30u)) - 1u : 0u;
   uint32_t kraft = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 10; i++) {
+    const uint32_t v = (w0 >> (3u * i)) & 7u;
+    kraft += (128u >> v) & (v ? 0xffu : 0u);
+  }
+#pragma unroll
+  for (uint32_t i = 0; i < 9; i++) {
+    const uint32_t v = (w1 >> (3u * i)) & 7u;
+    kraft += (128u >> v) & (v ? 0xffu : 0u);
+  }
+  return kraft == 128u;
+}
+
+// The rest of a dynamic header at bit p of the stream whose code-length code is complete.  The
+// bits come through a 128-bit window; the load of the next 64 is in flight while these are used.
+__device__ bool seg_lengths_ok(const uint8_t* src, uint64_t len, uint64_t p) {
+  auto load64 = [&](uint64_t b) -> uint64_t {  // stream bytes b .. b + 7 (zeros behind the end)
+    uint64_t v = 0;
+    if (b + 8 <= len) {
+      struct __attribute__((packed)) U64 { uint64_t v; };
+      v = reinterpret_cast<const U64*>(src + b)->v;
+    } else {
+      for (uint32_t i = 0; i < 8; i++)
+        if (b + i < len) v |= (uint64_t)src[b + i] << (8 * i);
+    }
+    return v;
+  };
+  uint64_t nb = p >> 3;  // next byte to load
+  uint64_t lo = load64(nb), hi = load64(nb + 8);
+  nb += 16;
+  uint32_t used = (uint32_t)p & 7u;  // bits of `lo` already taken
+  uint64_t q = p;                    // stream position of the window's next bit
+  auto peek = [&]() -> uint32_t { return (uint32_t)(used ? (lo >> used) | (hi << (64u - used)) : lo); };
+  auto take = [&](uint32_t n) {
+    used += n;
+    q += n;
+    if (used >= 64u) {
+      lo = hi;
+      hi = load64(nb);
+      nb += 8;
+      used -= 64u;
+    }
+  };
+  const uint32_t h = peek();
+  const uint32_t hlit = ((h >> 3) & 31u) + 257u, hdist = ((h >> 8) & 31u) + 1u, hclen = ((h >> 13) & 15u) + 4u;
+  take(17);
+  uint64_t cl = 0;  // 3 bits per symbol 0..18
+  for (uint32_t i = 0; i < hclen; i++) {
+    cl |= (uint64_t)(peek() & 7u) << (3u * c_clcl_order[i]);
+    take(3);
+  }
+  // canonical code (inflate.nim:29-65 in miniature): counts per length (4 bits each), first slot
+  // per length, symbols in code order (5 bits each)
+  uint32_t counts = 0;
+  for (uint32_t s = 0; s < 19; s++) counts += 1u << (4u * ((uint32_t)(cl >> (3u * s)) & 7u));  // (a count is < 16: two lengths at least)
+  uint64_t offs = 0;  // 8 bits per length
   {
-    const uint32_t w0 = seg_peek(src, len, p + 17), w1 = seg_peek(src, len, p + 47);  // entries 0-9, 10-18
-    for (uint32_t i = 0; i < hclen; i++) {
-      const uint32_t v = (i < 10u ? w0 >> (3u * i) : w1 >> (3u * (i - 10u))) & 7u;
-      cl |= (uint64_t)v << (3u * c_clcl_order[i]);
-      if (v) kraft += 128u >> v;
+    uint32_t run = 0;
+    for (uint32_t l = 1; l <= 7; l++) {
+      offs |= (uint64_t)run << (8u * l);
+      run += (counts >> (4u * l)) & 15u;
     }
   }
-  if (kraft != 128u) return false;
-  // canonical code (inflate.nim:29-65 in miniature): counts per length, symbols in code order
-  uint32_t count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (uint32_t s = 0; s < 19; s++) count[(cl >> (3u * s)) & 7u]++;
-  uint32_t offs[8];
-  offs[1] = 0;
-  for (uint32_t l = 1; l < 7; l++) offs[l + 1] = offs[l] + count[l];
-  uint64_t sorted_lo = 0, sorted_hi = 0;  // 5 bits per slot, 12 slots a word
+  uint64_t sorted_lo = 0, sorted_hi = 0;  // 12 slots a word
   for (uint32_t s = 0; s < 19; s++) {
     const uint32_t l = (uint32_t)(cl >> (3u * s)) & 7u;
     if (!l) continue;
-    const uint32_t at = offs[l]++;
+    const uint32_t at = (uint32_t)(offs >> (8u * l)) & 255u;
+    offs += 1ull << (8u * l);
     if (at < 12u) sorted_lo |= (uint64_t)s << (5u * at);
     else sorted_hi |= (uint64_t)s << (5u * (at - 12u));
   }
   // the HLIT + HDIST code lengths (inflate.nim:131-165); both codes are checked as they come
-  uint64_t q = p + 17 + 3 * hclen;
   const uint32_t total = hlit + hdist;
   uint32_t i = 0, prev = 0, lit_kraft = 0, dist_kraft = 0, dist_used = 0;
   bool eob = false;
   while (i < total) {
-    uint32_t w = seg_peek(src, len, q);
-    uint32_t code = 0, first = 0, index = 0, sym = 0xffu, nb = 0;
+    uint32_t w = peek();
+    uint32_t code = 0, first = 0, index = 0, sym = 0xffu, nbits = 0;
     for (uint32_t l = 1; l <= 7; l++) {
       code |= w & 1u;
       w >>= 1;
-      const uint32_t c = count[l];
+      const uint32_t c = (counts >> (4u * l)) & 15u;
       if (code < first + c) {  // (code >= first always holds: the code is complete)
         const uint32_t at = index + (code - first);
         sym = at < 12u ? (uint32_t)(sorted_lo >> (5u * at)) & 31u : (uint32_t)(sorted_hi >> (5u * (at - 12u))) & 31u;
-        nb = l;
+        nbits = l;
         break;
       }
       index += c;
@@ -116,22 +175,22 @@ __device__ bool seg_header_at(const uint8_t* src, uint64_t len, uint64_t p) {
       code <<= 1;
     }
     if (sym == 0xffu) return false;
-    q += nb;
     uint32_t rep = 1, val = sym;
     if (sym == 16) {
       if (i == 0) return false;
       rep = (w & 3u) + 3u;
-      q += 2;
+      nbits += 2;
       val = prev;
     } else if (sym == 17) {
       rep = (w & 7u) + 3u;
-      q += 3;
+      nbits += 3;
       val = 0;
     } else if (sym == 18) {
       rep = (w & 127u) + 11u;
-      q += 7;
+      nbits += 7;
       val = 0;
     }
+    take(nbits);
     if (i + rep > total) return false;
     if (val) {
       for (uint32_t k = 0; k < rep; k++) {
@@ -156,176 +215,410 @@ __device__ bool seg_header_at(const uint8_t* src, uint64_t len, uint64_t p) {
 
 }  // namespace
 
+// A workgroup per batch of 65536 bit positions of a segment's search range (g.find_seg /
+// g.find_batch name it): staged once, then a thread takes 64 consecutive positions at a time.
 __global__ __launch_bounds__(kFindThreads) void zh_seg_find_kernel(const uint8_t* __restrict__ d_src, ZhInflateArgs a,
                                                                    ZhSegArgs g) {
-  __shared__ uint32_t s_best;
-  const uint32_t sid = blockIdx.x, tid = threadIdx.x;
+  __shared__ uint32_t s_buf[kFindStage];
+  __shared__ uint32_t s_cand[kFindSlots], s_ncand;
+  const uint32_t sid = g.find_seg[blockIdx.x], batch = g.find_batch[blockIdx.x], tid = threadIdx.x;
+  if (tid == 0) g.cand_n[blockIdx.x] = 0;
   const uint32_t bid = g.parent[sid];
-  if (a.status[bid] != ZH_OK) {
-    if (tid == 0) g.start_bit[sid] = kSegNone;
-    return;
-  }
-  if (sid == g.first_seg[bid]) {  // the stream's first block: behind the container header, exact
-    if (tid == 0) g.start_bit[sid] = (uint64_t)a.body_pos[bid] * 8;
-    return;
-  }
+  const bool first = sid == g.first_seg[bid];
+  const bool live = a.status[bid] == ZH_OK;
+  if (batch == 0 && tid == 0)  // the stream's first block: behind the container header, exact
+    g.start_bit[sid] = first && live ? (uint64_t)a.body_pos[bid] * 8 : kSegNone;
+  if (first || !live) return;
   const ZhBufDesc bd = a.bufs[bid];
   const uint8_t* src = d_src + bd.src_off;
   const uint64_t len = a.src_len_dev ? a.src_len_dev[bid] : bd.src_len;
-  const uint64_t lo = g.nominal_bit[sid];
-  uint64_t hi = lo + g.search_bits[sid];
+  const uint64_t base = g.nominal_bit[sid] + (uint64_t)batch * kFindBatch;
+  uint64_t hi = g.nominal_bit[sid] + g.search_bits[sid];
   if (hi > len * 8) hi = len * 8;
-  for (uint64_t base = lo; base < hi; base += kFindBatch) {
-    if (tid == 0) s_best = 0xffffffffu;
-    __syncthreads();
-    // interleaved: in step j the threads test kFindThreads consecutive positions
-    for (uint32_t j = 0; j < kFindPer; j++) {
-      const uint64_t p = base + (uint64_t)j * kFindThreads + tid;
-      if (p >= hi) break;
-      if ((uint32_t)(p - base) > *(volatile uint32_t*)&s_best) break;  // (a lower position has passed already)
-      if (seg_header_at(src, len, p)) {
-        atomicMin(&s_best, (uint32_t)(p - base));
-        break;
+  if (base >= hi) return;
+  KPROF_DECL(8);  // cycles: 0 staging, 1 first 13 bits, 2 code-length codes; counts: 5 candidates, 6 queued, 7 waves
+  KPROF_COUNT(7, 1);
+  // stage the batch: dword i = stream bytes sb + 4 i .. (zeros behind the end)
+  const uint64_t sb = (base >> 3) & ~(uint64_t)3;
+  constexpr uint32_t kLoads = (kFindStage + kFindThreads - 1u) / kFindThreads;
+  if (sb + 4ull * kLoads * kFindThreads <= len) {  // all of it inside the stream: the loads go out together
+    struct __attribute__((packed)) U32 { uint32_t v; };
+    uint32_t v[kLoads];
+#pragma unroll
+    for (uint32_t k = 0; k < kLoads; k++) v[k] = reinterpret_cast<const U32*>(src + sb + 4ull * (tid + k * kFindThreads))->v;
+#pragma unroll
+    for (uint32_t k = 0; k < kLoads; k++)
+      if (tid + k * kFindThreads < kFindStage) s_buf[tid + k * kFindThreads] = v[k];
+  } else {
+    for (uint32_t i = tid; i < kFindStage; i += kFindThreads) {
+      const uint64_t b = sb + 4ull * i;
+      uint32_t v = 0;
+      for (uint32_t k = 0; k < 4; k++)
+        if (b + k < len) v |= (uint32_t)src[b + k] << (8u * k);
+      s_buf[i] = v;
+    }
+  }
+  if (tid == 0) s_ncand = 0;
+  __syncthreads();
+  KPROF_MARK(0);
+  const uint32_t rel0 = (uint32_t)(base - sb * 8);  // < 32
+  const uint64_t left = hi - base;  // positions of this batch inside the search range
+  for (uint32_t part = 0; part < kFindBatch / (kFindThreads * 64u); part++) {
+    // The header's first 13 bits, 64 positions at once: BFINAL = 0 (the last block is left to the
+    // decoder before it), BTYPE = 2 (bits 1-2 = 0, 1), HLIT < 30 (not all of bits 4-7 set),
+    // HDIST < 30 (not all of bits 9-12 set).
+    const uint32_t mine = (part * kFindThreads + tid) * 64u;
+    if (mine >= left) break;
+    const uint32_t r = rel0 + mine, bi = r >> 5;
+    const uint32_t d0 = s_buf[bi], d1 = s_buf[bi + 1u], d2 = s_buf[bi + 2u], d3 = s_buf[bi + 3u];
+    const uint32_t e0 = zh_alignbit(d1, d0, r), e1 = zh_alignbit(d2, d1, r), e2 = zh_alignbit(d3, d2, r);
+    auto x = [&](uint32_t k) -> uint64_t {  // bit j = stream bit r + j + k
+      return (uint64_t)zh_alignbit(e1, e0, k) | ((uint64_t)zh_alignbit(e2, e1, k) << 32);
+    };
+    uint64_t m = ~x(0) & ~x(1) & x(2) & ~(x(4) & x(5) & x(6) & x(7)) & ~(x(9) & x(10) & x(11) & x(12));
+    if (left - mine < 64u) m &= (1ull << (left - mine)) - 1ull;
+    KPROF_MARK(1);
+    while (m) {
+      const uint32_t j = (uint32_t)__ffsll((long long)m) - 1u;
+      m &= m - 1ull;
+      const uint32_t off = mine + j;
+      KPROF_COUNT(5, 1);
+      if (seg_precode_complete(s_buf, rel0 + off)) {
+        KPROF_COUNT(6, 1);
+        const uint32_t at = atomicAdd(&s_ncand, 1u);
+        if (at < kFindSlots) s_cand[at] = off;  // (a full queue drops candidates: a later block start will do)
       }
     }
-    __syncthreads();
-    const uint32_t best = s_best;
-    if (best != 0xffffffffu) {
-      if (tid == 0) g.start_bit[sid] = base + best;
-      return;
-    }
-    __syncthreads();
+    KPROF_MARK(2);
   }
-  if (tid == 0) g.start_bit[sid] = kSegNone;
+  __syncthreads();
+  // the survivors go to this workgroup's slots of the queue (one position in 4 500 of random bits:
+  // fifteen a batch)
+  const uint32_t nc = s_ncand < kFindSlots ? s_ncand : kFindSlots;
+  if (tid < nc) g.cand_off[(size_t)blockIdx.x * kFindSlots + tid] = s_cand[tid];
+  if (tid == 0) g.cand_n[blockIdx.x] = nc;
+  KPROF_FLUSH(56, 8);
 }
 
-// One thread per stream: does the chain of segments hold?
+// A thread per slot of the queue: the code lengths; the segment keeps its lowest position that passes.
+__global__ __launch_bounds__(kFindSlots) void zh_seg_check_kernel(const uint8_t* __restrict__ d_src, ZhInflateArgs a,
+                                                                  ZhSegArgs g) {
+  const uint32_t w = blockIdx.x, i = threadIdx.x;
+  if (i >= g.cand_n[w]) return;
+  const uint32_t sid = g.find_seg[w];
+  const uint64_t p = g.nominal_bit[sid] + (uint64_t)g.find_batch[w] * kFindBatch + g.cand_off[(size_t)w * kFindSlots + i];
+  const uint32_t bid = g.parent[sid];
+  const ZhBufDesc bd = a.bufs[bid];
+  const uint64_t len = a.src_len_dev ? a.src_len_dev[bid] : bd.src_len;
+  if (p >= *(volatile uint64_t*)&g.start_bit[sid]) return;  // (a lower position has passed already)
+  if (seg_lengths_ok(d_src + bd.src_off, len, p)) atomicMin((unsigned long long*)&g.start_bit[sid], (unsigned long long)p);
+}
+
+// One wave per stream: the chain of segments.  It starts with the stream's first segment; the next
+// link is the segment whose found start is exactly where the decoder of the last one stopped (it
+// stops nowhere else, unless the stream ends or fails); found starts in between were wrong guesses.
 __global__ __launch_bounds__(64) void zh_seg_chain_kernel(ZhInflateArgs a, ZhSegArgs g) {
-  const uint32_t bid = blockIdx.x * 64u + threadIdx.x;
-  if (bid >= g.nstreams) return;
+  const uint32_t bid = blockIdx.x;
+  const unsigned lane = zh_lane();
   const uint32_t first = g.first_seg[bid], last = g.first_seg[bid + 1u];
-  for (uint32_t k = first; k < last; k++) g.valid[k] = 0;
-  bool ok = a.status[bid] == ZH_OK && g.start_bit[first] != kSegNone;
+  bool ok = a.status[bid] == ZH_OK;
+  bool done = false;
   uint64_t total = 0;
-  if (ok) {
-    uint32_t cur = first, before = 0xffffffffu;
+  uint32_t nchain = 0, before = 0xffffffffu, c = first;
+  auto shfl64 = [&](uint64_t v, uint32_t l) -> uint64_t {
+    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)l, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, (int)l, 64);
+  };
+  // a chunk of 64 segments in registers
+  uint64_t start = kSegNone, endb = 0, outb = 0;
+  int32_t sst = 0;
+  uint32_t fin = 0;
+  auto load_chunk = [&]() {
+    const uint32_t k = c + lane;
+    start = k < last ? g.start_bit[k] : kSegNone;
+    const bool found = start != kSegNone;
+    sst = found ? g.seg_status[k] : 0;
+    fin = found ? g.final_block[k] : 0u;
+    endb = found ? g.end_bit[k] : 0ull;
+    outb = found ? g.seg_out[k] : 0ull;
+    if (k < last) g.valid[k] = 0;
+  };
+  if (ok) load_chunk();
+  uint64_t want = ok ? shfl64(start, 0) : kSegNone;  // (the first segment's start is exact)
+  ok = ok && want != kSegNone;
+  while (ok && !done) {
+    const bool found = start != kSegNone;
+    const uint64_t E = __ballot(found && start == want);
+    if (!E) {
+      // not in this chunk: behind it, unless a found start lies past the wanted position already
+      if (__ballot(found && start > want) || c + 64u >= last) {
+        ok = false;
+        break;
+      }
+      c += 64u;
+      load_chunk();
+      continue;
+    }
+    // every lane's link inside the chunk: the lane whose start is where this lane's decoder stopped
+    // (starts grow with the lane, so there is at most one)
+    uint32_t nxt = 64u;
+    for (int d = 1; d < 64; d++) {
+      const uint64_t s2 = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(start >> 32), d, 64) << 32) |
+                          (uint32_t)__shfl_down((int)(uint32_t)start, d, 64);
+      if (found && lane + (unsigned)d < 64u && s2 == endb && s2 != kSegNone) nxt = lane + (unsigned)d;
+    }
+    const uint64_t BAD = __ballot(found && sst != ZH_OK), FIN = __ballot(found && fin != 0u);
+    // the walk through the chunk: wave-uniform, one v_readlane per link
+    uint32_t j = (uint32_t)__ffsll((long long)E) - 1u, jl = j;
+    uint64_t ON = 0;
     for (;;) {
-      if (g.seg_status[cur] != ZH_OK) {
+      ON |= 1ull << j;
+      jl = j;
+      if ((BAD >> j) & 1ull) {
         ok = false;
         break;
       }
-      g.valid[cur] = 1;
-      g.prev[cur] = before;
-      g.out_start[cur] = total;
-      total += g.seg_out[cur];
-      before = cur;
-      if (g.final_block[cur]) break;
-      uint32_t t = cur + 1u;
-      while (t < last && g.start_bit[t] == kSegNone) t++;
-      if (t == last || g.end_bit[cur] != g.start_bit[t]) {  // the guess behind `cur` was wrong
-        ok = false;
+      if ((FIN >> j) & 1ull) {
+        done = true;
         break;
       }
-      cur = t;
+      const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)j);
+      if (nj >= 64u) break;
+      j = nj;
     }
-  }
-  if (ok && a.count_only) {  // a sizing pass: this is the answer
-    for (uint32_t k = first; k < last; k++) g.valid[k] = 0;
-  } else if (ok && total > a.bufs[bid].dst_cap) {
-    // more output than the slot holds: nothing is written (out_len 0 bytes of it are valid)
-    for (uint32_t k = first; k < last; k++) g.valid[k] = 0;
-    a.status[bid] = ZH_ERR_DST_TOO_SMALL;
-    total = 0;
-  }
-  if (!ok)
-    for (uint32_t k = first; k < last; k++) g.valid[k] = 0;
-  g.stream_ok[bid] = ok ? 1u : 0u;
-  if (ok) a.out_len[bid] = total;
-#ifdef ZH_EMU
-  if (getenv("ZH_DBG_SEG")) {
-    uint32_t found = 0, onchain = 0;
-    for (uint32_t k = first; k < last; k++) {
-      found += g.start_bit[k] != kSegNone;
-      onchain += g.valid[k];
+    if (!ok) break;
+    const bool on = (ON >> lane) & 1ull;
+    const uint64_t below = ON & zh_lanemask_lt();
+    uint32_t slo = on ? (uint32_t)outb : 0u, shi = on ? (uint32_t)(outb >> 32) : 0u;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t tl = (uint32_t)__shfl_up((int)slo, o, 64), th = (uint32_t)__shfl_up((int)shi, o, 64);
+      if (lane >= (unsigned)o) {
+        const uint64_t sum = (((uint64_t)shi << 32) | slo) + (((uint64_t)th << 32) | tl);
+        slo = (uint32_t)sum;
+        shi = (uint32_t)(sum >> 32);
+      }
     }
-    fprintf(stderr, "stream %u: %u segments, %u starts found, %u on the chain, ok %d, %llu bytes\n", bid, last - first,
-            found, onchain, (int)ok, (unsigned long long)total);
-  }
-#endif
-}
-
-// One workgroup per stream: the 32 KiB of output that end each chain segment, as bytes.
-__global__ __launch_bounds__(1024) void zh_seg_windows_kernel(ZhInflateArgs a, ZhSegArgs g) {
-  __shared__ uint8_t s_win[2][kWin];
-  const uint32_t bid = blockIdx.x, tid = threadIdx.x;
-  if (!g.stream_ok[bid] || a.status[bid] != ZH_OK) return;
-  const uint32_t first = g.first_seg[bid], last = g.first_seg[bid + 1u];
-  const uint16_t* sym = g.sym + g.sym_base[bid];
-  uint32_t par = 0;
-  bool have_prev = false;
-  int st = ZH_OK;
-  uint64_t fail_len = 0;
-  for (uint32_t k = first; k < last; k++) {
-    if (!g.valid[k]) continue;
-    if (g.seg_status[k] != ZH_OK) {  // the writer refused a copy (inflate.nim:224-225)
-      st = g.seg_status[k];
-      fail_len = g.out_start[k] + g.wr_len[k];
+    const uint64_t incl = ((uint64_t)shi << 32) | slo;
+    if (on) {
+      const uint32_t k = c + lane, ord = nchain + (uint32_t)__popcll(below);
+      g.valid[k] = 1;
+      g.prev[k] = below ? c + 63u - (uint32_t)__clzll((long long)below) : before;
+      g.out_start[k] = total + incl - outb;
+      g.order[first + ord] = k;
+      g.ordinal[k] = ord;
+    }
+    nchain += (uint32_t)__popcll(ON);
+    total += shfl64(incl, 63);
+    before = c + jl;
+    want = shfl64(endb, jl);
+    if (done) break;
+    if (c + 64u >= last) {  // (the chain leaves the last chunk without having met the last block)
+      ok = false;
       break;
     }
-    const uint64_t start = g.out_start[k], n = g.seg_out[k];
-    const uint8_t* pw = s_win[par];
-    uint8_t* nw = s_win[par ^ 1u];
-    uint8_t* gw = g.windows + (size_t)k * kWin;
-    for (uint32_t j = tid; j < kWin; j += 1024u) {
-      // window byte j is output byte start + n - 32768 + j
-      uint32_t v = 0;
-      if (n + j >= kWin) {  // inside this segment
-        const uint32_t s = sym[start + n + j - kWin];
-        v = s & 0x8000u ? (have_prev ? pw[s & 0x7fffu] : 0u) : s;
-      } else if (have_prev) {
-        v = pw[j + n];
-      }
-      nw[j] = (uint8_t)v;
-      gw[j] = (uint8_t)v;
-    }
-    __syncthreads();
-    par ^= 1u;
-    have_prev = true;
+    c += 64u;
+    load_chunk();
   }
-  if (tid == 0 && st != ZH_OK) {
-    a.status[bid] = st;
-    a.out_len[bid] = fail_len;
+  ok = ok && done;
+  bool write = ok;
+  if (ok && a.count_only) {  // a sizing pass: `total` is the answer
+    write = false;
+  } else if (ok && total > a.bufs[bid].dst_cap) {
+    // more output than the slot holds: nothing is written (0 bytes of the slot are valid)
+    write = false;
+    total = 0;
+    if (lane == 0) a.status[bid] = ZH_ERR_DST_TOO_SMALL;
+  }
+  if (!write)
+    for (uint32_t k = first + lane; k < last; k += 64u) g.valid[k] = 0;
+  else
+    for (uint32_t k = c + 64u + lane; k < last; k += 64u) g.valid[k] = 0;
+  if (lane == 0) {
+    g.stream_ok[bid] = ok ? 1u : 0u;
+    g.nchain[bid] = write ? nchain : 0u;
+    if (ok) a.out_len[bid] = total;
+#ifdef ZH_EMU
+    if (getenv("ZH_DBG_SEG"))
+      fprintf(stderr, "stream %u: %u segments, %u on the chain, ok %d, written %d, %llu bytes\n", bid, last - first,
+              nchain, (int)ok, (int)write, (unsigned long long)total);
+    if (getenv("ZH_DBG_SEG") && atoi(getenv("ZH_DBG_SEG")) > 1 && !ok)
+      for (uint32_t k = first; k < last; k++)
+        fprintf(stderr, "  seg %u: nominal %llu start %lld end %llu status %d final %u out %llu\n", k - first,
+                (unsigned long long)g.nominal_bit[k], (long long)g.start_bit[k], (unsigned long long)g.end_bit[k],
+                g.seg_status[k], g.final_block[k], (unsigned long long)g.seg_out[k]);
+#endif
   }
 }
 
-// Symbols -> bytes; `parts` workgroups share a segment.
+// The windows.  What a chain segment's last 32 KiB are, given the 32 KiB before the segment, is a
+// map (g.winsym: a byte, or "byte k of the window before"), and maps compose: the chain is cut into
+// groups of kWinGroup segments,
+//   zh_seg_windows_group_kernel  a workgroup per group composes its segments' maps in order, so that
+//                                each refers to the window before the GROUP (in place, window in LDS);
+//   zh_seg_windows_chain_kernel  a workgroup per stream turns the maps of the groups' last segments
+//                                into bytes, group by group (g.windows of those segments);
+// and a byte of any segment's window is at most two look-ups away (zh_seg_finish_kernel).  The
+// serial depth is kWinGroup + groups steps of 32 KiB instead of one step per segment.
+constexpr uint32_t kWinGroup = 32, kWinMaxGroups = 4096 / kWinGroup;
+
+__global__ __launch_bounds__(1024) void zh_seg_windows_group_kernel(ZhInflateArgs a, ZhSegArgs g) {
+  __shared__ uint16_t s_win[kWin];
+  const uint32_t bid = blockIdx.x / kWinMaxGroups, grp = blockIdx.x % kWinMaxGroups, tid = threadIdx.x;
+  if (!g.stream_ok[bid] || a.status[bid] != ZH_OK) return;
+  const uint32_t n = g.nchain[bid], first = g.first_seg[bid];
+  const uint32_t c0 = grp * kWinGroup, c1 = c0 + kWinGroup < n ? c0 + kWinGroup : n;
+  if (c0 >= n) return;
+  constexpr uint32_t kPer = kWin / 2u / 1024u;  // dwords (symbol pairs) per thread: 16
+  auto load = [&](uint32_t k, uint32_t* w) {
+    const uint32_t* ws = reinterpret_cast<const uint32_t*>(g.winsym + (size_t)k * kWin);
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; i++) w[i] = ws[tid + 1024u * i];
+  };
+  uint32_t cur[kPer], nxt[kPer];
+  uint32_t k = g.order[first + c0], kn = c0 + 1u < c1 ? g.order[first + c0 + 1u] : k;
+  load(k, cur);
+  for (uint32_t c = c0; c < c1; c++) {
+    const uint32_t knn = c + 2u < c1 ? g.order[first + c + 2u] : kn;  // (two ahead: its address is there in time)
+    if (c + 1u < c1) load(kn, nxt);
+    const bool head = c == c0;
+    uint32_t v[kPer];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; i++) {
+      uint32_t s0 = cur[i] & 0xffffu, s1 = cur[i] >> 16;
+      if (head) {
+        if (c == 0) {  // nothing lies before the stream (a copy from there has been refused already)
+          s0 &= s0 & 0x8000u ? 0u : 0xffu;
+          s1 &= s1 & 0x8000u ? 0u : 0xffu;
+        }
+      } else {
+        if (s0 & 0x8000u) s0 = s_win[s0 & 0x7fffu];
+        if (s1 & 0x8000u) s1 = s_win[s1 & 0x7fffu];
+      }
+      v[i] = s0 | (s1 << 16);
+    }
+    __syncthreads();  // (everybody has read the window before it changes)
+    uint32_t* gw = reinterpret_cast<uint32_t*>(g.winsym + (size_t)k * kWin);
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; i++) {
+      const uint32_t j = tid + 1024u * i;  // pair index
+      reinterpret_cast<uint32_t*>(s_win)[j] = v[i];
+      if (!head || c == 0) gw[j] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; i++) cur[i] = nxt[i];
+    k = kn;
+    kn = knn;
+  }
+}
+
+__global__ __launch_bounds__(1024) void zh_seg_windows_chain_kernel(ZhInflateArgs a, ZhSegArgs g) {
+  __shared__ uint8_t s_win[kWin];
+  __shared__ uint32_t s_failed;
+  const uint32_t bid = blockIdx.x, tid = threadIdx.x;
+  if (!g.stream_ok[bid] || a.status[bid] != ZH_OK) return;
+  const uint32_t n = g.nchain[bid], first = g.first_seg[bid];
+  // a writer that refused a copy (inflate.nim:224-225) fails the stream where it stopped
+  if (tid == 0) s_failed = 0xffffffffu;
+  __syncthreads();
+  for (uint32_t c = tid; c < n; c += 1024u)
+    if (g.seg_status[g.order[first + c]] != ZH_OK) atomicMin(&s_failed, c);
+  __syncthreads();
+  if (s_failed != 0xffffffffu) {
+    if (tid == 0) {
+      const uint32_t k = g.order[first + s_failed];
+      a.status[bid] = g.seg_status[k];
+      a.out_len[bid] = g.out_start[k] + g.wr_len[k];
+    }
+    return;
+  }
+  const uint32_t groups = (n + kWinGroup - 1u) / kWinGroup;
+  constexpr uint32_t kPer = kWin / 2u / 1024u;
+  auto last_of = [&](uint32_t grp) -> uint32_t {
+    const uint32_t c = (grp + 1u) * kWinGroup < n ? (grp + 1u) * kWinGroup : n;
+    return g.order[first + c - 1u];
+  };
+  auto load = [&](uint32_t k, uint32_t* w) {
+    const uint32_t* ws = reinterpret_cast<const uint32_t*>(g.winsym + (size_t)k * kWin);
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; i++) w[i] = ws[tid + 1024u * i];
+  };
+  uint32_t cur[kPer], nxt[kPer];
+  uint32_t k = groups ? last_of(0) : 0u, kn = groups > 1u ? last_of(1) : k;
+  if (groups) load(k, cur);
+  for (uint32_t grp = 0; grp < groups; grp++) {
+    const uint32_t knn = grp + 2u < groups ? last_of(grp + 2u) : kn;
+    if (grp + 1u < groups) load(kn, nxt);
+    uint16_t v[kPer];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; i++) {
+      const uint32_t s0 = cur[i] & 0xffffu, s1 = cur[i] >> 16;
+      uint32_t v0 = s0 & 0xffu, v1 = s1 & 0xffu;
+      if (s0 & 0x8000u) v0 = grp ? s_win[s0 & 0x7fffu] : 0u;
+      if (s1 & 0x8000u) v1 = grp ? s_win[s1 & 0x7fffu] : 0u;
+      v[i] = (uint16_t)(v0 | (v1 << 8));
+    }
+    __syncthreads();
+    uint16_t* gw = reinterpret_cast<uint16_t*>(g.windows + (size_t)k * kWin);
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; i++) {
+      const uint32_t j = tid + 1024u * i;
+      reinterpret_cast<uint16_t*>(s_win)[j] = v[i];
+      gw[j] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; i++) cur[i] = nxt[i];
+    k = kn;
+    kn = knn;
+  }
+}
+
+// Symbols -> bytes; `parts` workgroups share a segment.  A marker is byte k of the window before the
+// segment: the map of the chain segment before it (relative to its group), then the byte window
+// that ends the group before that one.
 __global__ __launch_bounds__(256) void zh_seg_finish_kernel(uint8_t* __restrict__ d_dst, ZhInflateArgs a, ZhSegArgs g,
                                                             uint32_t parts) {
   const uint32_t k = blockIdx.x / parts, part = blockIdx.x % parts;
   if (!g.valid[k]) return;
   const uint32_t bid = g.parent[k];
+  if (a.status[bid] != ZH_OK) return;
   const uint64_t start = g.out_start[k], n = g.wr_len[k];
   const uint16_t* sym = g.sym + g.sym_base[bid] + start;
   uint8_t* dst = d_dst + a.bufs[bid].dst_off + start;
   const uint32_t pk = g.prev[k];
-  const uint8_t* pw = pk == 0xffffffffu ? nullptr : g.windows + (size_t)pk * kWin;
+  const uint16_t* pmap = nullptr;
+  const uint8_t* pwin = nullptr;
+  if (pk != 0xffffffffu) {
+    pmap = g.winsym + (size_t)pk * kWin;
+    const uint32_t grp = g.ordinal[pk] / kWinGroup;
+    if (grp) pwin = g.windows + (size_t)g.order[g.first_seg[bid] + grp * kWinGroup - 1u] * kWin;
+  }
   for (uint64_t i = (uint64_t)part * 256u + threadIdx.x; i < n; i += (uint64_t)parts * 256u) {
-    const uint32_t s = sym[i];
-    dst[i] = (uint8_t)(s & 0x8000u ? (pw ? pw[s & 0x7fffu] : 0u) : s);
+    uint32_t s = sym[i];
+    if (s & 0x8000u) {
+      s = pmap ? pmap[s & 0x7fffu] : 0u;
+      if (s & 0x8000u) s = pwin ? pwin[s & 0x7fffu] : 0u;
+    }
+    dst[i] = (uint8_t)s;
   }
 }
 
 extern "C" void zh_launch_seg_find(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g) {
-  if (!g.nsegs) return;
-  hipLaunchKernelGGL(zh_seg_find_kernel, dim3(g.nsegs), dim3(kFindThreads), 0, stream, d_src, a, g);
+  if (!g.nsegs || !g.nfind) return;
+  hipLaunchKernelGGL(zh_seg_find_kernel, dim3(g.nfind), dim3(kFindThreads), 0, stream, d_src, a, g);
+}
+extern "C" void zh_launch_seg_check(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g) {
+  if (!g.nsegs || !g.nfind) return;
+  hipLaunchKernelGGL(zh_seg_check_kernel, dim3(g.nfind), dim3(kFindSlots), 0, stream, d_src, a, g);
 }
 extern "C" void zh_launch_seg_chain(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g) {
   if (!g.nstreams) return;
-  hipLaunchKernelGGL(zh_seg_chain_kernel, dim3((g.nstreams + 63u) / 64u), dim3(64), 0, stream, a, g);
+  hipLaunchKernelGGL(zh_seg_chain_kernel, dim3(g.nstreams), dim3(64), 0, stream, a, g);
 }
 extern "C" void zh_launch_seg_windows(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g) {
   if (!g.nstreams) return;
-  hipLaunchKernelGGL(zh_seg_windows_kernel, dim3(g.nstreams), dim3(1024), 0, stream, a, g);
+  hipLaunchKernelGGL(zh_seg_windows_group_kernel, dim3(g.nstreams * kWinMaxGroups), dim3(1024), 0, stream, a, g);
+  hipLaunchKernelGGL(zh_seg_windows_chain_kernel, dim3(g.nstreams), dim3(1024), 0, stream, a, g);
 }
 extern "C" void zh_launch_seg_finish(hipStream_t stream, uint8_t* d_dst, ZhInflateArgs a, ZhSegArgs g) {
   if (!g.nsegs) return;

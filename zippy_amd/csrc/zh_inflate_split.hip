@@ -109,17 +109,15 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
   const uint32_t bid = kSeg ? g.parent[sid] : sid;   // the stream
   if (a.status[bid] != ZH_OK) return;  // unwrap already failed this stream
   if (!kSeg && a.skip && a.skip[sid]) return;  // decoded segment-wise
-  uint64_t seg_start = 0, seg_target = kSegNone;
+  // segment mode: the next found start at or behind the decoder's position.  It stops only where it
+  // lands on one EXACTLY; a start it runs past was a wrong guess (bits inside a stored block that read
+  // like a header -- a compressed file inside an archive is full of them) and is ignored.
+  uint64_t seg_start = 0, seg_target = 0;
+  uint32_t seg_tj = sid, seg_last = 0;
   if (kSeg) {
     seg_start = g.start_bit[sid];
     if (seg_start == kSegNone) return;  // no block starts in this segment: the one before carries on through it
-    for (uint32_t j = sid + 1u, last = g.first_seg[bid + 1u]; j < last; j++) {
-      const uint64_t sj = g.start_bit[j];
-      if (sj != kSegNone) {
-        seg_target = sj;
-        break;
-      }
-    }
+    seg_last = g.first_seg[bid + 1u];
   }
 
   const ZhBufDesc bd = a.bufs[bid];
@@ -235,7 +233,20 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
   };
 
   while (!final_block && st == ZH_OK) {  // inflate.nim:273-289
-    if (kSeg && pos - (uint64_t)mis * 8 >= seg_target) break;  // the next segment's decoder takes over
+    if (kSeg) {
+      const uint64_t rel = pos - (uint64_t)mis * 8;
+      // (segments without a found start are stepped over; kSegNone is behind every position)
+      while (seg_tj == sid || (seg_tj < seg_last && (seg_target == kSegNone || seg_target < rel))) {
+        seg_tj++;
+        seg_target = seg_tj < seg_last ? g.start_bit[seg_tj] : kSegNone;
+      }
+#ifdef ZH_EMU
+      if (tid == 0 && getenv("ZH_DBG_BLOCKS") && atoi(getenv("ZH_DBG_BLOCKS")) > 1)
+        fprintf(stderr, "  region %u at %llu: next start %llu (segment %u), %llu tokens of %llu\n", sid, (unsigned long long)rel,
+                (unsigned long long)seg_target, seg_tj, (unsigned long long)ntok, (unsigned long long)cap);
+#endif
+      if (seg_target == rel) break;  // that segment's decoder takes over
+    }
     // ---- block header: staged, then read by wave 0 like the serial kernel does ----
     const uint64_t hbase = pos >> 5;  // dword of the header's first bit
     KPROF_MARK(4);
@@ -892,6 +903,15 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
     op += total;
     ti += n;
     output_visible();
+  }
+  if (kSeg && st == ZH_OK) {
+    // the 32 KiB that end the segment, for zh_seg_windows_kernel: symbols of this segment, or --
+    // the segment being shorter -- "byte k of the window before it"
+    uint16_t* ws = g.winsym + (size_t)sid * 32768u;
+    for (uint32_t j = tid; j < 32768u; j += kWrThreads) {
+      const int64_t at = (int64_t)op + j - 32768;
+      ws[j] = (uint16_t)(at >= 0 ? ld_out(at) : 0x8000u | (uint32_t)(j + op));
+    }
   }
   if (tid == 0) {
     if (kSeg) {
