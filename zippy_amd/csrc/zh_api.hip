@@ -80,7 +80,89 @@ struct zh_ctx {
   bool pin_busy[2] = {false, false};
   hipStream_t copy_stream = nullptr;  // transfers of a pipelined batch, next to `stream`'s kernels
   uint64_t pipe_min = 0, pipe_group = 0;  // zh_set_host_pipeline (0: ZH_PIPE_MIN / ZH_PIPE_GROUP / default)
+  // device memory the context has freed, kept for its next call (ctx_malloc / ctx_free)
+  struct DevBlock {
+    void* p;
+    size_t size;
+    bool used;
+    uint64_t stamp;
+  };
+  std::vector<DevBlock> dev_blocks;
+  size_t dev_cached = 0, dev_cache_max = 0;
+  uint64_t dev_stamp = 0;
+  bool dev_poison = false;
 };
+
+// Device allocations of a context.  hipMalloc / hipFree cost a call of one small buffer more than
+// its kernels (hipFree also waits for the device), so freed blocks are kept -- up to ZH_DEV_CACHE_MB
+// (default 2048; 0: none), blocks of up to half of that -- and handed out again to requests they fit
+// without wasting more than half.  Everything a context does is ordered on its stream, so a block
+// may be reused as soon as it has been given back.  ZH_DEV_CACHE_POISON=1 fills every block handed
+// out (test aid: nothing may rely on fresh memory being zero).
+static hipError_t ctx_malloc(zh_ctx* ctx, void** out, size_t bytes) {
+  const size_t want = bytes < 4096 ? 4096 : bytes;
+  int best = -1;
+  for (size_t i = 0; i < ctx->dev_blocks.size(); i++) {
+    const zh_ctx::DevBlock& b = ctx->dev_blocks[i];
+    if (b.used || b.size < want || b.size > 2 * want + (1u << 20)) continue;
+    if (best < 0 || b.size < ctx->dev_blocks[best].size) best = (int)i;
+  }
+  hipError_t e = hipSuccess;
+  if (best >= 0) {
+    ctx->dev_blocks[best].used = true;
+    ctx->dev_cached -= ctx->dev_blocks[best].size;
+    *out = ctx->dev_blocks[best].p;
+  } else {
+    size_t alloc = want;
+    if (want <= (1u << 20)) {
+      alloc = 4096;
+      while (alloc < want) alloc <<= 1;
+    } else {
+      alloc = (want + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    }
+    e = hipMalloc(out, alloc);
+    if (e != hipSuccess) {  // give the kept blocks back and try once more
+      (void)hipGetLastError();
+      for (size_t i = ctx->dev_blocks.size(); i-- > 0;)
+        if (!ctx->dev_blocks[i].used) {
+          (void)hipFree(ctx->dev_blocks[i].p);
+          ctx->dev_cached -= ctx->dev_blocks[i].size;
+          ctx->dev_blocks.erase(ctx->dev_blocks.begin() + i);
+        }
+      e = hipMalloc(out, alloc);
+    }
+    if (e != hipSuccess) return e;
+    ctx->dev_blocks.push_back({*out, alloc, true, 0});
+  }
+  if (ctx->dev_poison) (void)hipMemsetAsync(*out, 0xa5, bytes, ctx->stream);
+  return hipSuccess;
+}
+static void ctx_free(zh_ctx* ctx, void* p) {
+  if (!p) return;
+  for (size_t i = 0; i < ctx->dev_blocks.size(); i++) {
+    zh_ctx::DevBlock& b = ctx->dev_blocks[i];
+    if (b.p != p) continue;
+    if (b.size > ctx->dev_cache_max / 2) {
+      (void)hipFree(p);
+      ctx->dev_blocks.erase(ctx->dev_blocks.begin() + i);
+      return;
+    }
+    b.used = false;
+    b.stamp = ++ctx->dev_stamp;
+    ctx->dev_cached += b.size;
+    while (ctx->dev_cached > ctx->dev_cache_max) {  // the longest unused goes first
+      int old = -1;
+      for (size_t k = 0; k < ctx->dev_blocks.size(); k++)
+        if (!ctx->dev_blocks[k].used && (old < 0 || ctx->dev_blocks[k].stamp < ctx->dev_blocks[old].stamp)) old = (int)k;
+      if (old < 0) break;
+      (void)hipFree(ctx->dev_blocks[old].p);
+      ctx->dev_cached -= ctx->dev_blocks[old].size;
+      ctx->dev_blocks.erase(ctx->dev_blocks.begin() + old);
+    }
+    return;
+  }
+  (void)hipFree(p);  // (not ours)
+}
 
 #define ZH_HIP(ctx, call)                                                            \
   do {                                                                               \
@@ -155,6 +237,11 @@ extern "C" int zh_create(int device, void* stream, zh_ctx** out) {
     }
     c->own_stream = true;
   }
+  {
+    const char* e = getenv("ZH_DEV_CACHE_MB");
+    c->dev_cache_max = (size_t)(e ? strtoull(e, nullptr, 10) : 2048) << 20;
+    c->dev_poison = getenv("ZH_DEV_CACHE_POISON") != nullptr;
+  }
   c->cktabs = zh_checksum_tables(device);
   if (!c->cktabs) {
     delete c;
@@ -170,6 +257,7 @@ extern "C" void zh_destroy(zh_ctx* ctx) {
     if (ctx->pin_ev[k]) (void)hipEventDestroy(ctx->pin_ev[k]);
     if (ctx->pin[k]) (void)hipHostFree(ctx->pin[k]);
   }
+  for (auto& b : ctx->dev_blocks) (void)hipFree(b.p);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -311,13 +399,13 @@ extern "C" void zh_plan_destroy(zh_plan* p) {
   if (!p) return;
   // (nothing useful can be done about a failure while tearing down)
   (void)hipStreamSynchronize(p->ctx->stream);
-  if (p->arena) (void)hipFree(p->arena);
-  if (p->seg_arena) (void)hipFree(p->seg_arena);
-  if (p->tok_pool) (void)hipFree(p->tok_pool);
-  if (p->sg_arena) (void)hipFree(p->sg_arena);
-  if (p->sg_sym) (void)hipFree(p->sg_sym);
-  if (p->sg_windows) (void)hipFree(p->sg_windows);
-  if (p->sg_winsym) (void)hipFree(p->sg_winsym);
+  if (p->arena) ctx_free(p->ctx, p->arena);
+  if (p->seg_arena) ctx_free(p->ctx, p->seg_arena);
+  if (p->tok_pool) ctx_free(p->ctx, p->tok_pool);
+  if (p->sg_arena) ctx_free(p->ctx, p->sg_arena);
+  if (p->sg_sym) ctx_free(p->ctx, p->sg_sym);
+  if (p->sg_windows) ctx_free(p->ctx, p->sg_windows);
+  if (p->sg_winsym) ctx_free(p->ctx, p->sg_winsym);
   for (auto e : p->k_events) (void)hipEventDestroy(e);
   delete p;
 }
@@ -435,7 +523,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   const size_t o_cbest = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 4 : 0);
   ar.reserve(256);
 
-  if (hipMalloc(&p->arena, ar.size) != hipSuccess) {
+  if (ctx_malloc(p->ctx, (void**)&p->arena, ar.size) != hipSuccess) {
     ctx->last_error = "hipMalloc(plan arena, " + std::to_string(ar.size) + " bytes)";
     delete p;
     return ZH_ERR_NOMEM;
@@ -623,12 +711,12 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
                o_final = ar.reserve(ns * 4), o_sst = ar.reserve(ns * 4), o_sout = ar.reserve(ns * 8),
                o_wlen = ar.reserve(ns * 8), o_valid = ar.reserve(ns * 4), o_prev = ar.reserve(ns * 4),
                o_ostart = ar.reserve(ns * 8), o_sok = ar.reserve(n * 4), o_order = ar.reserve(ns * 4),
-               o_nchain = ar.reserve(n * 4), o_ordinal = ar.reserve(ns * 4);
+               o_nchain = ar.reserve(n * 4), o_ordinal = ar.reserve(ns * 4), o_go = ar.reserve(n * 4);
   const size_t nfind = find_seg.size();
   const size_t o_fseg = ar.reserve(nfind * 4), o_fbatch = ar.reserve(nfind * 4), o_cn = ar.reserve(nfind * 4),
                o_coff = ar.reserve(nfind * 64 * 4);
   ar.reserve(256);
-  if (hipMalloc(&p->sg_arena, ar.size) != hipSuccess) {
+  if (ctx_malloc(p->ctx, (void**)&p->sg_arena, ar.size) != hipSuccess) {
     (void)hipGetLastError();
     p->sg_arena = nullptr;
     return;
@@ -651,7 +739,7 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   if (up == hipSuccess) up = hipStreamSynchronize(s);
   if (up != hipSuccess) {
     (void)hipGetLastError();
-    (void)hipFree(p->sg_arena);
+    ctx_free(p->ctx, p->sg_arena);
     p->sg_arena = nullptr;
     return;
   }
@@ -678,6 +766,7 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   g.order = carve<uint32_t>(base, o_order);
   g.nchain = carve<uint32_t>(base, o_nchain);
   g.ordinal = carve<uint32_t>(base, o_ordinal);
+  g.go = carve<uint32_t>(base, o_go);
   g.nfind = (uint32_t)nfind;
   g.find_seg = carve<uint32_t>(base, o_fseg);
   g.find_batch = carve<uint32_t>(base, o_fbatch);
@@ -722,7 +811,7 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
                o_olen = ar.reserve(n * 8), o_st = ar.reserve(n * 4);
   const size_t o_toff = ar.reserve(n * 8), o_tcap = ar.reserve(n * 8);
   ar.reserve(256);
-  if (hipMalloc(&p->arena, ar.size) != hipSuccess) {
+  if (ctx_malloc(p->ctx, (void**)&p->arena, ar.size) != hipSuccess) {
     ctx->last_error = "hipMalloc(plan arena)";
     delete p;
     return ZH_ERR_NOMEM;
@@ -814,7 +903,7 @@ extern "C" int zh_plan_uncompress_indexed(zh_ctx* ctx, uint64_t src_off, uint64_
   const size_t o_bufs = ar.reserve(nseg * sizeof(ZhBufDesc)), o_start = ar.reserve(nseg * 8),
                o_olen = ar.reserve(nseg * 8), o_st = ar.reserve(nseg * 4);
   ar.reserve(256);
-  if (hipMalloc(&p->seg_arena, ar.size) != hipSuccess) {
+  if (ctx_malloc(p->ctx, (void**)&p->seg_arena, ar.size) != hipSuccess) {
     zh_plan_destroy(p);
     return ZH_ERR_NOMEM;
   }
@@ -867,19 +956,19 @@ extern "C" void zh_set_inflate_mode(zh_ctx* ctx, int mode) {
 static bool plan_token_pool(zh_plan* p) {
   if (p->tok_pool) return true;
   if (p->tok_failed || !p->tok_words) return false;
-  if (hipMalloc(&p->tok_pool, p->tok_words * 4) != hipSuccess) {
+  if (ctx_malloc(p->ctx, (void**)&p->tok_pool, p->tok_words * 4) != hipSuccess) {
     (void)hipGetLastError();
     p->tok_pool = nullptr;
     p->tok_failed = true;
     return false;
   }
   if (p->segmented) {  // without its buffers the plan simply is not segmented
-    if (hipMalloc(&p->sg_sym, p->sg_sym_count * 2) != hipSuccess ||
-        hipMalloc(&p->sg_windows, (size_t)p->sg.nsegs * 32768u) != hipSuccess ||
-        hipMalloc(&p->sg_winsym, (size_t)p->sg.nsegs * 65536u) != hipSuccess) {
+    if (ctx_malloc(p->ctx, (void**)&p->sg_sym, p->sg_sym_count * 2) != hipSuccess ||
+        ctx_malloc(p->ctx, (void**)&p->sg_windows, (size_t)p->sg.nsegs * 32768u) != hipSuccess ||
+        ctx_malloc(p->ctx, (void**)&p->sg_winsym, (size_t)p->sg.nsegs * 65536u) != hipSuccess) {
       (void)hipGetLastError();
-      if (p->sg_sym) (void)hipFree(p->sg_sym);
-      if (p->sg_windows) (void)hipFree(p->sg_windows);
+      if (p->sg_sym) ctx_free(p->ctx, p->sg_sym);
+      if (p->sg_windows) ctx_free(p->ctx, p->sg_windows);
       p->sg_sym = nullptr;
       p->sg_windows = nullptr;
       p->sg_winsym = nullptr;
@@ -1064,10 +1153,15 @@ extern "C" const int32_t* zh_plan_device_statuses(zh_plan* p) { return p ? p->st
 namespace {
 struct DevBuf {
   uint8_t* p = nullptr;
+  zh_ctx* ctx = nullptr;
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p) ctx_free(ctx, p);
   }
 };
+hipError_t dev_alloc(zh_ctx* ctx, DevBuf& b, size_t bytes) {
+  b.ctx = ctx;
+  return ctx_malloc(ctx, (void**)&b.p, bytes);
+}
 struct PlanGuard {
   zh_plan* p = nullptr;
   ~PlanGuard() { zh_plan_destroy(p); }
@@ -1276,7 +1370,7 @@ int upload_slices(zh_ctx* ctx, hipStream_t stream, const void* const* srcs,
 int upload(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n, DevBuf& dev,
            std::vector<uint64_t>& off, std::vector<uint64_t>& len64) {
   const uint64_t total = layout_slices(lens, n, off, len64);
-  if (hipMalloc(&dev.p, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
+  if (dev_alloc(ctx, dev, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
   return upload_slices(ctx, ctx->stream, srcs, off, len64, total, dev.p);
 }
 
@@ -1340,11 +1434,11 @@ int download_pack(zh_ctx* ctx, hipStream_t stream, Download& dl, const uint8_t* 
   }
   if (!total) return ZH_OK;
   if (!pack) {
-    if (hipMalloc(&dl.own_pack.p, total) != hipSuccess) return ZH_ERR_NOMEM;
+    if (dev_alloc(ctx, dl.own_pack, total) != hipSuccess) return ZH_ERR_NOMEM;
     pack = dl.own_pack.p;
   }
   dl.pack = pack;
-  if (hipMalloc(&dl.d_pieces.p, pieces.size() * sizeof(PackPiece)) != hipSuccess) return ZH_ERR_NOMEM;
+  if (dev_alloc(ctx, dl.d_pieces, pieces.size() * sizeof(PackPiece)) != hipSuccess) return ZH_ERR_NOMEM;
   ZH_HIP(ctx, hipMemcpyAsync(dl.d_pieces.p, pieces.data(), pieces.size() * sizeof(PackPiece),
                              hipMemcpyHostToDevice, stream));
   const PackPiece* const dev_pieces = reinterpret_cast<const PackPiece*>(dl.d_pieces.p);
@@ -1459,9 +1553,9 @@ int compress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, const size_t*
       q.dcap[i] = typical_cap(lens[q.i0 + i], data_format);
       q.dst_total += (q.dcap[i] + 255) & ~(uint64_t)255;
     }
-    if (hipMalloc(&q.d_src.p, q.src_total + 256) != hipSuccess ||
-        hipMalloc(&q.d_dst.p, q.dst_total + 256) != hipSuccess ||
-        hipMalloc(&q.d_pack.p, q.dst_total + 256) != hipSuccess) {
+    if (dev_alloc(ctx, q.d_src, q.src_total + 256) != hipSuccess ||
+        dev_alloc(ctx, q.d_dst, q.dst_total + 256) != hipSuccess ||
+        dev_alloc(ctx, q.d_pack, q.dst_total + 256) != hipSuccess) {
       (void)hipGetLastError();
       return kPipeFallback;
     }
@@ -1568,7 +1662,7 @@ static int compress_batch_impl(zh_ctx* ctx, const void* const* srcs, const size_
       total += (dcap[i] + 255) & ~(uint64_t)255;
     }
     DevBuf d_dst;
-    if (hipMalloc(&d_dst.p, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
+    if (dev_alloc(ctx, d_dst, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
     PlanGuard pg;
     st = zh_plan_compress(ctx, n, soff.data(), slen.data(), doff.data(), dcap.data(), level,
                           data_format, &pg.p);
@@ -1664,9 +1758,9 @@ static int uncompress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, cons
       q.dcap[i] = cap[q.i0 + i];
       q.dst_total += (q.dcap[i] + 255) & ~(uint64_t)255;
     }
-    if (hipMalloc(&q.d_src.p, q.src_total + 256) != hipSuccess ||
-        hipMalloc(&q.d_dst.p, q.dst_total + 256) != hipSuccess ||
-        hipMalloc(&q.d_pack.p, q.dst_total + 256) != hipSuccess) {
+    if (dev_alloc(ctx, q.d_src, q.src_total + 256) != hipSuccess ||
+        dev_alloc(ctx, q.d_dst, q.dst_total + 256) != hipSuccess ||
+        dev_alloc(ctx, q.d_pack, q.dst_total + 256) != hipSuccess) {
       (void)hipGetLastError();
       return kPipeFallback;
     }
@@ -1804,7 +1898,7 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
       total += (dcap[i] + 255) & ~(uint64_t)255;
     }
     DevBuf d_dst;
-    if (hipMalloc(&d_dst.p, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
+    if (dev_alloc(ctx, d_dst, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
     PlanGuard pg;
     st = zh_plan_uncompress(ctx, n, soff.data(), slen_now.data(), doff.data(), dcap.data(), data_format, &pg.p);
     if (st) return st;
@@ -1965,7 +2059,7 @@ extern "C" int zh_compress_blocks(zh_ctx* ctx, const void* src, size_t len, int 
     uint64_t dcap = (attempt == 0 ? typical_cap(len, data_format) : zh_compress_bound(len, data_format)) +
                     1024 * nblocks;
     DevBuf d_dst;
-    if (hipMalloc(&d_dst.p, dcap + 256) != hipSuccess) return ZH_ERR_NOMEM;
+    if (dev_alloc(ctx, d_dst, dcap + 256) != hipSuccess) return ZH_ERR_NOMEM;
     PlanGuard pg;
     st = zh_plan_compress_blocks(ctx, 1, soff.data(), slen.data(), &doff, &dcap, level, data_format,
                                  block_bytes, &pg.p);
@@ -2013,7 +2107,7 @@ extern "C" int zh_uncompress_indexed(zh_ctx* ctx, const void* src, size_t len, i
   const uint64_t total = index[n_entries - 1].out_off;
   if (total > (uint64_t)len * 1032 + 64) return ZH_ERR_INVALID_BUFFER;  // deflate cannot expand further
   DevBuf d_dst;
-  if (hipMalloc(&d_dst.p, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
+  if (dev_alloc(ctx, d_dst, total + 256) != hipSuccess) return ZH_ERR_NOMEM;
   PlanGuard pg;
   st = zh_plan_uncompress_indexed(ctx, soff[0], slen[0], 0, total, data_format, index, n_entries, &pg.p);
   if (st) return st == ZH_ERR_ARGUMENT ? ZH_ERR_INVALID_BUFFER : st;
@@ -2067,7 +2161,7 @@ static int checksum_host(zh_ctx* ctx, const void* const* srcs, const size_t* len
                o_oc = ar.reserve(n * 4), o_oa = ar.reserve(n * 4);
   ar.reserve(256);
   DevBuf scratch;
-  if (hipMalloc(&scratch.p, ar.size) != hipSuccess) return ZH_ERR_NOMEM;
+  if (dev_alloc(ctx, scratch, ar.size) != hipSuccess) return ZH_ERR_NOMEM;
   uint8_t* base = scratch.p;
   hipStream_t s = ctx->stream;
   ZH_HIP(ctx, hipMemcpyAsync(base + o_b, bufs.data(), n * sizeof(ZhBufDesc), hipMemcpyHostToDevice, s));

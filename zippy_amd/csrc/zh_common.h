@@ -133,6 +133,7 @@ struct ZhSegArgs {
   const uint32_t* find_batch;   // [nfind]
   uint32_t* cand_n;             // [nfind] positions of the batch that passed the cheap tests ...
   uint32_t* cand_off;           // [nfind][64] ... as offsets into the batch
+  uint32_t* go;                 // [nstreams] enough segments of the stream have a start: decode it segment-wise
   // find / tokens results
   uint64_t* start_bit;          // [nsegs] first bit of the segment's first block, or kSegNone
   uint64_t* end_bit;            // [nsegs] the block boundary the tokens kernel stopped at

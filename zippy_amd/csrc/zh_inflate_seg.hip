@@ -16,26 +16,29 @@
 //                          symbol, a usable distance code.  The lowest position of a segment that
 //                          passes is the segment's start: almost certainly a block start, but only
 //                          a GUESS;
-//   tokens (segment form)  decode from the found start to the first block boundary at or behind the
-//                          next found start, all segments at once;
-//   zh_seg_chain_kernel    the proof: walking the stream's segments in order, every decoder must
-//                          have stopped exactly where the next one started (the first one starts
-//                          at the stream's first block, which is exact, so by induction every start
-//                          on the chain then is a real block start and the concatenated tokens are
-//                          the serial decoder's).  Prefix-sums the output bytes.  Anything else --
-//                          a wrong guess, an error in a chain segment, a token region that
-//                          overflowed, more output than the slot holds -- clears the stream's flag
-//                          and the ordinary one-workgroup kernels decode it (they are launched
-//                          right behind and return at once for flagged streams);
+//   tokens (segment form)  all segments at once, each from its found start.  A decoder stops at the
+//                          first block boundary that IS a found start (or at the end of the stream):
+//                          a found start it runs past was a wrong guess -- bits inside a stored block
+//                          that read like a header, which a compressed file inside an archive is
+//                          full of -- and is ignored;
+//   zh_seg_chain_kernel    the proof: the stream's first segment starts at the stream's first block,
+//                          which is exact; the next link is the segment whose found start is exactly
+//                          where the last link's decoder stopped, so by induction every start on
+//                          the chain is a real block start and the concatenated tokens are the serial
+//                          decoder's.  Prefix-sums the output bytes.  Anything else -- an error in a
+//                          chain segment, a token region that overflowed, a chain that does not
+//                          reach the last block -- clears the stream's flag and the ordinary
+//                          one-workgroup kernels decode it (they are launched right behind and return
+//                          at once for flagged streams).  A chain that needs more room than the slot
+//                          has is ZH_ERR_DST_TOO_SMALL at once; a sizing pass ends here;
 //   writer (segment form)  every chain segment's bytes as 16-bit symbols: a copy that reaches into
 //                          the 32 KiB before the segment yields "window byte k" instead of a value;
-//   zh_seg_windows_kernel  chain segments in order, one workgroup per stream: the last 32 KiB at
-//                          the end of a segment, resolved through the window before it (LDS);
+//   zh_seg_windows_*       what those windows are: see the kernels;
 //   zh_seg_finish_kernel   symbols -> bytes in the caller's slot, all segments at once.
 //
 // Accept/reject, status and bytes are those of the ordinary kernels (same decoder, same checks; the
-// tests run both against the oracle).  Extra traffic: 4 bytes per token and 2 + 2 bytes per output
-// byte for the symbols.
+// tests run both against the oracle, damaged streams included).  Extra traffic: 4 bytes per token
+// and 2 + 2 bytes per output byte for the symbols.
 #include <cstdlib>
 
 #include "zh_common.h"
@@ -314,6 +317,20 @@ __global__ __launch_bounds__(kFindSlots) void zh_seg_check_kernel(const uint8_t*
   if (seg_lengths_ok(d_src + bd.src_off, len, p)) atomicMin((unsigned long long*)&g.start_bit[sid], (unsigned long long)p);
 }
 
+// One wave per stream: is it worth it?  A stream in which fewer than a quarter of the segments got
+// a start (one huge block, fixed-code blocks: this library's own streams of up to 4 MiB are a single
+// block) would be decoded by a few workgroups running far past their token regions: it goes to
+// the ordinary kernels right away.
+__global__ __launch_bounds__(64) void zh_seg_decide_kernel(ZhInflateArgs a, ZhSegArgs g) {
+  const uint32_t bid = blockIdx.x;
+  const unsigned lane = zh_lane();
+  const uint32_t first = g.first_seg[bid], last = g.first_seg[bid + 1u];
+  uint32_t found = 0;
+  for (uint32_t k = first + lane; k < last; k += 64u) found += g.start_bit[k] != kSegNone;
+  found = zh_wave_sum(found);
+  if (lane == 0) g.go[bid] = a.status[bid] == ZH_OK && found * 4u >= last - first ? 1u : 0u;
+}
+
 // One wave per stream: the chain of segments.  It starts with the stream's first segment; the next
 // link is the segment whose found start is exactly where the decoder of the last one stopped (it
 // stops nowhere else, unless the stream ends or fails); found starts in between were wrong guesses.
@@ -321,7 +338,7 @@ __global__ __launch_bounds__(64) void zh_seg_chain_kernel(ZhInflateArgs a, ZhSeg
   const uint32_t bid = blockIdx.x;
   const unsigned lane = zh_lane();
   const uint32_t first = g.first_seg[bid], last = g.first_seg[bid + 1u];
-  bool ok = a.status[bid] == ZH_OK;
+  bool ok = a.status[bid] == ZH_OK && g.go[bid] != 0u;
   bool done = false;
   uint64_t total = 0;
   uint32_t nchain = 0, before = 0xffffffffu, c = first;
@@ -610,6 +627,7 @@ extern "C" void zh_launch_seg_find(hipStream_t stream, const uint8_t* d_src, ZhI
 extern "C" void zh_launch_seg_check(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g) {
   if (!g.nsegs || !g.nfind) return;
   hipLaunchKernelGGL(zh_seg_check_kernel, dim3(g.nfind), dim3(kFindSlots), 0, stream, d_src, a, g);
+  hipLaunchKernelGGL(zh_seg_decide_kernel, dim3(g.nstreams), dim3(64), 0, stream, a, g);
 }
 extern "C" void zh_launch_seg_chain(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g) {
   if (!g.nstreams) return;

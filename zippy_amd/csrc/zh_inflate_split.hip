@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
   uint64_t seg_start = 0, seg_target = 0;
   uint32_t seg_tj = sid, seg_last = 0;
   if (kSeg) {
+    if (!g.go[bid]) return;  // too few starts were found: the stream is left to the ordinary kernels
     seg_start = g.start_bit[sid];
     if (seg_start == kSegNone) return;  // no block starts in this segment: the one before carries on through it
     seg_last = g.first_seg[bid + 1u];
