@@ -318,3 +318,11 @@ def test_gpu_segmented_streams(eng, monkeypatch):
     """Large streams on many workgroups (zh_inflate_seg.hip), small segments and the default ones."""
     pc.check_segmented(eng, 1024, monkeypatch, 2048)
     pc.check_segmented(eng, 32 * 1024, monkeypatch, 65536)
+    # blocks far longer than a segment: this library's own six-block stream (4 MiB of input a block)
+    monkeypatch.delenv("ZH_SEG_MIN")
+    monkeypatch.delenv("ZH_SEG_BYTES")
+    big = synth.gen_batch("mix", 1, 23 << 20, first_index=11)[0].tobytes()
+    comp, sts = eng.compress_batch([big], 1, oracle.dfGzip)
+    assert sts == [0]
+    outs, sts = eng.uncompress_batch(comp, oracle.dfGzip)
+    assert sts == [0] and outs[0] == big

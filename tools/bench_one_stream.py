@@ -25,6 +25,8 @@ def main():
     cases = []
     data = synth.gen_batch("mix", args.mib, 1 << 20).tobytes()
     cases.append(("zlib6_%dMiB" % args.mib, zlib.compress(data, 6), data, api.dfZlib))
+    own, sts = eng.compress_batch([data], 1, api.dfGzip)
+    cases.append(("own_level1_%dMiB" % args.mib, own[0], data, api.dfGzip))
     tgz = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "tarballs",
                        "libressl-3.4.2.tar.gz")
     if os.path.exists(tgz):

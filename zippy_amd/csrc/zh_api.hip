@@ -711,7 +711,7 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
                o_final = ar.reserve(ns * 4), o_sst = ar.reserve(ns * 4), o_sout = ar.reserve(ns * 8),
                o_wlen = ar.reserve(ns * 8), o_valid = ar.reserve(ns * 4), o_prev = ar.reserve(ns * 4),
                o_ostart = ar.reserve(ns * 8), o_sok = ar.reserve(n * 4), o_order = ar.reserve(ns * 4),
-               o_nchain = ar.reserve(n * 4), o_ordinal = ar.reserve(ns * 4), o_go = ar.reserve(n * 4);
+               o_nchain = ar.reserve(n * 4), o_ordinal = ar.reserve(ns * 4), o_go = ar.reserve(n * 4), o_etoff = ar.reserve(ns * 8), o_etcap = ar.reserve(ns * 8);
   const size_t nfind = find_seg.size();
   const size_t o_fseg = ar.reserve(nfind * 4), o_fbatch = ar.reserve(nfind * 4), o_cn = ar.reserve(nfind * 4),
                o_coff = ar.reserve(nfind * 64 * 4);
@@ -767,6 +767,8 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   g.nchain = carve<uint32_t>(base, o_nchain);
   g.ordinal = carve<uint32_t>(base, o_ordinal);
   g.go = carve<uint32_t>(base, o_go);
+  g.eff_tok_off = carve<uint64_t>(base, o_etoff);
+  g.eff_tok_cap = carve<uint64_t>(base, o_etcap);
   g.nfind = (uint32_t)nfind;
   g.find_seg = carve<uint32_t>(base, o_fseg);
   g.find_batch = carve<uint32_t>(base, o_fbatch);

@@ -134,6 +134,8 @@ struct ZhSegArgs {
   uint32_t* cand_n;             // [nfind] positions of the batch that passed the cheap tests ...
   uint32_t* cand_off;           // [nfind][64] ... as offsets into the batch
   uint32_t* go;                 // [nstreams] enough segments of the stream have a start: decode it segment-wise
+  uint64_t* eff_tok_off;        // [nsegs] token region of a segment that keeps its decoder (zh_seg_decide_kernel:
+  uint64_t* eff_tok_cap;        //   its own, or those of its whole group of segments)
   // find / tokens results
   uint64_t* start_bit;          // [nsegs] first bit of the segment's first block, or kSegNone
   uint64_t* end_bit;            // [nsegs] the block boundary the tokens kernel stopped at

@@ -317,18 +317,42 @@ __global__ __launch_bounds__(kFindSlots) void zh_seg_check_kernel(const uint8_t*
   if (seg_lengths_ok(d_src + bd.src_off, len, p)) atomicMin((unsigned long long*)&g.start_bit[sid], (unsigned long long)p);
 }
 
-// One wave per stream: is it worth it?  A stream in which fewer than a quarter of the segments got
-// a start (one huge block, fixed-code blocks: this library's own streams of up to 4 MiB are a single
-// block) would be decoded by a few workgroups running far past their token regions: it goes to
-// the ordinary kernels right away.
+// One wave per stream: is it worth it, and with how many decoders?  Fewer than four found starts
+// (one huge block, fixed-code blocks: this library's own streams of up to 4 MiB are a single block)
+// send the stream to the ordinary kernels right away.  Where starts are rare -- blocks much longer
+// than a segment -- the segments are taken in groups of f (a power of two, about half the spacing of
+// the starts): only a group's first found start keeps its decoder, and that decoder gets the token
+// regions of the whole group, which lie back to back -- so that a region holds the tokens of a
+// block or two whatever the block size.
 __global__ __launch_bounds__(64) void zh_seg_decide_kernel(ZhInflateArgs a, ZhSegArgs g) {
   const uint32_t bid = blockIdx.x;
   const unsigned lane = zh_lane();
-  const uint32_t first = g.first_seg[bid], last = g.first_seg[bid + 1u];
+  const uint32_t first = g.first_seg[bid], last = g.first_seg[bid + 1u], n = last - first;
   uint32_t found = 0;
   for (uint32_t k = first + lane; k < last; k += 64u) found += g.start_bit[k] != kSegNone;
   found = zh_wave_sum(found);
-  if (lane == 0) g.go[bid] = a.status[bid] == ZH_OK && found * 4u >= last - first ? 1u : 0u;
+  const bool go = a.status[bid] == ZH_OK && found >= 4u;
+  // (half the spacing of the starts: a region then takes three tokens per compressed byte of the
+  // stretch its decoder covers, and no decoder is given up while starts are merely not everywhere)
+  uint32_t f = 1;
+  while (go && f * found * 2u < n) f <<= 1;
+  // lane l takes groups l, l + 64, ...
+  for (uint32_t grp = lane; go && grp * f < n; grp += 64u) {
+    const uint32_t k0 = first + grp * f, k1 = k0 + f < last ? k0 + f : last;
+    const uint64_t base = g.tok_off[k0], room = g.tok_off[k1 - 1u] + g.tok_cap[k1 - 1u] - base;
+    bool taken = false;
+    for (uint32_t k = k0; k < k1; k++) {
+      if (g.start_bit[k] == kSegNone) continue;
+      if (taken) {
+        g.start_bit[k] = kSegNone;
+        continue;
+      }
+      taken = true;
+      g.eff_tok_off[k] = base;
+      g.eff_tok_cap[k] = room;
+    }
+  }
+  if (lane == 0) g.go[bid] = go ? 1u : 0u;
 }
 
 // One wave per stream: the chain of segments.  It starts with the stream's first segment; the next

@@ -133,8 +133,8 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
     if (off + 4 > end) v &= (1u << (8 * (uint32_t)(end - off))) - 1u;
     return v;
   };
-  uint32_t* const tok = tok_pool + (kSeg ? g.tok_off[sid] : tok_off[sid]);
-  const uint64_t cap = kSeg ? g.tok_cap[sid] : tok_cap[sid];  // records this stream may write (the end record included)
+  uint32_t* const tok = tok_pool + (kSeg ? g.eff_tok_off[sid] : tok_off[sid]);
+  const uint64_t cap = kSeg ? g.eff_tok_cap[sid] : tok_cap[sid];  // records this stream may write (the end record included)
   __shared__ uint32_t s_wbytes[kWaves];
 
   // stream position in bits (from asrc)
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
   const uint64_t gbase = kSeg ? g.out_start[sid] : 0;  // output bytes of the stream before this workgroup's
   Sym* dst = kSeg ? reinterpret_cast<Sym*>(g.sym + g.sym_base[bid] + gbase) : reinterpret_cast<Sym*>(d_dst + bd.dst_off);
   const uint64_t cap = bd.dst_cap - gbase;
-  const uint32_t* tok = tok_pool + (kSeg ? g.tok_off[sid] : tok_off[sid]);
+  const uint32_t* tok = tok_pool + (kSeg ? g.eff_tok_off[sid] : tok_off[sid]);
 
   uint64_t op = 0;  // bytes produced (the same in every thread)
   int st = ZH_OK;
