@@ -44,6 +44,8 @@ def main():
     eng.lib.zh_kprof_read(slots, 0)
     print("kernel ms:", {k: round(v, 3) for k, v in plan.kernel_times() if v > 0.01})
     show("zh_seg_find_kernel", FIND, list(slots[56:64]))
+    show("zh_seg_check_kernel", ["set-up", "candidates", "#-", "#candidates", "#passed", "#waves", "#--", "#---"],
+         list(slots[16:24]))
 
 
 if __name__ == "__main__":

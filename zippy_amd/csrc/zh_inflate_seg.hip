@@ -40,6 +40,7 @@
 // tests run both against the oracle, damaged streams included).  Extra traffic: 4 bytes per token
 // and 2 + 2 bytes per output byte for the symbols.
 #include <cstdlib>
+#include <cstring>
 
 #include "zh_common.h"
 #include "zh_kprof.h"
@@ -303,18 +304,159 @@ __global__ __launch_bounds__(kFindThreads) void zh_seg_find_kernel(const uint8_t
   KPROF_FLUSH(56, 8);
 }
 
-// A thread per slot of the queue: the code lengths; the segment keeps its lowest position that passes.
+// where code-length symbol s sits in a header (the inverse of c_clcl_order)
+__constant__ uint8_t c_clcl_place[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};
+
+// The code lengths of a candidate header, by a whole wave (the serial form above, seg_lengths_ok,
+// is what it has to agree with: ZH_SEG_CHECK=serial runs that one).  The code-length code goes into
+// a 128-entry table in LDS; then the 64 lanes decode the symbols that start at 64 consecutive bit
+// positions, a wave-uniform walk (one v_readlane a symbol) picks the ones really in the sequence,
+// and repeat counts, "previous length" and the two codes' Kraft sums are prefix sums and reductions.
+// The header (at most 17 + 57 + 316 * 14 bits) is staged in LDS first: one trip to memory a candidate.
+constexpr uint32_t kHdrWords = 144;  // 4608 bits
+__device__ bool seg_lengths_ok_wave(const uint8_t* src, uint64_t len, uint64_t p, uint8_t* s_lut, uint32_t* s_hdr) {
+  const unsigned lane = zh_lane();
+  const uint64_t hb = p >> 3;  // first staged byte
+  zh_wave_sync();              // (the candidate before is done with the staged bytes)
+  for (uint32_t i = lane; i < kHdrWords + 2u; i += 64u) {
+    const uint64_t b = hb + 4ull * i;
+    uint32_t v = 0;
+    if (b + 4 <= len) {
+      struct __attribute__((packed)) U32 { uint32_t v; };
+      v = reinterpret_cast<const U32*>(src + b)->v;
+    } else {
+      for (uint32_t k = 0; k < 4; k++)
+        if (b + k < len) v |= (uint32_t)src[b + k] << (8 * k);
+    }
+    s_hdr[i] = v;
+  }
+  zh_wave_sync();
+  auto peek = [&](uint64_t at) -> uint32_t {  // the 32 bits at stream bit `at` (inside the staged header)
+    const uint32_t rel = (uint32_t)(at - hb * 8), i = rel >> 5;
+    return zh_alignbit(s_hdr[i + 1u], s_hdr[i], rel);
+  };
+  const uint32_t h = zh_bcast(peek(p));
+  const uint32_t hlit = ((h >> 3) & 31u) + 257u, hdist = ((h >> 8) & 31u) + 1u, hclen = ((h >> 13) & 15u) + 4u;
+  // lane s < 19: the length of code-length symbol s (its place in the header: the inverse of c_clcl_order)
+  const uint32_t place = lane < 19u ? c_clcl_place[lane] : 99u;
+  const uint32_t l = place < hclen ? peek(p + 17u + 3u * place) & 7u : 0u;
+  // canonical codes (inflate.nim:29-65): symbols of one length in symbol order
+  uint32_t code = 0, next = 0;
+#pragma unroll
+  for (uint32_t k = 1; k <= 7; k++) {
+    const uint64_t m = __ballot(l == k);
+    if (l == k) code = next + (uint32_t)__popcll(m & zh_lanemask_lt());
+    next = (next + (uint32_t)__popcll(m)) << 1;
+  }
+  zh_wave_sync();  // (the table of the candidate before has been read)
+  if (l) {
+    const uint32_t rev = __brev(code) >> (32u - l);  // the stream carries codes first bit first
+    for (uint32_t e = rev; e < 128u; e += 1u << l) s_lut[e] = (uint8_t)(lane | (l << 5));
+  }
+  zh_wave_sync();
+  uint64_t q = p + 17u + 3u * hclen;
+  const uint32_t total = hlit + hdist;
+  uint32_t i = 0, prev = 0, lit_kraft = 0, dist_kraft = 0, dist_used = 0;
+  bool eob = false;
+  while (i < total) {
+    // the symbol that starts at bit q + lane
+    const uint32_t w = peek(q + lane);
+    const uint32_t e = s_lut[w & 127u], sym = e & 31u, cl = e >> 5;
+    const uint32_t x = w >> cl;
+    uint32_t rep = 1, val = sym, nb = cl;
+    if (sym == 16u) {
+      rep = (x & 3u) + 3u;
+      nb += 2u;
+    } else if (sym == 17u) {
+      rep = (x & 7u) + 3u;
+      nb += 3u;
+      val = 0;
+    } else if (sym == 18u) {
+      rep = (x & 127u) + 11u;
+      nb += 7u;
+      val = 0;
+    }
+    // the walk: which of the 64 positions start a symbol of the sequence
+    uint64_t on = 0;
+    uint32_t pos = 0;
+    while (pos < 64u) {
+      on |= 1ull << pos;
+      pos += (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)pos);
+    }
+    bool mine = (on >> lane) & 1ull;
+    // entries before mine in this window; symbols past the end of the sequence do not count
+    const uint32_t incl = zh_wave_scan(mine ? rep : 0u);
+    const uint32_t at = i + incl - (mine ? rep : 0u);  // index of my first entry
+    if (mine && at >= total) mine = false;
+    const uint64_t ON = __ballot(mine);
+    if (__ballot(mine && at + rep > total)) return false;  // inflate.nim:161-162: runs past the end
+    // "previous length" for symbol 16: the nearest symbol before that is not a 16
+    const uint64_t plain = __ballot(mine && sym != 16u) & zh_lanemask_lt();
+    const uint32_t from = plain ? 63u - (uint32_t)__clzll((long long)plain) : 0u;
+    const uint32_t pv = (uint32_t)__shfl((int)val, (int)from, 64);
+    if (sym == 16u) val = plain ? pv : prev;
+    if (i == 0 && (ON & 1ull) && (uint32_t)__builtin_amdgcn_readlane((int)sym, 0) == 16u) return false;  // nothing to repeat
+    uint32_t lk = 0, dk = 0, du = 0;
+    bool eb = false;
+    if (mine && val) {
+      const uint32_t nl = at >= hlit ? 0u : (at + rep <= hlit ? rep : hlit - at), nd = rep - nl;
+      lk = nl * (32768u >> val);
+      dk = nd * (32768u >> val);
+      du = nd;
+      eb = at <= 256u && 256u < at + nl;
+    }
+    lit_kraft += zh_wave_sum(lk);
+    dist_kraft += zh_wave_sum(dk);
+    dist_used += zh_wave_sum(du);
+    eob = eob || __ballot(eb) != 0;
+    if (lit_kraft > 32768u || dist_kraft > 32768u) return false;
+    // behind the last symbol taken
+    const uint32_t lastl = 63u - (uint32_t)__clzll((long long)ON);  // (ON has bit 0: at = i < total)
+    i = (uint32_t)__builtin_amdgcn_readlane((int)(at + rep), (int)lastl);
+    prev = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)lastl);
+    q += lastl + (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)lastl);
+  }
+  if (q > len * 8) return false;
+  if (!eob || lit_kraft != 32768u) return false;
+  return dist_kraft == 32768u || dist_used <= 1u;
+}
+
+// A wave per batch of the search: its queued candidates, one after the other; the segment keeps its
+// lowest position that passes.
 __global__ __launch_bounds__(kFindSlots) void zh_seg_check_kernel(const uint8_t* __restrict__ d_src, ZhInflateArgs a,
-                                                                  ZhSegArgs g) {
-  const uint32_t w = blockIdx.x, i = threadIdx.x;
-  if (i >= g.cand_n[w]) return;
+                                                                  ZhSegArgs g, int serial) {
+  __shared__ uint8_t s_lut[128];
+  __shared__ uint32_t s_hdr[kHdrWords + 2];
+  const uint32_t w = blockIdx.x, lane = threadIdx.x;
+  const uint32_t nc = g.cand_n[w];
+  if (!nc) return;
   const uint32_t sid = g.find_seg[w];
-  const uint64_t p = g.nominal_bit[sid] + (uint64_t)g.find_batch[w] * kFindBatch + g.cand_off[(size_t)w * kFindSlots + i];
+  const uint64_t base = g.nominal_bit[sid] + (uint64_t)g.find_batch[w] * kFindBatch;
   const uint32_t bid = g.parent[sid];
   const ZhBufDesc bd = a.bufs[bid];
   const uint64_t len = a.src_len_dev ? a.src_len_dev[bid] : bd.src_len;
-  if (p >= *(volatile uint64_t*)&g.start_bit[sid]) return;  // (a lower position has passed already)
-  if (seg_lengths_ok(d_src + bd.src_off, len, p)) atomicMin((unsigned long long*)&g.start_bit[sid], (unsigned long long)p);
+  if (serial) {  // a thread per candidate
+    if (lane >= nc) return;
+    const uint64_t p = base + g.cand_off[(size_t)w * kFindSlots + lane];
+    if (p >= *(volatile uint64_t*)&g.start_bit[sid]) return;  // (a lower position has passed already)
+    if (seg_lengths_ok(d_src + bd.src_off, len, p)) atomicMin((unsigned long long*)&g.start_bit[sid], (unsigned long long)p);
+    return;
+  }
+  const uint32_t mine = lane < nc ? g.cand_off[(size_t)w * kFindSlots + lane] : 0u;
+  KPROF_DECL(8);  // cycles: 0 set-up, 1 candidates; counts: 3 candidates, 4 passed, 5 waves
+  KPROF_COUNT(5, 1);
+  KPROF_MARK(0);
+  for (uint32_t c = 0; c < nc; c++) {
+    const uint64_t p = base + (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)c);
+    if (p >= zh_bcast64(*(volatile uint64_t*)&g.start_bit[sid])) continue;  // (a lower position has passed already)
+    KPROF_COUNT(3, 1);
+    if (seg_lengths_ok_wave(d_src + bd.src_off, len, p, s_lut, s_hdr)) {
+      KPROF_COUNT(4, 1);
+      if (lane == 0) atomicMin((unsigned long long*)&g.start_bit[sid], (unsigned long long)p);
+    }
+  }
+  KPROF_MARK(1);
+  KPROF_FLUSH(16, 8);
 }
 
 // One wave per stream: is it worth it, and with how many decoders?  Fewer than four found starts
@@ -650,7 +792,11 @@ extern "C" void zh_launch_seg_find(hipStream_t stream, const uint8_t* d_src, ZhI
 }
 extern "C" void zh_launch_seg_check(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g) {
   if (!g.nsegs || !g.nfind) return;
-  hipLaunchKernelGGL(zh_seg_check_kernel, dim3(g.nfind), dim3(kFindSlots), 0, stream, d_src, a, g);
+  static const int serial = [] {
+    const char* e = getenv("ZH_SEG_CHECK");
+    return e && strcmp(e, "serial") == 0 ? 1 : 0;
+  }();
+  hipLaunchKernelGGL(zh_seg_check_kernel, dim3(g.nfind), dim3(kFindSlots), 0, stream, d_src, a, g, serial);
   hipLaunchKernelGGL(zh_seg_decide_kernel, dim3(g.nstreams), dim3(64), 0, stream, a, g);
 }
 extern "C" void zh_launch_seg_chain(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g) {
