@@ -3,7 +3,7 @@
 #   bash tools/prof/final_pass.sh r02_a
 # -> gpurun_out/<tag>_bench.json (BASELINE metric), _c2/_c3/_c3own/_c4/_c4share/_c5 .json (the other
 #    BASELINE configs), _kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same bench command),
-#    _pytest_gpu.log, _host_api.json, _single_call.json, hbm_traffic.json (two --pmc passes)
+#    _pytest_gpu.log, _host_api.json, _single_call.json, _one_stream.json, _fuzz_seg.log, hbm_traffic.json (two --pmc passes)
 R=$(pwd); T=${1:-r02}
 O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
@@ -25,6 +25,7 @@ timeout 300 python tools/bench_single_call.py 2>/dev/null | tail -1 > $O/${T}_si
 timeout 300 python bench.py --buffers 512 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_share512.json
 timeout 300 python tools/bench_host_api.py --reps 2 --buffers 4096 2>/dev/null | tail -1 > $O/${T}_host_api_4096.json
 timeout 600 python tools/bench_one_stream.py 2>/dev/null | tail -1 > $O/${T}_one_stream.json
+timeout 600 python tools/gpu_fuzz.py --seg-mutations 4000 2>/dev/null | tail -3 > $O/${T}_fuzz_seg.log
 cd /tmp
 rm -rf /tmp/kt /tmp/pf /tmp/pw
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${T}_rocprof_bench.log 2>&1
