@@ -609,10 +609,12 @@ def check_segmented(eng, scale, monkeypatch, seg_bytes):
         assert len(blob) >= 4 * seg_bytes, len(blob)
         outs, sts = eng.uncompress_batch([blob], fmt)
         assert sts == [0] and outs[0] == plain, (fmt, len(blob), sts)
-    # a batch of them at once (same format): zlib streams
+    # a batch of them at once (same format), small streams (no segments) in between: zlib streams
     zl = [c for c in cases if c[1] == oracle.dfZlib]
-    outs, sts = eng.uncompress_batch([c[0] for c in zl], oracle.dfZlib)
-    assert sts == [0] * len(zl) and all(o == c[2] for o, c in zip(outs, zl))
+    small = [(zlib.compress(c[2][:k], 6), c[1], c[2][:k]) for c, k in zip(zl, (0, 1, 3000))]
+    mixed = [x for pair in zip(zl, small) for x in pair]
+    outs, sts = eng.uncompress_batch([c[0] for c in mixed], oracle.dfZlib)
+    assert sts == [0] * len(mixed) and all(o == c[2] for o, c in zip(outs, mixed))
     # damage: the statuses are those of the ordinary decoder
     rng = random.Random(3)
     blob, fmt, plain = cases[1]

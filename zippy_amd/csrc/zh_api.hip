@@ -644,13 +644,13 @@ extern "C" int zh_plan_block_index(zh_plan* p, size_t buf, zh_block_entry** inde
   return ZH_OK;
 }
 
-// Large streams are decoded segment-wise (zh_inflate_seg.hip) when a batch is a handful of them:
+// Large streams are decoded segment-wise (zh_inflate_seg.hip) in batches of up to 256 streams:
 // ZH_SEG=0 turns that off, ZH_SEG_MIN is the smallest stream (compressed bytes, default 128 KiB),
 // ZH_SEG_BYTES the segment length (default 32 KiB).
 struct SegConfig {
   bool on = true;
   uint64_t min_stream = 131072, seg_bytes = 32768;
-  size_t max_streams = 64;
+  size_t max_streams = 256;
 };
 static SegConfig seg_config() {  // (read per plan: the tests switch it)
   SegConfig v;
@@ -668,15 +668,19 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   zh_ctx* ctx = p->ctx;
   const size_t n = bufs.size();
   if (!c.on || !n || n > c.max_streams) return;
-  for (const ZhBufDesc& b : bufs)
-    if (b.src_len < c.min_stream || b.src_len < 2 * c.seg_bytes || b.src_len > (~0ull >> 4)) return;
+  // the large streams of the batch are cut into segments, the others have none (and take the
+  // ordinary kernels, like every stream whose chain of segments does not hold)
+  auto large = [&](const ZhBufDesc& b) {
+    return b.src_len >= c.min_stream && b.src_len >= 2 * c.seg_bytes && b.src_len <= (~0ull >> 4);
+  };
+  if (std::none_of(bufs.begin(), bufs.end(), large)) return;
   std::vector<uint32_t> parent, first_seg(n + 1), find_seg, find_batch;
   std::vector<uint64_t> nominal, search, toff, tcap, sym_base(n);
   uint64_t nsym = 0;
   for (size_t i = 0; i < n; i++) {
     const ZhBufDesc& b = bufs[i];
-    const uint64_t ns = std::min<uint64_t>(std::max<uint64_t>(b.src_len / c.seg_bytes, 2), 4096);
-    const uint64_t seg_bits = (b.src_len * 8 + ns - 1) / ns, seg_len = (seg_bits + 7) / 8;
+    const uint64_t ns = large(b) ? std::min<uint64_t>(std::max<uint64_t>(b.src_len / c.seg_bytes, 2), 4096) : 0;
+    const uint64_t seg_bits = ns ? (b.src_len * 8 + ns - 1) / ns : 0, seg_len = (seg_bits + 7) / 8;
     first_seg[i] = (uint32_t)parent.size();
     for (uint64_t k = 0; k < ns; k++) {
       for (uint64_t bt = 0; k && bt * 65536 < seg_bits; bt++) {  // (the first segment's start is known)
