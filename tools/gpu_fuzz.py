@@ -205,6 +205,35 @@ def seg_mutations(count, seed=20260927):
                     bad += 1
                     print("SEGMENT MUTATION MISMATCH fmt", fmt, len(blob), st)
     print("gpu_fuzz segment mutations: %d blobs accepted %d rejected %d bad %d" % (count, accepted, count - accepted, bad))
+    # noise and half-noise, default segment geometry: nothing may be accepted wrongly, nothing may hang
+    del os.environ["ZH_SEG_BYTES"], os.environ["ZH_SEG_MIN"]
+    big = zlib.compress(synth.gen_batch("mix", 1, 2 << 20, first_index=3)[0].tobytes(), 6)
+    noise = []
+    for k in range(48):
+        n = rnd.randrange(140000, 600000)
+        if k % 3 == 0:
+            blob = b"\x78\x9c" + rnd.randbytes(n)
+        elif k % 3 == 1:
+            cut = rnd.randrange(1000, len(big) - 1000)
+            blob = big[:cut] + rnd.randbytes(n)
+        else:
+            b = bytearray(big)
+            for _k in range(rnd.randrange(1, 200)):
+                b[rnd.randrange(2, len(b))] = rnd.randrange(256)
+            blob = bytes(b)
+        noise.append(blob)
+    for lo in range(0, len(noise), 8):
+        part = noise[lo:lo + 8]
+        outs, sts = eng.uncompress_batch(part, oracle.dfZlib)
+        for blob, o, st in zip(part, outs, sts):
+            try:
+                w = oracle.uncompress(blob, oracle.dfZlib)
+            except oracle.ZippyError:
+                w = None
+            if (st == 0) != (w is not None) or (st == 0 and o != w):
+                bad += 1
+                print("SEGMENT NOISE MISMATCH", len(blob), st)
+    print("gpu_fuzz segment noise: %d blobs, bad %d" % (len(noise), bad))
     return bad
 
 

@@ -376,6 +376,7 @@ __device__ bool seg_lengths_ok_wave(const uint8_t* src, uint64_t len, uint64_t p
       nb += 7u;
       val = 0;
     }
+    if (__ballot(cl == 0u)) return false;  // (cannot happen with a complete code: keeps the walk below moving whatever the bits)
     // the walk: which of the 64 positions start a symbol of the sequence
     uint64_t on = 0;
     uint32_t pos = 0;
