@@ -605,6 +605,14 @@ def check_segmented(eng, scale, monkeypatch, seg_bytes):
     monkeypatch.setenv("ZH_SEG_MIN", str(4 * seg_bytes))
     monkeypatch.setenv("ZH_SEG_BYTES", str(seg_bytes))
     cases = segmented_streams(scale)
+    # this library's own streams: ONE block (the last one) however long -- every decoder but the
+    # first starts inside it; raw deflate has no checksum to catch a wrong byte, only this comparison
+    own_src = [synth.gen_batch(kind, 1, 72 * scale, first_index=9)[0].tobytes() for kind in ("text", "mix")]
+    for fmt in (oracle.dfDeflate, oracle.dfZlib, oracle.dfGzip):
+        for level in (1, 6):
+            comp, sts = eng.compress_batch(own_src, level, fmt)
+            assert sts == [0, 0]
+            cases += [(c, fmt, p) for c, p in zip(comp, own_src) if len(c) >= 4 * seg_bytes]
     for blob, fmt, plain in cases:
         assert len(blob) >= 4 * seg_bytes, len(blob)
         outs, sts = eng.uncompress_batch([blob], fmt)

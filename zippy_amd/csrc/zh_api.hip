@@ -39,7 +39,8 @@ void zh_launch_inflate_write(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, 
 void zh_launch_segments_reduce(hipStream_t, ZhInflateArgs seg, ZhInflateArgs whole);
 void zh_launch_seg_find(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_seg_check(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g);
-void zh_launch_seg_tokens(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, uint32_t* tok_pool, ZhSegArgs g);
+void zh_launch_seg_tokens(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, uint32_t* tok_pool, ZhSegArgs g, int phase);
+void zh_launch_seg_decide(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_seg_chain(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_seg_write(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, const uint32_t* tok_pool, ZhSegArgs g);
 void zh_launch_seg_windows(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
@@ -649,7 +650,7 @@ extern "C" int zh_plan_block_index(zh_plan* p, size_t buf, zh_block_entry** inde
 // ZH_SEG_BYTES the segment length (default 32 KiB).
 struct SegConfig {
   bool on = true;
-  uint64_t min_stream = 131072, seg_bytes = 32768;
+  uint64_t min_stream = 131072, seg_bytes = 32768, tail_bytes = 4718592;
   size_t max_streams = 256;
 };
 static SegConfig seg_config() {  // (read per plan: the tests switch it)
@@ -657,6 +658,7 @@ static SegConfig seg_config() {  // (read per plan: the tests switch it)
   if (const char* e = getenv("ZH_SEG")) v.on = strcmp(e, "0") != 0;
   if (const char* e = getenv("ZH_SEG_MIN")) v.min_stream = strtoull(e, nullptr, 10);
   if (const char* e = getenv("ZH_SEG_BYTES")) v.seg_bytes = std::max<uint64_t>(64, strtoull(e, nullptr, 10));
+  if (const char* e = getenv("ZH_SEG_TAIL")) v.tail_bytes = strtoull(e, nullptr, 10);
   return v;
 }
 
@@ -685,7 +687,10 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
     for (uint64_t k = 0; k < ns; k++) {
       for (uint64_t bt = 0; k && bt * 65536 < seg_bits; bt++) {  // (the first segment's start is known)
         find_seg.push_back((uint32_t)parent.size());
-        find_batch.push_back((uint32_t)bt);
+        // the stream's last block (BFINAL = 1) is searched for in its last 4.5 MiB only -- this library's
+        // own last block is 4 MiB of input at most --: everywhere would double the candidates
+        const bool tail = (k * seg_bits + (bt + 1) * 65536) / 8 + c.tail_bytes >= b.src_len;
+        find_batch.push_back((uint32_t)bt | (tail ? 0x80000000u : 0u));
       }
       if (!k) {
         find_seg.push_back((uint32_t)parent.size());
@@ -715,7 +720,8 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
                o_final = ar.reserve(ns * 4), o_sst = ar.reserve(ns * 4), o_sout = ar.reserve(ns * 8),
                o_wlen = ar.reserve(ns * 8), o_valid = ar.reserve(ns * 4), o_prev = ar.reserve(ns * 4),
                o_ostart = ar.reserve(ns * 8), o_sok = ar.reserve(n * 4), o_order = ar.reserve(ns * 4),
-               o_nchain = ar.reserve(n * 4), o_ordinal = ar.reserve(ns * 4), o_go = ar.reserve(n * 4), o_etoff = ar.reserve(ns * 8), o_etcap = ar.reserve(ns * 8);
+               o_nchain = ar.reserve(n * 4), o_ordinal = ar.reserve(ns * 4), o_go = ar.reserve(n * 4), o_etoff = ar.reserve(ns * 8), o_etcap = ar.reserve(ns * 8), o_substart = ar.reserve(ns * 8), o_subhdr = ar.reserve(ns * 8),
+               o_issub = ar.reserve(ns * 4);
   const size_t nfind = find_seg.size();
   const size_t o_fseg = ar.reserve(nfind * 4), o_fbatch = ar.reserve(nfind * 4), o_cn = ar.reserve(nfind * 4),
                o_coff = ar.reserve(nfind * 64 * 4);
@@ -773,6 +779,9 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   g.go = carve<uint32_t>(base, o_go);
   g.eff_tok_off = carve<uint64_t>(base, o_etoff);
   g.eff_tok_cap = carve<uint64_t>(base, o_etcap);
+  g.sub_start = carve<uint64_t>(base, o_substart);
+  g.sub_hdr = carve<uint64_t>(base, o_subhdr);
+  g.is_sub = carve<uint32_t>(base, o_issub);
   g.nfind = (uint32_t)nfind;
   g.find_seg = carve<uint32_t>(base, o_fseg);
   g.find_batch = carve<uint32_t>(base, o_fbatch);
@@ -1079,8 +1088,11 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       zh_launch_seg_find(s, d_src, a, p->sg);
       prof_mark(p, "zh_seg_check_kernel");
       zh_launch_seg_check(s, d_src, a, p->sg);
+      prof_mark(p, "zh_seg_substart_kernel");
+      zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 0);
+      zh_launch_seg_decide(s, a, p->sg);
       prof_mark(p, "zh_seg_tokens_kernel");
-      zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg);
+      zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 1);
       prof_mark(p, "zh_seg_chain_kernel");
       zh_launch_seg_chain(s, a, p->sg);
       if (!a.count_only) {

@@ -130,12 +130,16 @@ struct ZhSegArgs {
   // the search for block starts: one workgroup per batch of 65536 bit positions of a segment
   uint32_t nfind;
   const uint32_t* find_seg;     // [nfind]
-  const uint32_t* find_batch;   // [nfind]
+  const uint32_t* find_batch;   // [nfind] (bit 31: the stream's last block may start in this batch: BFINAL = 1 counts too)
   uint32_t* cand_n;             // [nfind] positions of the batch that passed the cheap tests ...
   uint32_t* cand_off;           // [nfind][64] ... as offsets into the batch
   uint32_t* go;                 // [nstreams] enough segments of the stream have a start: decode it segment-wise
   uint64_t* eff_tok_off;        // [nsegs] token region of a segment that keeps its decoder (zh_seg_decide_kernel:
   uint64_t* eff_tok_cap;        //   its own, or those of its whole group of segments)
+  // sub-starts (zh_inflate_tokens_kernel phase 0, merged into start_bit by zh_seg_decide_kernel)
+  uint64_t* sub_start;          // [nsegs] a token boundary at or behind the segment's nominal first bit, or kSegNone
+  uint64_t* sub_hdr;            // [nsegs] first bit of the header of the block it lies in
+  uint32_t* is_sub;             // [nsegs] start_bit is such a boundary, not a block start
   // find / tokens results
   uint64_t* start_bit;          // [nsegs] first bit of the segment's first block, or kSegNone
   uint64_t* end_bit;            // [nsegs] the block boundary the tokens kernel stopped at

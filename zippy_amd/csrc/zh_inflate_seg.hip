@@ -8,7 +8,8 @@
 //   zh_seg_find_kernel     the compressed bytes are cut into segments of equal length, and every
 //   zh_seg_check_kernel    bit position is asked whether it reads as the header of a dynamic-
 //                          Huffman block (inflate.nim:115-171).  The find kernel takes the cheap
-//                          questions, a thread per 64 positions: BFINAL = 0, BTYPE = 2, HLIT and
+//                          questions, a thread per 64 positions: BFINAL = 0 (either value in the last
+//                          4.5 MiB of the stream, where its last block starts), BTYPE = 2, HLIT and
 //                          HDIST in range (all 64 at once, bitwise), then a complete code-length
 //                          code (one position in 4 500 of random bits survives: they are queued);
 //                          the check kernel, a thread per survivor, decodes the code lengths: exactly
@@ -225,7 +226,8 @@ __global__ __launch_bounds__(kFindThreads) void zh_seg_find_kernel(const uint8_t
                                                                    ZhSegArgs g) {
   __shared__ uint32_t s_buf[kFindStage];
   __shared__ uint32_t s_cand[kFindSlots], s_ncand;
-  const uint32_t sid = g.find_seg[blockIdx.x], batch = g.find_batch[blockIdx.x], tid = threadIdx.x;
+  const uint32_t sid = g.find_seg[blockIdx.x], batch = g.find_batch[blockIdx.x] & 0x7fffffffu, tid = threadIdx.x;
+  const bool tail = (g.find_batch[blockIdx.x] >> 31) != 0u;  // the stream's last block may start in this batch
   if (tid == 0) g.cand_n[blockIdx.x] = 0;
   const uint32_t bid = g.parent[sid];
   const bool first = sid == g.first_seg[bid];
@@ -268,8 +270,8 @@ __global__ __launch_bounds__(kFindThreads) void zh_seg_find_kernel(const uint8_t
   const uint32_t rel0 = (uint32_t)(base - sb * 8);  // < 32
   const uint64_t left = hi - base;  // positions of this batch inside the search range
   for (uint32_t part = 0; part < kFindBatch / (kFindThreads * 64u); part++) {
-    // The header's first 13 bits, 64 positions at once: BFINAL = 0 (the last block is left to the
-    // decoder before it), BTYPE = 2 (bits 1-2 = 0, 1), HLIT < 30 (not all of bits 4-7 set),
+    // The header's first 13 bits, 64 positions at once: BFINAL = 0 (unless the stream's last block
+    // may start here), BTYPE = 2 (bits 1-2 = 0, 1), HLIT < 30 (not all of bits 4-7 set),
     // HDIST < 30 (not all of bits 9-12 set).
     const uint32_t mine = (part * kFindThreads + tid) * 64u;
     if (mine >= left) break;
@@ -279,7 +281,8 @@ __global__ __launch_bounds__(kFindThreads) void zh_seg_find_kernel(const uint8_t
     auto x = [&](uint32_t k) -> uint64_t {  // bit j = stream bit r + j + k
       return (uint64_t)zh_alignbit(e1, e0, k) | ((uint64_t)zh_alignbit(e2, e1, k) << 32);
     };
-    uint64_t m = ~x(0) & ~x(1) & x(2) & ~(x(4) & x(5) & x(6) & x(7)) & ~(x(9) & x(10) & x(11) & x(12));
+    uint64_t m = ~x(1) & x(2) & ~(x(4) & x(5) & x(6) & x(7)) & ~(x(9) & x(10) & x(11) & x(12));
+    if (!tail) m &= ~x(0);  // BFINAL = 0, except near the end of the stream
     if (left - mine < 64u) m &= (1ull << (left - mine)) - 1ull;
     KPROF_MARK(1);
     while (m) {
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(kFindSlots) void zh_seg_check_kernel(const uint8_t*
   const uint32_t nc = g.cand_n[w];
   if (!nc) return;
   const uint32_t sid = g.find_seg[w];
-  const uint64_t base = g.nominal_bit[sid] + (uint64_t)g.find_batch[w] * kFindBatch;
+  const uint64_t base = g.nominal_bit[sid] + (uint64_t)(g.find_batch[w] & 0x7fffffffu) * kFindBatch;
   const uint32_t bid = g.parent[sid];
   const ZhBufDesc bd = a.bufs[bid];
   const uint64_t len = a.src_len_dev ? a.src_len_dev[bid] : bd.src_len;
@@ -471,9 +474,21 @@ __global__ __launch_bounds__(64) void zh_seg_decide_kernel(ZhInflateArgs a, ZhSe
   const uint32_t bid = blockIdx.x;
   const unsigned lane = zh_lane();
   const uint32_t first = g.first_seg[bid], last = g.first_seg[bid + 1u], n = last - first;
+  // segments inside long blocks take the sub-starts phase 0 of the tokens kernel guessed for them
   uint32_t found = 0;
-  for (uint32_t k = first + lane; k < last; k += 64u) found += g.start_bit[k] != kSegNone;
+  for (uint32_t k = first + lane; k < last; k += 64u) {
+    uint64_t sk = g.start_bit[k];
+    uint32_t sub = 0;
+    if (sk == kSegNone && k != first && g.sub_start[k] != kSegNone) {
+      sk = g.sub_start[k];
+      g.start_bit[k] = sk;
+      sub = 1;
+    }
+    g.is_sub[k] = sub;
+    found += sk != kSegNone;
+  }
   found = zh_wave_sum(found);
+  zh_wave_sync();
   const bool go = a.status[bid] == ZH_OK && found >= 4u;
   // (half the spacing of the starts: a region then takes three tokens per compressed byte of the
   // stretch its decoder covers, and no decoder is given up while starts are merely not everywhere)
@@ -798,6 +813,9 @@ extern "C" void zh_launch_seg_check(hipStream_t stream, const uint8_t* d_src, Zh
     return e && strcmp(e, "serial") == 0 ? 1 : 0;
   }();
   hipLaunchKernelGGL(zh_seg_check_kernel, dim3(g.nfind), dim3(kFindSlots), 0, stream, d_src, a, g, serial);
+}
+extern "C" void zh_launch_seg_decide(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g) {
+  if (!g.nsegs) return;
   hipLaunchKernelGGL(zh_seg_decide_kernel, dim3(g.nstreams), dim3(64), 0, stream, a, g);
 }
 extern "C" void zh_launch_seg_chain(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g) {

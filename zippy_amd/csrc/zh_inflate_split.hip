@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
                                                                 uint32_t* __restrict__ tok_pool,
                                                                 const uint64_t* __restrict__ tok_off,
                                                                 const uint64_t* __restrict__ tok_cap,
-                                                                ZhSegArgs g) {
+                                                                ZhSegArgs g, int phase) {
   constexpr uint32_t kSuperBits = kSplitThreads * kSubBits;
   constexpr uint32_t kStageWords = (kSplitThreads + 1u) * kSubStride;
   constexpr uint32_t kWaves = kSplitThreads / 64u;
@@ -112,13 +112,23 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
   // segment mode: the next found start at or behind the decoder's position.  It stops only where it
   // lands on one EXACTLY; a start it runs past was a wrong guess (bits inside a stored block that read
   // like a header -- a compressed file inside an archive is full of them) and is ignored.
-  uint64_t seg_start = 0, seg_target = 0;
+  // A segment inside a long block can have a SUB-START: a token boundary of that block, guessed in
+  // phase 0 of this kernel (below) from the block's header (g.sub_hdr) by decoding towards the
+  // segment from 4096 bits before it -- Huffman decoding falls in step by itself.  Its decoder reads
+  // the tables from that header and starts at the boundary; the decoder before lands on it only if
+  // it is in the same block (and stops there, in the middle of the block).
+  uint64_t seg_start = 0, seg_target = 0, cur_hdr = kSegNone;
   uint32_t seg_tj = sid, seg_last = 0;
-  if (kSeg) {
+  bool sub_first = false, seg_landed = false;
+  if (kSeg && phase != 0) {
     if (!g.go[bid]) return;  // too few starts were found: the stream is left to the ordinary kernels
     seg_start = g.start_bit[sid];
-    if (seg_start == kSegNone) return;  // no block starts in this segment: the one before carries on through it
+    if (seg_start == kSegNone) return;  // no start in this segment: the decoder before carries on through it
     seg_last = g.first_seg[bid + 1u];
+    sub_first = g.is_sub[sid] != 0u;
+  }
+  if (kSeg && phase == 0) {
+    if (sid == g.first_seg[bid] || g.start_bit[sid] != kSegNone) return;  // (it has a real start)
   }
 
   const ZhBufDesc bd = a.bufs[bid];
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
   __shared__ uint32_t s_wbytes[kWaves];
 
   // stream position in bits (from asrc)
-  uint64_t pos = kSeg ? (uint64_t)mis * 8 + seg_start : ((uint64_t)mis + a.body_pos[sid]) * 8;
+  uint64_t pos = kSeg ? (uint64_t)mis * 8 + (sub_first ? g.sub_hdr[sid] : seg_start) : ((uint64_t)mis + a.body_pos[sid]) * 8;
   uint64_t ntok = 0, out_bytes = 0;
   KPROF_DECL(8);  // cycles: 0 header + tables, 1 staging, 2 sync turns, 3 scan, 4 token pass; counts: 5 superchunks, 6 turns, 7 streams
   int st = ZH_OK;
@@ -233,21 +243,9 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
     return r;
   };
 
-  while (!final_block && st == ZH_OK) {  // inflate.nim:273-289
-    if (kSeg) {
-      const uint64_t rel = pos - (uint64_t)mis * 8;
-      // (segments without a found start are stepped over; kSegNone is behind every position)
-      while (seg_tj == sid || (seg_tj < seg_last && (seg_target == kSegNone || seg_target < rel))) {
-        seg_tj++;
-        seg_target = seg_tj < seg_last ? g.start_bit[seg_tj] : kSegNone;
-      }
-#ifdef ZH_EMU
-      if (tid == 0 && getenv("ZH_DBG_BLOCKS") && atoi(getenv("ZH_DBG_BLOCKS")) > 1)
-        fprintf(stderr, "  region %u at %llu: next start %llu (segment %u), %llu tokens of %llu\n", sid, (unsigned long long)rel,
-                (unsigned long long)seg_target, seg_tj, (unsigned long long)ntok, (unsigned long long)cap);
-#endif
-      if (seg_target == rel) break;  // that segment's decoder takes over
-    }
+  // the block header at `pos`: staged, then read by wave 0 like the serial kernel does; leaves the
+  // tables in LDS and the s_c_* words
+  auto parse_header = [&]() {
     // ---- block header: staged, then read by wave 0 like the serial kernel does ----
     const uint64_t hbase = pos >> 5;  // dword of the header's first bit
     KPROF_MARK(4);
@@ -382,15 +380,121 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
     }
     __syncthreads();
     KPROF_MARK(0);
+  };
+  // the superchunk that starts at the dword of `base_bit`, into s_in
+  auto stage_super = [&](uint64_t base_bit) {
+      {
+        constexpr uint32_t kWords = kSuperBits / 32u + kSubWords;  // the superchunk + the row behind it
+        constexpr uint32_t kLoads = (kWords + kSplitThreads - 1u) / kSplitThreads;  // 17 dwords a thread
+        const uint64_t w0 = base_bit >> 5;
+        uint32_t dw[kLoads];
+        if ((w0 + kLoads * kSplitThreads) * 4 <= end) {  // all of it inside the input: plain loads
+#pragma unroll
+          for (uint32_t j = 0; j < kLoads; j++) dw[j] = asrc[w0 + tid + j * kSplitThreads];
+        } else {
+#pragma unroll
+          for (uint32_t j = 0; j < kLoads; j++) dw[j] = load_dword((w0 + tid + j * kSplitThreads) * 4);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kLoads; j++) {
+          const uint32_t w = tid + j * kSplitThreads;
+          if (w < kWords) {
+            const uint32_t at = w + 3u * (w / kSubWords);
+            s_in[at] = dw[j];
+            if ((w & (kSubWords - 1u)) < 3u && w >= kSubWords) s_in[at - 3u] = dw[j];  // the copy behind the subchunk before
+          }
+        }
+      }
+  };
+
+  // segment mode: the next found start at or behind stream bit `rel` (segments without one are stepped
+  // over; kSegNone is behind every position)
+  auto next_start = [&](uint64_t rel) {
+    while (seg_tj == sid || (seg_tj < seg_last && (seg_target == kSegNone || seg_target < rel))) {
+      seg_tj++;
+      seg_target = seg_tj < seg_last ? g.start_bit[seg_tj] : kSegNone;
+    }
+  };
+
+  if (kSeg && phase == 0) {
+    // ---- phase 0: a sub-start for this segment ----
+    // the block it lies in, if any found start tells: the nearest one before it
+    uint64_t hdr = kSegNone;
+    for (uint32_t k = sid, lo = g.first_seg[bid], n = 0; k > lo && n < 256u; n++) {
+      k--;
+      const uint64_t sk = g.start_bit[k];
+      if (sk != kSegNone) {
+        hdr = sk;
+        break;
+      }
+    }
+    uint64_t found = kSegNone;
+    const uint64_t target = (uint64_t)mis * 8 + g.nominal_bit[sid];
+    // (a header less than a segment and a half back: the decoder that starts there is about to arrive
+    // anyway -- ordinary blocks of a few tens of KiB -- and parsing it once more costs more than it saves)
+    if (hdr != kSegNone && target < end * 8 && g.nominal_bit[sid] - hdr >= g.search_bits[sid] + g.search_bits[sid] / 2) {
+      pos = (uint64_t)mis * 8 + hdr;
+      parse_header();
+      const uint64_t payload = s_c_pos;
+      if (s_c_st == (uint32_t)ZH_OK && s_c_btype != 0u && payload < target) {
+        constexpr uint64_t kBefore = 4096;  // bits of run-up
+        const bool exact = payload + kBefore >= target;  // (the block starts that close: no guessing)
+        const uint64_t s0 = exact ? payload : target - kBefore;
+        const uint64_t base_bit = s0 & ~(uint64_t)31;
+        __syncthreads();
+        stage_super(base_bit);
+        __syncthreads();
+        const uint64_t end_bit = end * 8;
+        const uint32_t end_rel = (uint32_t)(end_bit - base_bit < 0xfffffff0ull ? end_bit - base_bit : 0xfffffff0ull);
+        if (tid < 64u) {
+          // 64 decoders a bit apart: after 4096 bits they have all fallen in step with the block's
+          // real token sequence, or this is no place to start
+          const uint32_t from = (uint32_t)(s0 - base_bit) + (exact ? 0u : tid);
+          const RunResult r = run(from, (uint32_t)(target - base_bit), end_rel, nullptr);
+          const uint32_t e0 = zh_bcast(r.end);
+          const uint64_t ok = __ballot(r.term == 0u && r.end == e0);
+          if ((ok & 1ull) && __popcll(ok) >= 56) found = base_bit + e0 - (uint64_t)mis * 8;
+        }
+      }
+    }
+    if (tid == 0) {
+      g.sub_start[sid] = found;
+      g.sub_hdr[sid] = hdr;
+    }
+    return;
+  }
+
+  while (!final_block && st == ZH_OK) {  // inflate.nim:273-289
+    if (kSeg && !sub_first) {
+      const uint64_t rel = pos - (uint64_t)mis * 8;
+      next_start(rel);
+#ifdef ZH_EMU
+      if (tid == 0 && getenv("ZH_DBG_BLOCKS") && atoi(getenv("ZH_DBG_BLOCKS")) > 1)
+        fprintf(stderr, "  region %u at %llu: next start %llu (segment %u), %llu tokens of %llu\n", sid, (unsigned long long)rel,
+                (unsigned long long)seg_target, seg_tj, (unsigned long long)ntok, (unsigned long long)cap);
+#endif
+      if (seg_target == rel && !g.is_sub[seg_tj]) break;  // that segment's decoder takes over
+    }
+    const uint64_t hdr_at = pos;
+    parse_header();
+    if (kSeg) cur_hdr = hdr_at - (uint64_t)mis * 8;
     const uint32_t btype = s_c_btype;
 #ifdef ZH_EMU
     if (tid == 0 && getenv("ZH_DBG_BLOCKS"))
-      fprintf(stderr, "block at bit %llu type %u (region %u)\n", (unsigned long long)(hbase * 32 + (pos & 31u) - mis * 8), btype, sid);
+      fprintf(stderr, "block at bit %llu type %u (region %u)\n", (unsigned long long)(hdr_at - mis * 8), btype, sid);
 #endif
     st = (int)s_c_st;
     if (s_c_final) final_block = true;
     pos = s_c_pos;
     if (st != ZH_OK) break;
+    if (kSeg && sub_first) {  // this decoder starts inside the block
+      sub_first = false;
+      if (btype == 0) {
+        st = ZH_ERR_INVALID_BUFFER;
+        break;
+      }
+      pos = (uint64_t)mis * 8 + seg_start;
+    }
 
     if (btype == 0) {
       const uint32_t len = s_c_stored_len;
@@ -417,29 +521,26 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
     for (;;) {
       const uint64_t base_bit = pos & ~(uint64_t)31;
       const uint32_t rel0 = (uint32_t)(pos - base_bit);
-      __syncthreads();  // (everybody is done with the previous contents of s_in)
-      {
-        constexpr uint32_t kWords = kSuperBits / 32u + kSubWords;  // the superchunk + the row behind it
-        constexpr uint32_t kLoads = (kWords + kSplitThreads - 1u) / kSplitThreads;  // 17 dwords a thread
-        const uint64_t w0 = base_bit >> 5;
-        uint32_t dw[kLoads];
-        if ((w0 + kLoads * kSplitThreads) * 4 <= end) {  // all of it inside the input: plain loads
-#pragma unroll
-          for (uint32_t j = 0; j < kLoads; j++) dw[j] = asrc[w0 + tid + j * kSplitThreads];
-        } else {
-#pragma unroll
-          for (uint32_t j = 0; j < kLoads; j++) dw[j] = load_dword((w0 + tid + j * kSplitThreads) * 4);
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < kLoads; j++) {
-          const uint32_t w = tid + j * kSplitThreads;
-          if (w < kWords) {
-            const uint32_t at = w + 3u * (w / kSubWords);
-            s_in[at] = dw[j];
-            if ((w & (kSubWords - 1u)) < 3u && w >= kSubWords) s_in[at - 3u] = dw[j];  // the copy behind the subchunk before
+      // segment mode: a sub-start of this block ahead?  The superchunk is then cut there: the
+      // thread that covers the position decodes up to it, the threads behind sit out.
+      uint32_t cut_rel = 0xffffffffu, cut_t = kSplitThreads;
+      if (kSeg) {
+        const uint64_t rel = pos - (uint64_t)mis * 8;
+        next_start(rel);
+        if (seg_tj < seg_last && seg_target != kSegNone && g.is_sub[seg_tj] && g.sub_hdr[seg_tj] == cur_hdr) {
+          if (seg_target == rel) {  // landed on it: that segment's decoder takes over
+            seg_landed = true;
+            break;
+          }
+          const uint64_t t_abs = seg_target + (uint64_t)mis * 8;
+          if (t_abs < base_bit + kSuperBits) {
+            cut_rel = (uint32_t)(t_abs - base_bit);
+            cut_t = (cut_rel - 1u) / kSubBits;
           }
         }
       }
+      __syncthreads();  // (everybody is done with the previous contents of s_in)
+      stage_super(base_bit);
       if (tid == 0) {
         s_first_dirty[0] = s_first_dirty[1] = kSplitThreads;
         s_first_term[0] = s_first_term[1] = kSplitThreads;
@@ -451,8 +552,8 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
       __syncthreads();
       KPROF_MARK(1);
       KPROF_COUNT(5, 1);
-      const uint32_t limit = (tid + 1u) * kSubBits;
-      uint32_t my_start = tid == 0 ? rel0 : tid * kSubBits;
+      const uint32_t limit = kSeg && tid == cut_t ? cut_rel : (tid + 1u) * kSubBits;
+      uint32_t my_start = tid == 0 ? rel0 : (kSeg && tid > cut_t ? kNoStart : tid * kSubBits);
       bool dirty = true;
       RunResult r = {0, 0, 0, 0};
       // A turn: threads whose start changed decode again; then every thread takes the end of the
@@ -474,7 +575,7 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
           s_end[tid] = r.term ? kNoStart : r.end;
         }
         __syncthreads();
-        const uint32_t ns = tid == 0 ? rel0 : s_end[tid - 1u];
+        const uint32_t ns = tid == 0 ? rel0 : (kSeg && tid > cut_t ? kNoStart : s_end[tid - 1u]);
         dirty = ns != my_start;
         my_start = ns;
         if (dirty) atomicMin(&s_first_dirty[par], tid);
@@ -504,7 +605,9 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
         // pointer doubling, or the block done before).  The first 48 positions' results are the
         // subchunk's map start -> end.
         KPROF_COUNT(5, 1u << 16);
-        const uint32_t map_end = fd + kMapGroup < kSplitThreads ? fd + kMapGroup : kSplitThreads;
+        uint32_t map_end = fd + kMapGroup < kSplitThreads ? fd + kMapGroup : kSplitThreads;
+        if (kSeg && map_end > cut_t) map_end = cut_t;  // (the cut thread's subchunk ends early: it settles turn by turn)
+        if (map_end <= fd) continue;
         for (uint32_t t = fd + (tid >> 6); t < map_end; t += kSplitThreads / 64u) {
           const uint32_t t_lim = (t + 1u) * kSubBits;
           uint32_t next_e = 0;  // block behind this one: lane l = result of position blockEnd + l
@@ -545,7 +648,7 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
         __syncthreads();
         {  // the mapped threads (and the one behind them) take their exact starts; whoever's start
            // changed decodes again in the next turn, which also settles what lies behind the group
-          const uint32_t ns2 = tid == 0 ? rel0 : s_end[tid - 1u];
+          const uint32_t ns2 = tid == 0 ? rel0 : (kSeg && tid > cut_t ? kNoStart : s_end[tid - 1u]);
           if (ns2 != my_start) {
             my_start = ns2;
             dirty = true;
@@ -592,14 +695,15 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
         pos = base_bit + s_c_endrel;  // behind the end-of-block code
         break;
       }
-      pos = base_bit + s_end[kSplitThreads - 1u];
+      pos = base_bit + s_end[kSeg && cut_t < kSplitThreads ? cut_t : kSplitThreads - 1u];
     }
+    if (kSeg && seg_landed) break;
   }
   if (tid == 0) {
     tok[ntok] = kRecSpecial | kRecEnd | ((uint32_t)st << 16);
     if (kSeg) {
       g.end_bit[sid] = pos - (uint64_t)mis * 8;
-      g.final_block[sid] = final_block ? 1u : 0u;
+      g.final_block[sid] = final_block && !seg_landed ? 1u : 0u;  // (a decoder that hands over inside the last block has not ended the stream)
       g.seg_status[sid] = st;
       g.seg_out[sid] = out_bytes;
     }
@@ -941,20 +1045,21 @@ extern "C" void zh_launch_inflate_tokens(hipStream_t stream, const uint8_t* d_sr
   if (!a.nbufs) return;
   if (zh_inflate_wide(a.nbufs))
     hipLaunchKernelGGL((zh_inflate_tokens_kernel<1024, false>), dim3(a.nbufs), dim3(1024), 0, stream, d_src, a,
-                       tok_pool, tok_off, tok_cap, ZhSegArgs{});
+                       tok_pool, tok_off, tok_cap, ZhSegArgs{}, 1);
   else
     hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, false>), dim3(a.nbufs), dim3(256), 0, stream, d_src, a,
-                       tok_pool, tok_off, tok_cap, ZhSegArgs{});
+                       tok_pool, tok_off, tok_cap, ZhSegArgs{}, 1);
 }
+// phase 0: sub-starts for the segments inside long blocks (before zh_seg_decide_kernel); phase 1: the tokens
 extern "C" void zh_launch_seg_tokens(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a, uint32_t* tok_pool,
-                                     ZhSegArgs g) {
+                                     ZhSegArgs g, int phase) {
   if (!g.nsegs) return;
   if (zh_inflate_wide(g.nsegs))
     hipLaunchKernelGGL((zh_inflate_tokens_kernel<1024, true>), dim3(g.nsegs), dim3(1024), 0, stream, d_src, a,
-                       tok_pool, nullptr, nullptr, g);
+                       tok_pool, nullptr, nullptr, g, phase);
   else
     hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, true>), dim3(g.nsegs), dim3(256), 0, stream, d_src, a,
-                       tok_pool, nullptr, nullptr, g);
+                       tok_pool, nullptr, nullptr, g, phase);
 }
 extern "C" void zh_launch_seg_write(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a, const uint32_t* tok_pool,
                                     ZhSegArgs g) {
