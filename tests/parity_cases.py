@@ -604,6 +604,7 @@ def check_segmented(eng, scale, monkeypatch, seg_bytes):
     whole streams, streams cut short and streams with a flipped bit."""
     monkeypatch.setenv("ZH_SEG_MIN", str(4 * seg_bytes))
     monkeypatch.setenv("ZH_SEG_BYTES", str(seg_bytes))
+    monkeypatch.setenv("ZH_SEG_SETUP", "0")  # (the set-up cost that keeps small jobs off this path)
     cases = segmented_streams(scale)
     # this library's own streams: ONE block (the last one) however long -- every decoder but the
     # first starts inside it; raw deflate has no checksum to catch a wrong byte, only this comparison

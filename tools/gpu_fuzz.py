@@ -176,6 +176,7 @@ def seg_mutations(count, seed=20260927):
     import parity_cases as pc
     os.environ["ZH_SEG_BYTES"] = "2048"
     os.environ["ZH_SEG_MIN"] = "8192"
+    os.environ["ZH_SEG_SETUP"] = "0"
     eng = api.engine()
     rnd = random.Random(seed)
     cases = pc.segmented_streams(1024)
@@ -206,7 +207,7 @@ def seg_mutations(count, seed=20260927):
                     print("SEGMENT MUTATION MISMATCH fmt", fmt, len(blob), st)
     print("gpu_fuzz segment mutations: %d blobs accepted %d rejected %d bad %d" % (count, accepted, count - accepted, bad))
     # noise and half-noise, default segment geometry: nothing may be accepted wrongly, nothing may hang
-    del os.environ["ZH_SEG_BYTES"], os.environ["ZH_SEG_MIN"]
+    del os.environ["ZH_SEG_BYTES"], os.environ["ZH_SEG_MIN"], os.environ["ZH_SEG_SETUP"]
     big = zlib.compress(synth.gen_batch("mix", 1, 2 << 20, first_index=3)[0].tobytes(), 6)
     noise = []
     for k in range(48):

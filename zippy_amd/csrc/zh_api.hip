@@ -650,7 +650,7 @@ extern "C" int zh_plan_block_index(zh_plan* p, size_t buf, zh_block_entry** inde
 // ZH_SEG_BYTES the segment length (default 32 KiB).
 struct SegConfig {
   bool on = true;
-  uint64_t min_stream = 131072, seg_bytes = 32768, tail_bytes = 4718592;
+  uint64_t min_stream = 131072, seg_bytes = 32768, tail_bytes = 4718592, setup_bytes = 8u << 20;
   size_t max_streams = 256;
 };
 static SegConfig seg_config() {  // (read per plan: the tests switch it)
@@ -659,6 +659,7 @@ static SegConfig seg_config() {  // (read per plan: the tests switch it)
   if (const char* e = getenv("ZH_SEG_MIN")) v.min_stream = strtoull(e, nullptr, 10);
   if (const char* e = getenv("ZH_SEG_BYTES")) v.seg_bytes = std::max<uint64_t>(64, strtoull(e, nullptr, 10));
   if (const char* e = getenv("ZH_SEG_TAIL")) v.tail_bytes = strtoull(e, nullptr, 10);
+  if (const char* e = getenv("ZH_SEG_SETUP")) v.setup_bytes = strtoull(e, nullptr, 10);  // (the tests' small streams: 0)
   return v;
 }
 
@@ -676,6 +677,18 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
     return b.src_len >= c.min_stream && b.src_len >= 2 * c.seg_bytes && b.src_len <= (~0ull >> 4);
   };
   if (std::none_of(bufs.begin(), bufs.end(), large)) return;
+  // Worth it?  The ordinary kernels give every stream one workgroup: the batch takes as long as its
+  // longest stream (measured: 8.7 us per KB of compressed data); segment-wise the machine is full but a
+  // byte costs four times more work (0.19 us per KB of the whole batch, 1.6 ms to set up).
+  // 1 MiB streams (400 KB compressed): up to 20 of them; large ones: up to 39.
+  {
+    uint64_t longest = 0, total = 0;
+    for (const ZhBufDesc& b : bufs) {
+      longest = std::max<uint64_t>(longest, b.src_len);
+      if (large(b)) total += b.src_len;
+    }
+    if (longest * 40 <= total + c.setup_bytes) return;
+  }
   std::vector<uint32_t> parent, first_seg(n + 1), find_seg, find_batch;
   std::vector<uint64_t> nominal, search, toff, tcap, sym_base(n);
   uint64_t nsym = 0;
