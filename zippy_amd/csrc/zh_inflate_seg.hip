@@ -17,6 +17,13 @@
 //                          symbol, a usable distance code.  The lowest position of a segment that
 //                          passes is the segment's start: almost certainly a block start, but only
 //                          a GUESS;
+//   tokens kernel phase 0   sub-starts: a segment inside a long block (this library's own streams are
+//   zh_seg_decide_kernel    ONE block per 4 MiB of input) gets a token boundary of that block as its
+//                          start -- guessed by decoding towards the segment from 4096 bits before it
+//                          with the tables of the nearest header found before it (Huffman decoding
+//                          falls in step by itself) -- together with that header's position; the
+//                          decide kernel merges them and sends streams with fewer than four starts
+//                          to the ordinary kernels (zh_inflate_split.hip has the details);
 //   tokens (segment form)  all segments at once, each from its found start.  A decoder stops at the
 //                          first block boundary that IS a found start (or at the end of the stream):
 //                          a found start it runs past was a wrong guess -- bits inside a stored block
