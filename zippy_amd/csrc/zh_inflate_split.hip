@@ -31,6 +31,13 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef ZH_RUNUP
+#define ZH_RUNUP 512
+#endif
+#ifndef ZH_SUBBITS
+#define ZH_SUBBITS 512
+#endif
+
 #include "zh_common.h"
 #include "zh_kprof.h"
 #include "zh_tables.h"
@@ -38,7 +45,7 @@
 
 namespace {
 
-constexpr uint32_t kSubBits = 512;                            // one thread's share of a superchunk
+constexpr uint32_t kSubBits = ZH_SUBBITS;                            // one thread's share of a superchunk
 constexpr uint32_t kSubWords = kSubBits / 32u;                 // 16
 // The staged superchunk gives every subchunk 19 dwords: its own 16 and a copy of the next three
 // (a token that starts in the subchunk reads at most that far), so dword w of the superchunk sits
@@ -48,6 +55,10 @@ constexpr uint32_t kSubStride = kSubWords + 3u;
 constexpr uint32_t kHeaderWords = 288;                        // a dynamic header is < 900 bytes
 constexpr uint32_t kDistSub = 256;                            // second-level distance tables
 constexpr uint32_t kNoStart = 0xffffffffu;                    // "the thread before me ended the block"
+// bits decoded ahead of a subchunk to find its first token boundary (4096 x 1 MiB, tokens kernel: none
+// 20.3 ms, 128 bits 17.5, 256 16.4, 512 15.5; subchunks of 1024 bits with a run-up of 512: 17.8)
+constexpr uint32_t kRunUp = ZH_RUNUP;
+static_assert(kRunUp <= ZH_SUBBITS, "a run-up stays inside the subchunk before");
 constexpr uint32_t kMinTurns = 3;     // speculative turns before the all-starts pass may take over
 constexpr uint32_t kSlowGain = 12;    // ... when a turn added fewer final threads than this
 constexpr uint32_t kMapGroup = 64;    // subchunks mapped per all-starts pass
@@ -554,6 +565,14 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
       KPROF_COUNT(5, 1);
       const uint32_t limit = kSeg && tid == cut_t ? cut_rel : (tid + 1u) * kSubBits;
       uint32_t my_start = tid == 0 ? rel0 : (kSeg && tid > cut_t ? kNoStart : tid * kSubBits);
+      // A run-up: a thread first decodes the last kRunUp bits of the subchunk before its own, from a
+      // guessed bit; by the time it crosses into its subchunk it has usually fallen in step, and the
+      // boundary it crosses at is the start the thread before will hand it -- no second turn for it.
+      if (kRunUp && tid != 0 && my_start != kNoStart) {
+        const uint32_t from = tid * kSubBits - kRunUp;  // (kRunUp <= kSubBits; thread 1 may as well start where thread 0 does)
+        const RunResult pre = run(from > rel0 ? from : rel0, tid * kSubBits, end_rel, nullptr);
+        if (pre.term == 0u) my_start = pre.end;
+      }
       bool dirty = true;
       RunResult r = {0, 0, 0, 0};
       // A turn: threads whose start changed decode again; then every thread takes the end of the
