@@ -856,7 +856,7 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
     twords += tcap[i] + 1024;  // (the writer reads whole batches of records, up to 640 behind the last)
   }
   plan_segments(p, bufs, &twords);
-  p->tok_words = twords + 16384;  // (... and stages them up to 4096 at a time, two stagings ahead)
+  p->tok_words = twords + 32768;  // (... and stages them up to 8192 at a time, two stagings ahead)
   hipError_t up = hipMemcpyAsync(base + o_toff, toff.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
   if (up == hipSuccess) up = hipMemcpyAsync(base + o_tcap, tcap.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
   if (up == hipSuccess)

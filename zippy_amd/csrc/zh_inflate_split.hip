@@ -31,6 +31,12 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef ZH_WR_OCC
+#define ZH_WR_OCC 5
+#endif
+#ifndef ZH_WR_BYTES
+#define ZH_WR_BYTES 8
+#endif
 #ifndef ZH_RUNUP
 #define ZH_RUNUP 512
 #endif
@@ -748,17 +754,18 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
 // g.sym: a byte, or -- for a byte copied from the 32 KiB before the segment, which some other
 // workgroup is writing at the same time -- 0x8000 | its index in that window.  Copies of symbols are
 // copies whatever the symbol is; zh_seg_windows_kernel / zh_seg_finish_kernel turn them into bytes.
-template <uint32_t kWrThreads, bool kSeg>
-__global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint8_t* __restrict__ d_src,
+template <uint32_t kWrThreads, bool kSeg, uint32_t kB>
+__global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : 1) void zh_inflate_write_kernel(const uint8_t* __restrict__ d_src,
                                                                uint8_t* __restrict__ d_dst, ZhInflateArgs a,
                                                                const uint32_t* __restrict__ tok_pool,
                                                                const uint64_t* __restrict__ tok_off,
                                                                ZhSegArgs g) {
   typedef typename std::conditional<kSeg, uint16_t, uint8_t>::type Sym;
   constexpr uint32_t kWrWaves = kWrThreads / 64u;
-  constexpr uint32_t kWrRound = kWrThreads * 4u;  // output bytes per round
-  constexpr uint32_t kWrRecs = kWrThreads * 2u;   // records looked at per round
-  constexpr uint32_t kWrRing = kWrThreads * 8u;   // token records staged in LDS (a power of two)
+  constexpr uint32_t kR = kB / 2u;                    // records a thread looks at per round (kB: output bytes it owns)
+  constexpr uint32_t kWrRound = kWrThreads * kB;      // output bytes per round
+  constexpr uint32_t kWrRecs = kWrThreads * kR;       // records looked at per round
+  constexpr uint32_t kWrRing = kWrThreads * kR * 4u;  // token records staged in LDS (a power of two)
   __shared__ uint32_t s_tok[kWrRing];
   __shared__ uint32_t s_map32[kWrRound / 2];  // u16 per byte: (index in the round of the record that starts there) + 1
   __shared__ uint32_t s_par32[kWrRound / 2];  // u16 per byte: the byte of this round it copies (itself: a root)
@@ -817,66 +824,82 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
     op += length;
   };
 
-  // records [ti, hi) are in the ring; `pre` holds records [hi, hi + 1024) on their way from HBM
+  // records [ti, hi) are in the ring; `pre` holds records [hi, hi + 2 kR threads) on their way from HBM
   uint64_t ti = 0, hi = 0;
-  uint32_t pre[4];
+  uint32_t pre[2 * kR];
   auto fetch_ahead = [&]() {
 #pragma unroll
-    for (int k = 0; k < 4; k++) pre[k] = tok[hi + tid + kWrThreads * k];
+    for (uint32_t k = 0; k < 2 * kR; k++) pre[k] = tok[hi + tid + kWrThreads * k];
   };
   auto commit_ahead = [&]() {  // (callers keep a barrier between this and the ring's readers)
 #pragma unroll
-    for (int k = 0; k < 4; k++) s_tok[(uint32_t)(hi + tid + kWrThreads * k) & (kWrRing - 1u)] = pre[k];
-    hi += 4u * kWrThreads;
+    for (uint32_t k = 0; k < 2 * kR; k++) s_tok[(uint32_t)(hi + tid + kWrThreads * k) & (kWrRing - 1u)] = pre[k];
+    hi += 2u * kR * kWrThreads;
   };
   fetch_ahead();
   if (tid < 4) s_flag[tid] = 0;
 
   for (uint32_t round = 0;; round++) {
-    if (hi < ti + kWrRecs + 128u) {  // a round looks at 512 records (+ 2 behind a stored-run record)
+    if (hi < ti + kWrRecs + 128u) {  // a round looks at kWrRecs records (+ 2 behind a stored-run record)
       commit_ahead();
       fetch_ahead();
     }
     __syncthreads();
-    const uint32_t i0 = 2u * tid;
-    const uint32_t r0 = s_tok[(uint32_t)(ti + i0) & (kWrRing - 1u)], r1 = s_tok[(uint32_t)(ti + i0 + 1u) & (kWrRing - 1u)];
+    const uint32_t i0 = kR * tid;
+    uint32_t r[kR];
+#pragma unroll
+    for (uint32_t k = 0; k < kR; k++) r[k] = s_tok[(uint32_t)(ti + i0 + k) & (kWrRing - 1u)];
     // ---- records up to the first special one ----
     {
-      const uint64_t sp0 = __ballot((r0 & kRecSpecial) != 0), sp1 = __ballot((r1 & kRecSpecial) != 0);
-      const uint32_t f0 = sp0 ? 2u * ((uint32_t)__ffsll((long long)sp0) - 1u) : 128u;
-      const uint32_t f1 = sp1 ? 2u * ((uint32_t)__ffsll((long long)sp1) - 1u) + 1u : 128u;
-      const uint32_t fw = f0 < f1 ? f0 : f1;
-      if (lane == 0) s_w[0][wv] = fw < 128u ? wv * 128u + fw : kWrRecs;
+      uint32_t fw = 64u * kR;
+#pragma unroll
+      for (uint32_t k = 0; k < kR; k++) {
+        const uint64_t sp = __ballot((r[k] & kRecSpecial) != 0);
+        const uint32_t f = sp ? kR * ((uint32_t)__ffsll((long long)sp) - 1u) + k : 64u * kR;
+        fw = f < fw ? f : fw;
+      }
+      if (lane == 0) s_w[0][wv] = fw < 64u * kR ? wv * 64u * kR + fw : kWrRecs;
     }
     __syncthreads();
     uint32_t fs = kWrRecs;
 #pragma unroll
     for (uint32_t w = 0; w < kWrWaves; w++) fs = min(fs, s_w[0][w]);
-    const uint32_t len0 = i0 < fs ? r0 & 0x1ffu : 0u, len1 = i0 + 1u < fs ? r1 & 0x1ffu : 0u;
-    const uint32_t incl = zh_wave_scan(len0 + len1);
+    uint32_t len[kR], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kR; k++) {
+      len[k] = i0 + k < fs ? r[k] & 0x1ffu : 0u;
+      sum += len[k];
+    }
+    const uint32_t incl = zh_wave_scan(sum);
     if (lane == 63) s_w[1][wv] = incl;
     __syncthreads();
     uint32_t before = 0;
 #pragma unroll
     for (uint32_t w = 0; w < kWrWaves; w++)
       if (w < wv) before += s_w[1][w];
-    // where the records' output starts in the round
-    const uint32_t o0 = before + incl - len0 - len1, o1 = o0 + len0;
-    const bool fit0 = i0 < fs && o0 + len0 <= kWrRound, fit1 = i0 + 1u < fs && o1 + len1 <= kWrRound;
-    const bool lit0 = (r0 >> 9) & 1u, lit1 = (r1 >> 9) & 1u;
+    // where the records' output starts in the round; the records that fit are a prefix (the sums grow)
+    uint32_t o[kR];
+    bool fit[kR];
     {
-      const uint64_t b0 = __ballot(fit0), b1 = __ballot(fit1);  // prefixes of the lanes (the sums grow)
-      const uint32_t endl = fit1 ? o1 + len1 : fit0 ? o0 + len0 : 0u;
-      const uint32_t nfit = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
+      uint32_t at = before + incl - sum, endl = 0, nfit = 0;
+      bool bad = false;
+#pragma unroll
+      for (uint32_t k = 0; k < kR; k++) {
+        o[k] = at;
+        fit[k] = i0 + k < fs && at + len[k] <= kWrRound;
+        if (fit[k]) endl = at + len[k];
+        // inflate.nim:224-225 `distance > op` (a distance is at most 32768)
+        bad = bad || (fit[k] && !((r[k] >> 9) & 1u) && (uint64_t)(r[k] >> 16) > gbase + op + at);
+        nfit += (uint32_t)__popcll(__ballot(fit[k]));
+        at += len[k];
+      }
+      const uint64_t b0 = __ballot(fit[0]);
       const uint32_t wend = b0 ? (uint32_t)__builtin_amdgcn_readlane(endl, (uint32_t)__popcll(b0) - 1u) : 0u;
       if (lane == 0) {
         s_w[2][wv] = nfit;
         s_w[3][wv] = wend;
       }
-      // inflate.nim:224-225 `distance > op` (a distance is at most 32768)
-      if (gbase + op < 32768u && ((fit0 && !lit0 && (uint64_t)(r0 >> 16) > gbase + op + o0) ||
-                                  (fit1 && !lit1 && (uint64_t)(r1 >> 16) > gbase + op + o1)))
-        s_flag[round & 1u] = 1;  // (flag words alternate between rounds; the idle one is cleared below)
+      if (gbase + op < 32768u && bad) s_flag[round & 1u] = 1;  // (flag words alternate between rounds; the idle one is cleared below)
     }
     __syncthreads();
     uint32_t n = 0, total = 0;
@@ -925,21 +948,26 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
       break;
     }
     // ---- byte -> record ----
-    s_map32[2u * tid] = 0;
-    s_map32[2u * tid + 1u] = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kB / 2u; j++) s_map32[(kB / 2u) * tid + j] = 0;
     __syncthreads();
-    if (fit0) s_map[o0] = (uint16_t)(i0 + 1u);
-    if (fit1) s_map[o1] = (uint16_t)(i0 + 2u);
+#pragma unroll
+    for (uint32_t k = 0; k < kR; k++)
+      if (fit[k]) s_map[o[k]] = (uint16_t)(i0 + k + 1u);
     __syncthreads();
-    uint32_t t[4];
+    uint32_t t[kB];
     {
-      const uint32_t m01 = s_map32[2u * tid], m23 = s_map32[2u * tid + 1u];
-      t[0] = m01 & 0xffffu;
-      t[1] = max(t[0], m01 >> 16);
-      t[2] = max(t[1], m23 & 0xffffu);
-      t[3] = max(t[2], m23 >> 16);
+      uint32_t m = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < kB / 2u; j++) {
+        const uint32_t w = s_map32[(kB / 2u) * tid + j];
+        m = max(m, w & 0xffffu);
+        t[2u * j] = m;
+        m = max(m, w >> 16);
+        t[2u * j + 1u] = m;
+      }
     }
-    const uint32_t run = zh_wave_scan_max(t[3]);
+    const uint32_t run = zh_wave_scan_max(t[kB - 1u]);
     if (lane == 63) s_w[4][wv] = run;
     uint32_t carry = (uint32_t)__shfl_up((int)run, 1, 64);
     if (lane == 0) carry = 0;
@@ -948,12 +976,12 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
     for (uint32_t w = 0; w < kWrWaves; w++)
       if (w < wv) carry = max(carry, s_w[4][w]);
     // ---- every byte: literal, copy from before the round (far), or from inside it (near) ----
-    uint32_t par[4], val[4];
+    uint32_t par[kB], val[kB];
     bool any_near = false;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t pb = 4u * tid + (uint32_t)j;  // byte of the round
-      const uint32_t tk = max(carry, t[j]);       // its record + 1 (>= 1 for every live byte)
+    for (uint32_t j = 0; j < kB; j++) {
+      const uint32_t pb = kB * tid + j;       // byte of the round
+      const uint32_t tk = max(carry, t[j]);  // its record + 1 (>= 1 for every live byte)
       const uint32_t rec = s_tok[(uint32_t)(ti + tk - 1u) & (kWrRing - 1u)];
       par[j] = pb;
       val[j] = (rec >> 16) & 0xffu;
@@ -968,13 +996,17 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
       }
     }
     if (any_near) s_flag[2u + (round & 1u)] = 1;
-    s_par32[2u * tid] = par[0] | (par[1] << 16);
-    s_par32[2u * tid + 1u] = par[2] | (par[3] << 16);
+#pragma unroll
+    for (uint32_t j = 0; j < kB / 2u; j++) s_par32[(kB / 2u) * tid + j] = par[2u * j] | (par[2u * j + 1u] << 16);
     if (kSeg) {
-      s_val32[2u * tid] = (val[0] & 0xffffu) | (val[1] << 16);
-      s_val32[2u * tid + 1u] = (val[2] & 0xffffu) | (val[3] << 16);
+#pragma unroll
+      for (uint32_t j = 0; j < kB / 2u; j++)
+        s_val32[(kB / 2u) * tid + j] = (val[2u * j] & 0xffffu) | (val[2u * j + 1u] << 16);
     } else {
-      s_val32[tid] = (val[0] & 0xffu) | ((val[1] & 0xffu) << 8) | ((val[2] & 0xffu) << 16) | (val[3] << 24);
+#pragma unroll
+      for (uint32_t j = 0; j < kB / 4u; j++)
+        s_val32[(kB / 4u) * tid + j] = (val[4u * j] & 0xffu) | ((val[4u * j + 1u] & 0xffu) << 8) |
+                                      ((val[4u * j + 2u] & 0xffu) << 16) | (val[4u * j + 3u] << 24);
     }
     __syncthreads();
     if (s_flag[2u + (round & 1u)]) {
@@ -985,7 +1017,7 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
       for (uint32_t k = 0;; k++) {
         bool changed = false;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (uint32_t j = 0; j < kB; j++) {
           const uint32_t q = s_par[par[j]];
           changed |= q != par[j];
           par[j] = q;
@@ -994,35 +1026,37 @@ __global__ __launch_bounds__(kWrThreads) void zh_inflate_write_kernel(const uint
         __syncthreads();
         const bool again = s_w[5][k & 1u] != 0;
         if (!again) break;
-        s_par32[2u * tid] = par[0] | (par[1] << 16);
-        s_par32[2u * tid + 1u] = par[2] | (par[3] << 16);
+#pragma unroll
+        for (uint32_t j = 0; j < kB / 2u; j++) s_par32[(kB / 2u) * tid + j] = par[2u * j] | (par[2u * j + 1u] << 16);
         if (tid == 0) s_w[5][(k & 1u) ^ 1u] = 0;
         __syncthreads();
       }
 #pragma unroll
-      for (int j = 0; j < 4; j++) val[j] = s_val[par[j]];
+      for (uint32_t j = 0; j < kB; j++) val[j] = s_val[par[j]];
     }
-    const uint32_t pb0 = 4u * tid;
-    if (kSeg) {
-      if (pb0 + 4u <= total) {
-        struct __attribute__((packed)) U64 { uint64_t v; };
-        reinterpret_cast<U64*>(dst + op + pb0)->v = (uint64_t)((val[0] & 0xffffu) | (val[1] << 16)) |
-                                                    ((uint64_t)((val[2] & 0xffffu) | (val[3] << 16)) << 32);
-      } else {
+    const uint32_t pb0 = kB * tid;
+    if (pb0 + kB <= total) {  // (gfx950 global stores need no alignment)
+      struct __attribute__((packed)) U64 { uint64_t v; };
+      struct __attribute__((packed)) U32 { uint32_t v; };
+      if (kSeg) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (pb0 + (uint32_t)j < total) dst[op + pb0 + (uint32_t)j] = (Sym)val[j];
+        for (uint32_t j = 0; j < kB / 4u; j++)
+          reinterpret_cast<U64*>(dst + op + pb0 + 4u * j)->v =
+              (uint64_t)((val[4u * j] & 0xffffu) | (val[4u * j + 1u] << 16)) |
+              ((uint64_t)((val[4u * j + 2u] & 0xffffu) | (val[4u * j + 3u] << 16)) << 32);
+      } else if (kB == 8u) {
+        reinterpret_cast<U64*>(dst + op + pb0)->v =
+            (uint64_t)((val[0] & 0xffu) | ((val[1] & 0xffu) << 8) | ((val[2] & 0xffu) << 16) | (val[3] << 24)) |
+            ((uint64_t)((val[kB - 4u] & 0xffu) | ((val[kB - 3u] & 0xffu) << 8) | ((val[kB - 2u] & 0xffu) << 16) |
+                        (val[kB - 1u] << 24)) << 32);
+      } else {
+        reinterpret_cast<U32*>(dst + op + pb0)->v =
+            (val[0] & 0xffu) | ((val[1] & 0xffu) << 8) | ((val[2] & 0xffu) << 16) | (val[3] << 24);
       }
     } else {
-      const uint32_t w = (val[0] & 0xffu) | ((val[1] & 0xffu) << 8) | ((val[2] & 0xffu) << 16) | (val[3] << 24);
-      if (pb0 + 4u <= total) {
-        struct __attribute__((packed)) U32 { uint32_t v; };
-        reinterpret_cast<U32*>(dst + op + pb0)->v = w;  // (gfx950 global stores need no alignment)
-      } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (pb0 + (uint32_t)j < total) dst[op + pb0 + (uint32_t)j] = (Sym)(w >> (8 * j));
-      }
+      for (uint32_t j = 0; j < kB; j++)
+        if (pb0 + j < total) dst[op + pb0 + j] = (Sym)val[j];
     }
     op += total;
     ti += n;
@@ -1084,19 +1118,19 @@ extern "C" void zh_launch_seg_write(hipStream_t stream, const uint8_t* d_src, Zh
                                     ZhSegArgs g) {
   if (!g.nsegs) return;
   if (zh_inflate_wide(g.nsegs))
-    hipLaunchKernelGGL((zh_inflate_write_kernel<1024, true>), dim3(g.nsegs), dim3(1024), 0, stream, d_src, nullptr, a,
+    hipLaunchKernelGGL((zh_inflate_write_kernel<1024, true, ZH_WR_BYTES>), dim3(g.nsegs), dim3(1024), 0, stream, d_src, nullptr, a,
                        tok_pool, nullptr, g);
   else
-    hipLaunchKernelGGL((zh_inflate_write_kernel<256, true>), dim3(g.nsegs), dim3(256), 0, stream, d_src, nullptr, a,
+    hipLaunchKernelGGL((zh_inflate_write_kernel<256, true, ZH_WR_BYTES>), dim3(g.nsegs), dim3(256), 0, stream, d_src, nullptr, a,
                        tok_pool, nullptr, g);
 }
 extern "C" void zh_launch_inflate_write(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a,
                                         const uint32_t* tok_pool, const uint64_t* tok_off) {
   if (!a.nbufs) return;
   if (zh_inflate_wide(a.nbufs))
-    hipLaunchKernelGGL((zh_inflate_write_kernel<1024, false>), dim3(a.nbufs), dim3(1024), 0, stream, d_src, d_dst, a,
+    hipLaunchKernelGGL((zh_inflate_write_kernel<1024, false, ZH_WR_BYTES>), dim3(a.nbufs), dim3(1024), 0, stream, d_src, d_dst, a,
                        tok_pool, tok_off, ZhSegArgs{});
   else
-    hipLaunchKernelGGL((zh_inflate_write_kernel<256, false>), dim3(a.nbufs), dim3(256), 0, stream, d_src, d_dst, a,
+    hipLaunchKernelGGL((zh_inflate_write_kernel<256, false, ZH_WR_BYTES>), dim3(a.nbufs), dim3(256), 0, stream, d_src, d_dst, a,
                        tok_pool, tok_off, ZhSegArgs{});
 }
