@@ -27,6 +27,7 @@ def engine():
         # batches of up to three streams decode with the wide (1024-thread) inflate kernels, larger
         # ones with the narrow (256-thread) ones: the tests' batches cover both
         os.environ.setdefault("ZH_INFLATE_WIDE", "3")
+        os.environ.setdefault("ZH_INFLATE_MID", "8")  # (... and those of four to eight with the 512-thread ones)
         _engine = Engine(build_emu.build())
         _engine.set_gzip_fname_len(0)
     return _engine

@@ -88,13 +88,13 @@ struct RunResult {
 }  // namespace
 
 // kSplitThreads: 256 (a superchunk of 16 KiB of the stream, five workgroups per CU: batches) or
-// 1024 (64 KiB, one workgroup per CU: a handful of streams, where the chain of a stream's
+// 1024 (64 KiB, one workgroup per CU: up to a few streams per CU, where the chain of a stream's
 // superchunks is what takes the time).
 // kSeg: a workgroup takes a SEGMENT of a stream (ZhSegArgs, zh_inflate_seg.hip): it starts at the
 // block the segment's search found, stops at the first block boundary at or behind the next found
 // start, and reports where that was, how many bytes its tokens make and whether the stream ended.
 template <uint32_t kSplitThreads, bool kSeg>
-__global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(const uint8_t* __restrict__ d_src,
+__global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void zh_inflate_tokens_kernel(const uint8_t* __restrict__ d_src,
                                                                 ZhInflateArgs a,
                                                                 uint32_t* __restrict__ tok_pool,
                                                                 const uint64_t* __restrict__ tok_off,
@@ -749,13 +749,13 @@ __global__ __launch_bounds__(kSplitThreads, 4) void zh_inflate_tokens_kernel(con
 // LDS and L2 round trips: wide rounds are what shortens it (64-byte rounds by one wave: 13 ms for
 // a 1 MiB stream whatever the batch).  A single copy that does not fit a round goes alone.
 // ---------------------------------------------------------------------------
-// kWrThreads: 256 (rounds of 1024 bytes: batches) or 1024 (rounds of 4096 bytes: a handful of streams).
+// kWrThreads: 256 (batches), 512 (a few hundred streams) or 1024 (up to a stream per CU); a round is kB bytes a thread.
 // kSeg: a workgroup writes a chain SEGMENT of a stream (zh_inflate_seg.hip) as 16-bit symbols into
 // g.sym: a byte, or -- for a byte copied from the 32 KiB before the segment, which some other
 // workgroup is writing at the same time -- 0x8000 | its index in that window.  Copies of symbols are
 // copies whatever the symbol is; zh_seg_windows_kernel / zh_seg_finish_kernel turn them into bytes.
 template <uint32_t kWrThreads, bool kSeg, uint32_t kB>
-__global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : 1) void zh_inflate_write_kernel(const uint8_t* __restrict__ d_src,
+__global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThreads == 512 ? 2 : 1) void zh_inflate_write_kernel(const uint8_t* __restrict__ d_src,
                                                                uint8_t* __restrict__ d_dst, ZhInflateArgs a,
                                                                const uint32_t* __restrict__ tok_pool,
                                                                const uint64_t* __restrict__ tok_off,
@@ -1085,52 +1085,63 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : 1) void
 // Few streams: one wide workgroup each (a stream is a chain of superchunks and of rounds, and wide
 // ones shorten it); many: narrow workgroups, several per CU (ZH_INFLATE_WIDE = largest batch that
 // still gets the wide form).
-static bool zh_inflate_wide(uint32_t nbufs) {
-  static const uint32_t upto = [] {
+// -> threads per workgroup.  Few streams: one wide workgroup each (a stream is a chain of superchunks and of
+// rounds, and wide ones shorten it); many: narrow workgroups, several per CU.  Measured on 1 MiB streams
+// (tokens / writer, ms): 256 streams 1.5 / 1.5 wide, 2.1 / 2.0 with 512 threads, 3.8 / 3.2 narrow; 512 streams
+// 2.8 / 2.9, 4.1 / 2.6, 4.0 / 3.6; 768 streams 4.0 / 4.4, 6.0 / 4.3, 4.2 / 4.1; 1024 streams 5.4 / 5.8, 8.1 / 5.0,
+// 4.3 / 4.4.  ZH_INFLATE_WIDE / ZH_INFLATE_MID: the tokens kernel's / the writer's largest wide batch.
+static uint32_t zh_tokens_width(uint32_t nbufs) {
+  static const uint32_t wide = [] {
     const char* e = getenv("ZH_INFLATE_WIDE");
-    return e ? (uint32_t)atoi(e) : 512u;  // (512 x 1 MiB: wide 7.4 ms, narrow 9.5; 1024: 14.2 against 10.3)
+    return e ? (uint32_t)atoi(e) : 768u;
   }();
-  return nbufs <= upto;
+  return nbufs <= wide ? 1024u : 256u;
+}
+static uint32_t zh_writer_width(uint32_t nbufs) {
+  static const uint32_t wide = [] {
+    const char* e = getenv("ZH_INFLATE_WIDE");
+    return e ? (uint32_t)atoi(e) : 256u;
+  }();
+  static const uint32_t mid = [] {
+    const char* e = getenv("ZH_INFLATE_MID");
+    return e ? (uint32_t)atoi(e) : 640u;
+  }();
+  return nbufs <= wide ? 1024u : nbufs <= mid ? 512u : 256u;
 }
 
 extern "C" void zh_launch_inflate_tokens(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a,
                                          uint32_t* tok_pool, const uint64_t* tok_off, const uint64_t* tok_cap) {
   if (!a.nbufs) return;
-  if (zh_inflate_wide(a.nbufs))
-    hipLaunchKernelGGL((zh_inflate_tokens_kernel<1024, false>), dim3(a.nbufs), dim3(1024), 0, stream, d_src, a,
-                       tok_pool, tok_off, tok_cap, ZhSegArgs{}, 1);
+  if (zh_tokens_width(a.nbufs) == 1024u)
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<1024, false>), dim3(a.nbufs), dim3(1024), 0, stream, d_src, a, tok_pool, tok_off, tok_cap, ZhSegArgs{}, 1);
   else
-    hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, false>), dim3(a.nbufs), dim3(256), 0, stream, d_src, a,
-                       tok_pool, tok_off, tok_cap, ZhSegArgs{}, 1);
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, false>), dim3(a.nbufs), dim3(256), 0, stream, d_src, a, tok_pool, tok_off, tok_cap, ZhSegArgs{}, 1);
 }
 // phase 0: sub-starts for the segments inside long blocks (before zh_seg_decide_kernel); phase 1: the tokens
 extern "C" void zh_launch_seg_tokens(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a, uint32_t* tok_pool,
                                      ZhSegArgs g, int phase) {
   if (!g.nsegs) return;
-  if (zh_inflate_wide(g.nsegs))
-    hipLaunchKernelGGL((zh_inflate_tokens_kernel<1024, true>), dim3(g.nsegs), dim3(1024), 0, stream, d_src, a,
-                       tok_pool, nullptr, nullptr, g, phase);
+  if (g.nsegs <= 512u)  // (segments are short: a wide workgroup only pays while there is a CU for each or so)
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<1024, true>), dim3(g.nsegs), dim3(1024), 0, stream, d_src, a, tok_pool, nullptr, nullptr, g, phase);
   else
-    hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, true>), dim3(g.nsegs), dim3(256), 0, stream, d_src, a,
-                       tok_pool, nullptr, nullptr, g, phase);
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, true>), dim3(g.nsegs), dim3(256), 0, stream, d_src, a, tok_pool, nullptr, nullptr, g, phase);
 }
 extern "C" void zh_launch_seg_write(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a, const uint32_t* tok_pool,
                                     ZhSegArgs g) {
   if (!g.nsegs) return;
-  if (zh_inflate_wide(g.nsegs))
-    hipLaunchKernelGGL((zh_inflate_write_kernel<1024, true, ZH_WR_BYTES>), dim3(g.nsegs), dim3(1024), 0, stream, d_src, nullptr, a,
-                       tok_pool, nullptr, g);
+  if (g.nsegs <= 512u)
+    hipLaunchKernelGGL((zh_inflate_write_kernel<1024, true, ZH_WR_BYTES>), dim3(g.nsegs), dim3(1024), 0, stream, d_src, nullptr, a, tok_pool, nullptr, g);
   else
-    hipLaunchKernelGGL((zh_inflate_write_kernel<256, true, ZH_WR_BYTES>), dim3(g.nsegs), dim3(256), 0, stream, d_src, nullptr, a,
-                       tok_pool, nullptr, g);
+    hipLaunchKernelGGL((zh_inflate_write_kernel<256, true, ZH_WR_BYTES>), dim3(g.nsegs), dim3(256), 0, stream, d_src, nullptr, a, tok_pool, nullptr, g);
 }
 extern "C" void zh_launch_inflate_write(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a,
                                         const uint32_t* tok_pool, const uint64_t* tok_off) {
   if (!a.nbufs) return;
-  if (zh_inflate_wide(a.nbufs))
-    hipLaunchKernelGGL((zh_inflate_write_kernel<1024, false, ZH_WR_BYTES>), dim3(a.nbufs), dim3(1024), 0, stream, d_src, d_dst, a,
-                       tok_pool, tok_off, ZhSegArgs{});
+  const uint32_t th = zh_writer_width(a.nbufs);
+  if (th == 1024u)
+    hipLaunchKernelGGL((zh_inflate_write_kernel<1024, false, ZH_WR_BYTES>), dim3(a.nbufs), dim3(1024), 0, stream, d_src, d_dst, a, tok_pool, tok_off, ZhSegArgs{});
+  else if (th == 512u)
+    hipLaunchKernelGGL((zh_inflate_write_kernel<512, false, ZH_WR_BYTES>), dim3(a.nbufs), dim3(512), 0, stream, d_src, d_dst, a, tok_pool, tok_off, ZhSegArgs{});
   else
-    hipLaunchKernelGGL((zh_inflate_write_kernel<256, false, ZH_WR_BYTES>), dim3(a.nbufs), dim3(256), 0, stream, d_src, d_dst, a,
-                       tok_pool, tok_off, ZhSegArgs{});
+    hipLaunchKernelGGL((zh_inflate_write_kernel<256, false, ZH_WR_BYTES>), dim3(a.nbufs), dim3(256), 0, stream, d_src, d_dst, a, tok_pool, tok_off, ZhSegArgs{});
 }
