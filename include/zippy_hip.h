@@ -186,6 +186,11 @@ typedef struct zh_plan zh_plan;
 int zh_plan_compress(zh_ctx *ctx, size_t n, const uint64_t *src_off, const uint64_t *src_len,
                      const uint64_t *dst_off, const uint64_t *dst_cap, int level,
                      int data_format, zh_plan **out);
+/* An uncompress plan of a handful of streams (its longest stream weighs more than 1/40 of the batch
+ * + 8 MiB) decodes every stream of >= 128 KiB with many workgroups (block starts searched for,
+ * decoded from at once, proved afterwards; same bytes and statuses as one decoder per stream, which
+ * remains the fallback stream by stream).  Its scratch -- about 45 bytes per compressed byte --
+ * is allocated at the plan's first run; ZH_SEG=0 in the environment turns this off. */
 int zh_plan_uncompress(zh_ctx *ctx, size_t n, const uint64_t *src_off, const uint64_t *src_len,
                        const uint64_t *dst_off, const uint64_t *dst_cap, int data_format,
                        zh_plan **out);
