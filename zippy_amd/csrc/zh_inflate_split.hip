@@ -768,12 +768,11 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
   constexpr uint32_t kWrRing = kWrThreads * kR * 4u;  // token records staged in LDS (a power of two)
   __shared__ uint32_t s_tok[kWrRing];
   __shared__ uint32_t s_map32[kWrRound / 2];  // u16 per byte: (index in the round of the record that starts there) + 1
-  __shared__ uint32_t s_par32[kWrRound / 2];  // u16 per byte: the byte of this round it copies (itself: a root)
+  __shared__ uint32_t s_par32[2][kWrRound / 2];  // u16 per byte: the byte of this round it copies (itself: a root); two copies take turns
   __shared__ uint32_t s_val32[kWrRound * sizeof(Sym) / 4];  // a symbol per byte: its value (valid for roots)
   __shared__ uint32_t s_w[6][kWrWaves];       // per-wave partial results
   __shared__ uint32_t s_flag[4];              // round-wide flags (see below)
   uint16_t* const s_map = reinterpret_cast<uint16_t*>(s_map32);
-  uint16_t* const s_par = reinterpret_cast<uint16_t*>(s_par32);
   Sym* const s_val = reinterpret_cast<Sym*>(s_val32);
   const uint32_t tid = threadIdx.x, wv = tid >> 6;
   const unsigned lane = zh_lane();
@@ -838,8 +837,11 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
   };
   fetch_ahead();
   if (tid < 4) s_flag[tid] = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < kB / 2u; j++) s_map32[(kB / 2u) * tid + j] = 0;
 
   for (uint32_t round = 0;; round++) {
+    if (tid < 4) s_w[5][tid] = 0;  // (the pointer-doubling loop's flags)
     if (hi < ti + kWrRecs + 128u) {  // a round looks at kWrRecs records (+ 2 behind a stored-run record)
       commit_ahead();
       fetch_ahead();
@@ -849,25 +851,12 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
     uint32_t r[kR];
 #pragma unroll
     for (uint32_t k = 0; k < kR; k++) r[k] = s_tok[(uint32_t)(ti + i0 + k) & (kWrRing - 1u)];
-    // ---- records up to the first special one ----
-    {
-      uint32_t fw = 64u * kR;
-#pragma unroll
-      for (uint32_t k = 0; k < kR; k++) {
-        const uint64_t sp = __ballot((r[k] & kRecSpecial) != 0);
-        const uint32_t f = sp ? kR * ((uint32_t)__ffsll((long long)sp) - 1u) + k : 64u * kR;
-        fw = f < fw ? f : fw;
-      }
-      if (lane == 0) s_w[0][wv] = fw < 64u * kR ? wv * 64u * kR + fw : kWrRecs;
-    }
-    __syncthreads();
-    uint32_t fs = kWrRecs;
-#pragma unroll
-    for (uint32_t w = 0; w < kWrWaves; w++) fs = min(fs, s_w[0][w]);
+    // ---- the records that fit the round: a prefix, which ends at the first special record at the
+    // latest (it counts as longer than a round, so neither it nor anything behind it fits) ----
     uint32_t len[kR], sum = 0;
 #pragma unroll
     for (uint32_t k = 0; k < kR; k++) {
-      len[k] = i0 + k < fs ? r[k] & 0x1ffu : 0u;
+      len[k] = r[k] & kRecSpecial ? kWrRound + 1u : r[k] & 0x1ffu;
       sum += len[k];
     }
     const uint32_t incl = zh_wave_scan(sum);
@@ -886,7 +875,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
 #pragma unroll
       for (uint32_t k = 0; k < kR; k++) {
         o[k] = at;
-        fit[k] = i0 + k < fs && at + len[k] <= kWrRound;
+        fit[k] = at + len[k] <= kWrRound;
         if (fit[k]) endl = at + len[k];
         // inflate.nim:224-225 `distance > op` (a distance is at most 32768)
         bad = bad || (fit[k] && !((r[k] >> 9) & 1u) && (uint64_t)(r[k] >> 16) > gbase + op + at);
@@ -947,10 +936,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
       st = ZH_ERR_DST_TOO_SMALL;
       break;
     }
-    // ---- byte -> record ----
-#pragma unroll
-    for (uint32_t j = 0; j < kB / 2u; j++) s_map32[(kB / 2u) * tid + j] = 0;
-    __syncthreads();
+    // ---- byte -> record (the map is all zeros here: whoever reads a word clears it) ----
 #pragma unroll
     for (uint32_t k = 0; k < kR; k++)
       if (fit[k]) s_map[o[k]] = (uint16_t)(i0 + k + 1u);
@@ -961,6 +947,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
 #pragma unroll
       for (uint32_t j = 0; j < kB / 2u; j++) {
         const uint32_t w = s_map32[(kB / 2u) * tid + j];
+        s_map32[(kB / 2u) * tid + j] = 0;
         m = max(m, w & 0xffffu);
         t[2u * j] = m;
         m = max(m, w >> 16);
@@ -997,7 +984,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
     }
     if (any_near) s_flag[2u + (round & 1u)] = 1;
 #pragma unroll
-    for (uint32_t j = 0; j < kB / 2u; j++) s_par32[(kB / 2u) * tid + j] = par[2u * j] | (par[2u * j + 1u] << 16);
+    for (uint32_t j = 0; j < kB / 2u; j++) s_par32[0][(kB / 2u) * tid + j] = par[2u * j] | (par[2u * j + 1u] << 16);
     if (kSeg) {
 #pragma unroll
       for (uint32_t j = 0; j < kB / 2u; j++)
@@ -1010,26 +997,25 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
     }
     __syncthreads();
     if (s_flag[2u + (round & 1u)]) {
-      // par <- par[par] until every byte points at a root.  s_w[5][k & 1] counts the threads that
-      // moved in step k (cleared two steps ahead by thread 0, between the barriers).
-      if (tid == 0) s_w[5][0] = s_w[5][1] = 0;
-      __syncthreads();
+      // par <- par[par] until every byte points at a root: a step reads one copy of the pointers and
+      // writes the other, one barrier a step.  s_w[5][k & 3] says that somebody moved in step k (all
+      // four are cleared when a round starts, and two steps ahead by thread 0 in long loops).
       for (uint32_t k = 0;; k++) {
+        const uint16_t* const rd = reinterpret_cast<const uint16_t*>(s_par32[k & 1u]);
         bool changed = false;
 #pragma unroll
         for (uint32_t j = 0; j < kB; j++) {
-          const uint32_t q = s_par[par[j]];
+          const uint32_t q = rd[par[j]];
           changed |= q != par[j];
           par[j] = q;
         }
-        if (changed) s_w[5][k & 1u] = 1;
-        __syncthreads();
-        const bool again = s_w[5][k & 1u] != 0;
-        if (!again) break;
+        if (changed) s_w[5][k & 3u] = 1;
 #pragma unroll
-        for (uint32_t j = 0; j < kB / 2u; j++) s_par32[(kB / 2u) * tid + j] = par[2u * j] | (par[2u * j + 1u] << 16);
-        if (tid == 0) s_w[5][(k & 1u) ^ 1u] = 0;
+        for (uint32_t j = 0; j < kB / 2u; j++)
+          s_par32[(k & 1u) ^ 1u][(kB / 2u) * tid + j] = par[2u * j] | (par[2u * j + 1u] << 16);
+        if (tid == 0) s_w[5][(k + 2u) & 3u] = 0;
         __syncthreads();
+        if (!s_w[5][k & 3u]) break;
       }
 #pragma unroll
       for (uint32_t j = 0; j < kB; j++) val[j] = s_val[par[j]];
