@@ -34,16 +34,21 @@ __constant__ uint8_t c_clcl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4
 
 constexpr int kMaxSyms = 288;
 
+// 5.8 KiB, so that the kernel's LDS stays under 10 KiB and sixteen blocks share a CU (4096 blocks: one
+// round of the machine): children only for the internal nodes, and the quicksort stack and the depth
+// histogram of the length limiting live where the heap was.
 struct HuffWork {
-  uint64_t hkey[kMaxSyms];         // the heap: node frequency << 16 | node (one LDS read per comparison)
-  uint16_t left[2 * kMaxSyms];
-  uint16_t right[2 * kMaxSyms];
+  uint64_t hkey[kMaxSyms + 2];     // the heap: node frequency << 16 | node (one LDS read per comparison)
+  uint16_t left[kMaxSyms];         // of internal node i (n <= i < 2n - 1), at [i - n]
+  uint16_t right[kMaxSyms];
   uint16_t depth[2 * kMaxSyms];
   int16_t symbol[kMaxSyms];        // leaf -> symbol
   uint16_t order[kMaxSyms];        // leaves, sorted by depth when limiting
-  uint16_t stack[2 * kMaxSyms + 4];
-  int32_t histogram[2 * kMaxSyms];
+  // behind the heap phase, in hkey's bytes:
+  __device__ uint16_t* stack() { return reinterpret_cast<uint16_t*>(hkey); }                         // [2 * kMaxSyms + 4]
+  __device__ int32_t* histogram() { return reinterpret_cast<int32_t*>(hkey) + (kMaxSyms + 2); }     // [kMaxSyms + 2]
 };
+static_assert((2 * kMaxSyms + 4) * 2 <= (kMaxSyms + 2) * 4 && (kMaxSyms + 2) * 8 <= sizeof(uint64_t) * (kMaxSyms + 2), "");
 
 __device__ inline uint32_t rev16(uint32_t v) { return __brev(v) >> 16; }
 
@@ -133,8 +138,8 @@ __device__ int huffman_codes(const uint32_t* freq, int num_freq, int min_codes, 
     while (hlen >= 2) {  // :57-63
       const uint64_t l = heap_pop(w, hlen);
       const uint64_t r = heap_pop(w, hlen);
-      w.left[total] = (uint16_t)(l & 0xffffu);
-      w.right[total] = (uint16_t)(r & 0xffffu);
+      w.left[total - n] = (uint16_t)(l & 0xffffu);
+      w.right[total - n] = (uint16_t)(r & 0xffffu);
       w.hkey[hlen++] = (((l >> 16) + (r >> 16)) << 16) | (uint64_t)total;
       heap_sift_to_root(w, 0, hlen - 1);
       total++;
@@ -144,35 +149,37 @@ __device__ int huffman_codes(const uint32_t* freq, int num_freq, int min_codes, 
     w.depth[total - 1] = 0;
     for (int i = total - 1; i >= n; i--) {
       const uint16_t d = (uint16_t)(w.depth[i] + 1);
-      w.depth[w.left[i]] = d;
-      w.depth[w.right[i]] = d;
+      w.depth[w.left[i - n]] = d;
+      w.depth[w.right[i - n]] = d;
     }
     int longest = 0;
     for (int i = 0; i < n; i++)
       if (w.depth[i] > longest) longest = w.depth[i];
     if (longest > limit) {  // :78-131
-      for (int i = 0; i <= longest; i++) w.histogram[i] = 0;
-      for (int i = 0; i < n; i++) w.histogram[w.depth[i]]++;
+      uint16_t* const stack_ = w.stack();
+      int32_t* const hist_ = w.histogram();
+      for (int i = 0; i <= longest; i++) hist_[i] = 0;
+      for (int i = 0; i < n; i++) hist_[w.depth[i]]++;
       int i = longest;
       while (i > limit) {
-        if (w.histogram[i] == 0) {
+        if (hist_[i] == 0) {
           i--;
           continue;
         }
         int j = i - 2;
-        while (j > 0 && w.histogram[j] == 0) j--;
-        w.histogram[i] -= 2;
-        w.histogram[i - 1]++;
-        w.histogram[j + 1] += 2;
-        w.histogram[j]--;
+        while (j > 0 && hist_[j] == 0) j--;
+        hist_[i] -= 2;
+        hist_[i - 1]++;
+        hist_[j + 1] += 2;
+        hist_[j]--;
       }
       // :103-123 quickSort(nodes by depth), explicit stack instead of recursion
       int sp = 0;
-      w.stack[sp++] = 0;
-      w.stack[sp++] = (uint16_t)(n - 1);
+      stack_[sp++] = 0;
+      stack_[sp++] = (uint16_t)(n - 1);
       while (sp > 0) {
-        const int inr = (int16_t)w.stack[--sp];
-        const int inl = (int16_t)w.stack[--sp];
+        const int inr = (int16_t)stack_[--sp];
+        const int inl = (int16_t)stack_[--sp];
         int r = inr, l = inl;
         const int cnt = r - l + 1;
         if (cnt < 2) continue;
@@ -190,16 +197,16 @@ __device__ int huffman_codes(const uint32_t* freq, int num_freq, int min_codes, 
             r--;
           }
         }
-        w.stack[sp++] = (uint16_t)inl;
-        w.stack[sp++] = (uint16_t)(int16_t)r;
-        w.stack[sp++] = (uint16_t)l;
-        w.stack[sp++] = (uint16_t)inr;
+        stack_[sp++] = (uint16_t)inl;
+        stack_[sp++] = (uint16_t)(int16_t)r;
+        stack_[sp++] = (uint16_t)l;
+        stack_[sp++] = (uint16_t)inr;
       }
       int code_len = 1;
       for (int k = 0; k < n; k++) {  // :125-131
-        while (w.histogram[code_len] == 0) code_len++;
+        while (hist_[code_len] == 0) code_len++;
         w.depth[w.order[k]] = (uint16_t)code_len;
-        w.histogram[code_len]--;
+        hist_[code_len]--;
       }
     }
     for (int i = 0; i < n; i++) lens[w.symbol[i]] = (uint8_t)w.depth[i];
