@@ -129,6 +129,175 @@ def hbm_traffic(n, size):
     return {}
 
 
+def own_bytes(N, C):
+    """Algorithmic bytes a kernel has to move for a shard of N uncompressed / C compressed bytes
+    (DESIGN.md 5): the matchers read the source (N), emit reads it again and writes
+    the stream (N + C), the serial decoder reads the stream and writes the output (N + C); of the
+    split decoder's pair the tokens kernel must read the stream (C) and the writer must write the
+    output (N) -- the token records between them are this design's own traffic, not the
+    algorithm's, and show up in `traffic` instead; the checksum reads N."""
+    return {"zh_l1_match_kernel": N, "zh_chain_search_kernel": N, "zh_chain_walk_kernel": N,
+            "zh_l1p_match_kernel": N, "zh_emit_kernel": N + C, "zh_inflate_kernel": N + C,
+            "zh_inflate_tokens_kernel": C, "zh_inflate_write_kernel": N, "zh_checksum_pieces_kernel": N}
+
+
+def time_plans(torch, stream, cplan, uplan, bufs, steps, warmup, verify=None):
+    """`warmup` untimed passes (verified by `verify`), then `steps` timed ones with HIP events on
+    the launch stream: (compress ms, uncompress ms, per-kernel average ms)."""
+    d_src, d_comp, d_back = bufs
+    for _ in range(max(warmup, 1)):
+        if cplan is not None:
+            cplan.run(d_src.data_ptr(), d_comp.data_ptr())
+        if uplan is not None:
+            uplan.run(d_comp.data_ptr(), d_back.data_ptr())
+    torch.cuda.synchronize()
+    if verify:
+        verify()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tc = tu = 0.0
+    kms = {}
+    for _ in range(steps):
+        ev[0].record(stream)
+        if cplan is not None:
+            cplan.run(d_src.data_ptr(), d_comp.data_ptr())
+        ev[1].record(stream)
+        if uplan is not None:
+            uplan.run(d_comp.data_ptr(), d_back.data_ptr())
+        ev[2].record(stream)
+        ev[2].synchronize()
+        tc += ev[0].elapsed_time(ev[1])
+        tu += ev[1].elapsed_time(ev[2])
+        for pl in (cplan, uplan):
+            if pl is not None:
+                for name, ms in pl.kernel_times():
+                    kms.setdefault(name, []).append(ms)
+    if not steps:
+        return 0.0, 0.0, {}
+    return tc / steps, tu / steps, {k: sum(v) / len(v) for k, v in kms.items()}
+
+
+def side_configs(torch, eng, api, synth, stream, host, steps):
+    """BASELINE.json configs 2-5 on this GPU, a few steps each, after the headline: one entry per
+    config with its throughput (uncompressed GiB/s over the timed passes), ratio, dominant kernel
+    and that kernel's fraction of the HBM roof.  Inputs resident in HBM, round trips verified."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    out = {}
+
+    def entry(workload, nbytes, comp_bytes, tc, tu, kms):
+        ms = (tc if tc else 0.0) + (tu if tu else 0.0)
+        own = own_bytes(nbytes, comp_bytes)
+        dom = max((k for k in kms if k.startswith("zh_")), key=lambda k: kms[k])
+        e = {"workload": workload, "value": round(nbytes / GIB / (ms * 1e-3), 3), "unit": "GiB/s",
+             "ms_per_step": round(ms, 3), "ratio": round(nbytes / comp_bytes, 4),
+             "dominant_kernel": dom, "dominant_kernel_ms": round(kms[dom], 4),
+             "frac": round(own.get(dom, nbytes + comp_bytes) / (kms[dom] * 1e-3) / HBM_PEAK, 6),
+             "kernels_ms": {k: round(v, 4) for k, v in sorted(kms.items(), key=lambda kv: -kv[1]) if k != "end"}}
+        if tc and tu:
+            e["compress_GiBps"] = round(nbytes / GIB / (tc * 1e-3), 3)
+            e["uncompress_GiBps"] = round(nbytes / GIB / (tu * 1e-3), 3)
+        return e
+
+    def batch(tag, workload, n, size, level, do_c, do_u, foreign=None, nsteps=steps):
+        data = host.reshape(-1)[:n * size].reshape(n, size)
+        d_src = torch.from_numpy(data.reshape(-1)).cuda()
+        cap = size + size // 8 + 2048
+        slot = (cap + 255) & ~255
+        d_comp = torch.empty(n * slot, dtype=torch.uint8, device="cuda")
+        d_back = torch.empty(n * size, dtype=torch.uint8, device="cuda")
+        src_off = [i * size for i in range(n)]
+        comp_off = [i * slot for i in range(n)]
+        cplan = uplan = None
+        comp_lens = None
+        if foreign is None:
+            cplan = eng.plan_compress(src_off, [size] * n, comp_off, [cap] * n, level, api.dfGzip)
+            cplan.set_profiling(True)
+        else:
+            def gz(i):
+                c = zlib.compressobj(foreign, zlib.DEFLATED, 31)
+                return c.compress(data[i].tobytes()) + c.flush()
+            with ThreadPoolExecutor(min(os.cpu_count() or 1, 32)) as ex:
+                blobs = list(ex.map(gz, range(n)))
+            comp_lens = [len(b) for b in blobs]
+            stage = torch.zeros(n * slot, dtype=torch.uint8)
+            sv = stage.numpy()
+            for i, b in enumerate(blobs):
+                sv[i * slot:i * slot + len(b)] = memoryview(b)
+            d_comp.copy_(stage)
+            del stage, sv, blobs
+        if do_u or foreign is not None:
+            uplan = eng.plan_uncompress(comp_off, comp_lens or [cap] * n, src_off, [size] * n, api.dfGzip)
+            if comp_lens is None:
+                uplan.set_src_lens_device(cplan.device_lens())
+            uplan.set_profiling(True)
+        state = {}
+
+        def verify():
+            if cplan is not None:
+                clens, csts = cplan.results()
+                assert all(x == 0 for x in csts), tag
+                state["C"] = sum(clens)
+            else:
+                state["C"] = sum(comp_lens)
+            if uplan is not None:
+                ulens, usts = uplan.results()
+                assert all(x == 0 for x in usts) and ulens == [size] * n, tag
+                assert torch.equal(d_back, d_src), tag
+            else:  # compress only: the streams must still decode (device decoder, CRC-32 checked)
+                chk = eng.plan_uncompress(comp_off, [cap] * n, src_off, [size] * n, api.dfGzip)
+                chk.set_src_lens_device(cplan.device_lens())
+                chk.run(d_comp.data_ptr(), d_back.data_ptr())
+                ulens, usts = chk.results()
+                assert all(x == 0 for x in usts) and torch.equal(d_back, d_src), tag
+                chk.close()
+
+        # warm-up runs both plans that exist; the timed loop only the legs the config names
+        time_plans(torch, stream, cplan, uplan, (d_src, d_comp, d_back), 0, 1, verify)
+        tc, tu, kms = time_plans(torch, stream, cplan if do_c else None, uplan if do_u else None,
+                                 (d_src, d_comp, d_back), nsteps, 0)
+        out[tag] = entry(workload, n * size, state["C"], tc if do_c else None, tu if do_u else None, kms)
+        for pl in (cplan, uplan):
+            if pl is not None:
+                pl.close()
+        del d_src, d_comp, d_back
+        torch.cuda.empty_cache()
+
+    nb = host.shape[0]
+    batch("c2", "config 2: 1024 x 64 KiB, compress BestSpeed gzip", min(1024, nb * 16), 65536, 1, True, False)
+    batch("c3_own", "config 3: %d x 1 MiB uncompress only (this library's BestSpeed streams), CRC-32 verified" % nb,
+          nb, 1 << 20, 1, False, True)
+    batch("c3_zlib6", "config 3: %d x 1 MiB uncompress only, gzip members made by system zlib level 6 "
+          "(multi-block dynamic streams), CRC-32 verified" % nb, nb, 1 << 20, 1, False, True, foreign=6)
+    share = max(1, nb // 8)
+    batch("c4_share", "config 4: one GPU's share of eight (%d x 1 MiB), compress DefaultCompression gzip" % share,
+          share, 1 << 20, -1, True, False, nsteps=max(2, steps // 2))
+
+    # config 5: ONE large buffer as independent 32 KiB deflate blocks (tools/bench_c5.py)
+    mib = min(128, nb)
+    size = mib << 20
+    d_src = torch.from_numpy(host.reshape(-1)[:size]).cuda()
+    cap = size + size // 8 + 1024 * (size // 32768 + 1) + 4096
+    d_comp = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    d_back = torch.empty(size, dtype=torch.uint8, device="cuda")
+    cplan = eng.plan_compress_blocks([0], [size], [0], [cap], 1, api.dfGzip, 32768)
+    cplan.set_profiling(True)
+    cplan.run(d_src.data_ptr(), d_comp.data_ptr())
+    (clen,), (cst,) = cplan.results()
+    assert cst == 0, cst
+    uplan = eng.plan_uncompress_indexed(0, clen, 0, size, cplan.block_index(0), api.dfGzip)
+    uplan.set_profiling(True)
+
+    def verify5():
+        (ulen,), (ust,) = uplan.results()
+        assert ust == 0 and ulen == size and torch.equal(d_back, d_src), "config 5"
+    tc, tu, kms = time_plans(torch, stream, cplan, uplan, (d_src, d_comp, d_back), steps, 1, verify5)
+    out["c5"] = entry("config 5: 1 x %d MiB as independent 32 KiB deflate blocks, compress BestSpeed gzip + "
+                      "indexed uncompress" % mib, size, clen, tc, tu, kms)
+    cplan.close()
+    uplan.close()
+    return out
+
+
 def relaunch_under_torchrun(args):
     import socket
     import subprocess
@@ -162,6 +331,8 @@ def main():
                     help="BASELINE config 3: time only the uncompress pass (inflate + CRC-32)")
     ap.add_argument("--compress-only", action="store_true", help="BASELINE configs 2/4: time only the compress pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip BASELINE configs 2-5 (run after the headline at N=1 with the default workload)")
     ap.add_argument("--no-transfer", action="store_true", help="skip the RCCL scatter/gather leg (N > 1)")
     args = ap.parse_args()
     if args.foreign is not None:
@@ -318,8 +489,7 @@ def main():
         # once and every compressed byte once (N + C); a kernel is charged what IT must move:
         # matcher N (reads the source), emit N + C, inflate C + N, checksum N.
         N, C = n * size, comp_total
-        own = {"zh_l1_match_kernel": N, "zh_chain_search_kernel": N, "zh_emit_kernel": N + C,
-               "zh_inflate_kernel": N + C, "zh_checksum_pieces_kernel": N}
+        own = own_bytes(N, C)
         traffic = hbm_traffic(n, size)
 
         def roof(nbytes, ms, name=None):
@@ -342,7 +512,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": scaling,
+            "scaling": scaling if world > 1 else None,  # one GPU: nothing is scaled
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic (G-mix: seeded slices of the reference's own test corpus, SURVEY.md 8d)",
@@ -370,6 +540,15 @@ def main():
         if transfer:
             out["transfer"] = transfer
             out["value_incl_transfer"] = transfer["value_incl_transfer"]
+        headline = (world == 1 and do_c and do_u and args.foreign is None and args.level == 1
+                    and size == 1 << 20 and n >= 8)
+        if headline and not args.no_configs:
+            # the other BASELINE configs, so that the driver's line carries all five
+            cplan.close()
+            uplan.close()
+            del d_comp, d_back, d_src
+            torch.cuda.empty_cache()
+            out["configs"] = side_configs(torch, eng, api, synth, stream, host, max(2, min(args.steps, 5)))
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             cores = min(os.cpu_count() or 1, 32)
             per_core = max(1, min(64, (16 << 20) // size))  # ~0.1 s a repetition: ten of them are not noise
