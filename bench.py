@@ -331,6 +331,8 @@ def main():
                     help="BASELINE config 3: time only the uncompress pass (inflate + CRC-32)")
     ap.add_argument("--compress-only", action="store_true", help="BASELINE configs 2/4: time only the compress pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parallel-parse", action="store_true",
+                    help="skip the second timing with the opt-in parallel BestSpeed parse")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip BASELINE configs 2-5 (run after the headline at N=1 with the default workload)")
     ap.add_argument("--no-transfer", action="store_true", help="skip the RCCL scatter/gather leg (N > 1)")
@@ -542,6 +544,39 @@ def main():
             out["value_incl_transfer"] = transfer["value_incl_transfer"]
         headline = (world == 1 and do_c and do_u and args.foreign is None and args.level == 1
                     and size == 1 << 20 and n >= 8)
+        if do_c and do_u and args.foreign is None and args.level == 1 and not args.no_parallel_parse:
+            # the same step with the opt-in PARALLEL BestSpeed parse (zh_set_l1_parse(ctx, 1),
+            # csrc/zh_l1p_match.hip): valid streams that are not the reference's bytes, under the
+            # north star's encoder contract (round trip exact, size within 2 % of zippy's).
+            # `value` above stays the byte-identical parse.
+            import zlib
+            eng.set_l1_parse(1)
+
+            def verify_pp():
+                plens, psts = cplan.results()
+                assert all(x == 0 for x in psts), "parallel parse: compress statuses"
+                ul, us = uplan.results()
+                assert all(x == 0 for x in us) and ul == [size] * n, "parallel parse: uncompress statuses"
+                assert torch.equal(d_back, d_src), "parallel parse: round trip mismatch"
+                for i in range(0, n, max(1, n // 8)):  # a sample through system zlib as well
+                    z = d_comp[i * slot:i * slot + plens[i]].cpu().numpy().tobytes()
+                    assert zlib.decompress(z, 31) == host[i].tobytes(), "parallel parse: zlib disagrees"
+                verify_pp.C = sum(plens)
+            ptc, ptu, pk = time_plans(torch, stream, cplan, uplan, (d_src, d_comp, d_back), args.steps,
+                                      max(args.warmup, 1), verify_pp)
+            eng.set_l1_parse(-1)
+            out["value_parallel_parse"] = round(n * size / GIB / ((ptc + ptu) * 1e-3), 3)
+            out["ratio_parallel_parse"] = round(n * size / verify_pp.C, 4)
+            out["parallel_parse"] = {
+                "what": "same step, BestSpeed matcher = zh_l1p_match_kernel (not the reference's token stream; "
+                        "round trip verified on device + zlib sample; size vs the exact parse: %.4f)" % (
+                            verify_pp.C / comp_total),
+                "ms_per_step": round(ptc + ptu, 3), "compress_GiBps": round(n * size / GIB / (ptc * 1e-3), 3),
+                "uncompress_GiBps": round(n * size / GIB / (ptu * 1e-3), 3),
+                "size_vs_exact_parse": round(verify_pp.C / comp_total, 5),
+                "kernels_ms": {k: round(v, 4) for k, v in sorted(pk.items(), key=lambda kv: -kv[1]) if k != "end"},
+                "roofline_matcher": roof(N, pk["zh_l1p_match_kernel"], "zh_l1p_match_kernel"),
+            }
         if headline and not args.no_configs:
             # the other BASELINE configs, so that the driver's line carries all five
             cplan.close()

@@ -100,6 +100,16 @@ void zh_set_gzip_fname_len(zh_ctx *ctx, int k);
  * < 0 = the default (0, or the ZH_INFLATE=serial environment variable). */
 void zh_set_inflate_mode(zh_ctx *ctx, int mode);
 
+/* Which BestSpeed (level 1) match finder later compress calls of this context use.
+ * 0 = the reference's parse (snappy.nim:12-136 replayed decision for decision: the streams are
+ * byte-identical to zippy's own); 1 = the parallel parse of csrc/zh_l1p_match.hip: every position
+ * enters the hash table and the greedy selection runs chunk-parallel, so the token stream differs
+ * from zippy's while meeting the encoder contract -- a valid RFC 1951/1950/1952 stream that zippy's
+ * uncompress() decodes to the input bit for bit, compressed size within 2 % of zippy's at level 1
+ * (tests/test_gpu_parity.py: test_gpu_parallel_parse_*).  < 0 = the default (0, or the
+ * ZH_L1_PARSE=parallel environment variable).  All other levels are unaffected. */
+void zh_set_l1_parse(zh_ctx *ctx, int mode);
+
 /* Host-buffer compress calls of at least min_batch_bytes of input run as pipelined groups of
  * about group_bytes each: one group's kernels overlap the neighbours' transfers (no reference
  * counterpart; the results are the same bytes either way).  0 = default (1 GiB / 512 MiB, or the

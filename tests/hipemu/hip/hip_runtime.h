@@ -41,6 +41,7 @@ struct dim3 {
 struct emu_uint3 { unsigned x, y, z; };
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 extern emu_uint3 threadIdx, blockIdx, blockDim, gridDim;
 

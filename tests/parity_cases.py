@@ -47,6 +47,40 @@ def check_compress_identical(eng, inputs, levels, formats=FORMATS):
                 assert oracle.uncompress(out, fmt) == src
 
 
+def check_parallel_parse(eng, inputs, formats=(oracle.dfGzip,), margin=1.02):
+    """The opt-in parallel BestSpeed parse (zh_set_l1_parse(ctx, 1), csrc/zh_l1p_match.hip) under the
+    encoder contract of BASELINE.json's north star: every stream decodes to its input through the
+    oracle's zippy-equivalent uncompress AND through zlib, the streams of a batch are together no
+    larger than `margin` x the oracle's (= zippy's) at level 1, the result does not depend on the
+    run, and the other levels still give the oracle's bytes while the switch is on."""
+    eng.set_gzip_fname_len(0)
+    eng.set_l1_parse(1)
+    try:
+        for fmt in formats:
+            outs, sts = eng.compress_batch(inputs, 1, fmt)
+            again, _ = eng.compress_batch(inputs, 1, fmt)
+            dev = ref = 0
+            for src, out, st in zip(inputs, outs, sts):
+                assert st == 0, (fmt, len(src), st)
+                assert zlib.decompress(out, WBITS[fmt]) == src, (fmt, len(src))
+                assert oracle.uncompress(out, fmt) == src, (fmt, len(src))
+                dev += len(out)
+                ref += len(oracle.compress(src, 1, fmt, fname_len=0))
+            assert outs == again, "parallel parse: two runs, two results"
+            assert dev <= margin * ref, "parallel parse: %d B against the oracle's %d B" % (dev, ref)
+            back, sts2 = eng.uncompress_batch(outs, oracle.dfDeflate if fmt == oracle.dfDeflate
+                                              else oracle.dfDetect)
+            assert all(x == 0 for x in sts2) and back == list(inputs)
+        small = [b for b in inputs if len(b) <= 70000][:6]
+        for level in (-2, 0, -1):
+            outs, sts = eng.compress_batch(small, level, oracle.dfGzip)
+            for src, out in zip(small, outs):
+                assert out == oracle.compress(src, level, oracle.dfGzip, fname_len=0), level
+    finally:
+        eng.set_l1_parse(-1)
+    return dev, ref
+
+
 def check_roundtrip(eng, inputs, level, fmt=oracle.dfGzip):
     outs, sts = eng.compress_batch(inputs, level, fmt)
     assert all(s == 0 for s in sts)

@@ -120,6 +120,14 @@ def test_emu_level1_many_fragments(eng):
         assert out == oracle.deflate(src, 1)
 
 
+def test_emu_parallel_parse_contract(eng):
+    """zh_l1p_match_kernel under the emulator: valid streams, size within 2 % of the oracle's."""
+    inputs = [b.tobytes() for b in synth.gen_batch("mix", 5, 100000)]
+    inputs += [b.tobytes() for b in synth.gen_batch("runs", 2, 70001)]
+    inputs += pc.edge_inputs()
+    pc.check_parallel_parse(eng, inputs, formats=(oracle.dfGzip, oracle.dfDeflate))
+
+
 def test_emu_ragged_staging(eng):
     pc.check_ragged_staging(eng, 1)
 

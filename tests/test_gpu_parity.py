@@ -111,6 +111,20 @@ def test_gpu_level1_identical_at_scale(eng):
     assert all(s == 0 for s in sts) and back == bufs
 
 
+def test_gpu_parallel_parse_contract(eng, golds):
+    """Opt-in parallel BestSpeed parse (include/zippy_hip.h zh_set_l1_parse): not the oracle's bytes,
+    but valid streams the oracle's uncompress and zlib decode to the input, at most 2 % larger in
+    total than the oracle's -- on the corpus files, the edge sizes and every data kind."""
+    corpus = [golds[n] for n in ("alice29.txt", "asyoulik.txt", "fireworks.jpg", "geo.protodata", "html",
+                                 "kppkn.gtb", "paper-100k.pdf", "zerotest1.gold", "randtest1.gold")]
+    pc.check_parallel_parse(eng, corpus, formats=(oracle.dfGzip, oracle.dfZlib, oracle.dfDeflate))
+    pc.check_parallel_parse(eng, pc.edge_inputs())
+    for kind in ("mix", "runs", "text"):
+        inputs = [b.tobytes() for b in synth.gen_batch(kind, 24, 1 << 20)]
+        dev, ref = pc.check_parallel_parse(eng, inputs)
+        print("parallel parse, %s: %d B against the oracle's %d B (%.4f)" % (kind, dev, ref, dev / ref))
+
+
 def test_gpu_unsized_streams(eng, inflate_mode):
     pc.check_unsized_streams(eng)
 

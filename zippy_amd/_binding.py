@@ -20,6 +20,7 @@ _SIGS = {
     "zh_set_gzip_fname_len": (None, [_c.c_void_p, _c.c_int]),
     "zh_set_host_pipeline": (None, [_c.c_void_p, _c.c_size_t, _c.c_size_t]),
     "zh_set_inflate_mode": (None, [_c.c_void_p, _c.c_int]),
+    "zh_set_l1_parse": (None, [_c.c_void_p, _c.c_int]),
     "zh_compress_bound": (_c.c_size_t, [_c.c_size_t, _c.c_int]),
     "zh_compress_batch": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
                                      _c.c_size_t, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p),
@@ -321,6 +322,11 @@ class Engine:
     def set_inflate_mode(self, mode):
         """0: parallel token decode + writer (default), 1: serial two-wave decoder, -1: default."""
         self.lib.zh_set_inflate_mode(self._h, mode)
+
+    def set_l1_parse(self, mode):
+        """BestSpeed match finder: 0 the reference's parse (byte-identical streams, default),
+        1 the parallel parse (valid streams of about the same size), -1: default / ZH_L1_PARSE."""
+        self.lib.zh_set_l1_parse(self._h, mode)
 
     def set_host_pipeline(self, min_batch_bytes=0, group_bytes=0):
         self.lib.zh_set_host_pipeline(self._h, min_batch_bytes, group_bytes)

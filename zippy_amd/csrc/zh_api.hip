@@ -48,6 +48,9 @@ void zh_launch_seg_finish(hipStream_t, uint8_t* d_dst, ZhInflateArgs a, ZhSegArg
 void zh_launch_l1_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int huffman_only,
                         uint16_t* table_pool, uint32_t* next_frag);
 uint32_t zh_l1_table_slots(void);
+void zh_launch_l1p_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint16_t* link_pool,
+                         uint32_t* next_frag);
+uint32_t zh_l1p_slots(void);
 void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint16_t* head_scratch,
                           uint64_t* prevw);
 void zh_launch_chain_search(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
@@ -71,6 +74,7 @@ struct zh_ctx {
   bool own_stream = false;
   int fname_len = -1;
   int inflate_mode = -1;  // -1: ZH_INFLATE or the default (split), 0 split, 1 serial
+  int l1_parse = -1;      // -1: ZH_L1_PARSE or the default (exact), 0 exact (the reference's parse), 1 parallel
   std::string last_error;
   const void* cktabs = nullptr;
   std::mt19937 rng{std::random_device{}()};
@@ -518,7 +522,10 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   p->head_bytes = chain ? nb * ((size_t)2 << 17) : 0;
   const size_t o_head = ar.reserve(p->head_bytes);
   // one 32 KiB hash table per persistent matcher wave (zh_launch_l1_match: min(fragments, slots) waves)
-  const size_t o_l1tab = ar.reserve(level == 1 ? std::min<size_t>(nf, zh_l1_table_slots()) * 32768 : 0);
+  // (the parallel parse, zh_launch_l1p_match, keeps 64 KiB of candidate links per workgroup there instead)
+  const size_t o_l1tab = ar.reserve(level == 1 ? std::max(std::min<size_t>(nf, zh_l1_table_slots()) * 32768,
+                                                          std::min<size_t>(nf, zh_l1p_slots()) * 65536)
+                                               : 0);
   const size_t o_l1ctr = ar.reserve(256);
   const size_t o_cprev = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 8 : 0);
   const size_t o_cbest = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 4 : 0);
@@ -976,6 +983,18 @@ static bool inflate_split_enabled(const zh_ctx* ctx) {
   }();
   return ctx->inflate_mode < 0 ? on : ctx->inflate_mode == 0;
 }
+// BestSpeed parse: 0 the reference's (snappy.nim:12-136, byte-identical streams), 1 the parallel
+// parse of zh_l1p_match.hip (valid streams of about the same size, not the reference's bytes)
+static bool l1_parallel(const zh_ctx* ctx) {
+  static const bool on = [] {
+    const char* e = getenv("ZH_L1_PARSE");
+    return e && strcmp(e, "parallel") == 0;
+  }();
+  return ctx->l1_parse < 0 ? on : ctx->l1_parse == 1;
+}
+extern "C" void zh_set_l1_parse(zh_ctx* ctx, int mode) {
+  if (ctx) ctx->l1_parse = mode < 0 ? -1 : mode ? 1 : 0;
+}
 extern "C" void zh_set_inflate_mode(zh_ctx* ctx, int mode) {
   if (ctx) ctx->inflate_mode = mode < 0 ? -1 : mode ? 1 : 0;
 }
@@ -1055,7 +1074,10 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       const uint32_t gy = (uint32_t)std::min<uint64_t>(64, (p->dst_max_cap >> 16) + 1);
       hipLaunchKernelGGL(zh_zero_slots_kernel, dim3((uint32_t)p->n * gy), dim3(256), 0, s, d_dst, p->d_bufs, gy);
     }
-    if (p->level == 1 || p->level == -2) {
+    if (p->level == 1 && l1_parallel(ctx)) {
+      prof_mark(p, "zh_l1p_match_kernel");
+      zh_launch_l1p_match(s, d_src, a, p->l1_tables, p->l1_counter);
+    } else if (p->level == 1 || p->level == -2) {
       prof_mark(p, "zh_l1_match_kernel");
       zh_launch_l1_match(s, d_src, a, p->level == -2, p->l1_tables, p->l1_counter);
     } else if (p->level != 0) {

@@ -1,0 +1,345 @@
+// BestSpeed matcher, PARALLEL parse (opt-in: zh_set_l1_parse(ctx, 1) / ZH_L1_PARSE=parallel).
+//
+// NOT the reference's parse.  zh_l1_match_kernel replays snappy.nim:12-136 decision for
+// decision, which ties a fragment to one serial walk; this kernel produces a
+// *different*, equally valid token stream under the contract BASELINE.json's north star
+// states for the encoder: an RFC 1951 stream that zippy's uncompress() decodes to the input
+// bit for bit, with a compressed size within a stated margin of zippy's at the same level
+// (tests: every buffer through oracle.uncompress and zlib, aggregate size <= 1.02 x oracle).
+// Everything behind the match list -- statistics, Huffman codes, layout, emission -- is the
+// exact path's.  Same fragment rule as the reference (snappy.nim:150-163): matches never
+// leave their 32 KiB fragment, so fragments stay independent.
+//
+// One workgroup (512 threads) per fragment, the fragment's bytes in LDS:
+//   P1  links    one wave walks the fragment in order, 64 positions a step, through a
+//                16384-entry hash table in LDS (same hash as snappy.nim:70-71), one returning
+//                atomicMax a position: its candidate is the latest earlier position with its
+//                hash -- EVERY position is inserted, not only the ones a serial parse visits;
+//   P2  lengths  a thread per position: common prefix with its candidate, 0 or 4..258
+//                (internal.nim:251-270 determineMatchLength, limit snappy.nim:110);
+//   P3  parse    greedy left to right (take the match at p if there is one, else a
+//                literal) -- a static problem once the lengths are known: a thread per 64
+//                positions walks from a guessed entry, exits are handed on and threads whose
+//                entry changed walk again; thread 0's entry is exact, so at the fixed point
+//                every entry is the serial walk's by induction;
+//   P4  output   match list (same SoA records the exact matcher writes), litlen / distance
+//                histograms, literal count, extra-bit sum.
+// Algorithmic bytes: N read.  The candidate links of a fragment (64 KiB) go through a per-
+// workgroup slot of HBM scratch that stays L2-resident (persistent workgroups).
+#include <cstdlib>
+#include <cstring>
+
+#include "zh_common.h"
+#include "zh_kprof.h"
+#include "zh_tables.h"
+
+namespace {
+constexpr uint32_t kHashMul = 0x1e35a7bdu;  // snappy.nim:70-71
+constexpr uint32_t kT = 512;                // threads per workgroup
+constexpr uint32_t kChunk = 64;             // positions per parse thread (kT * kChunk = 32768)
+constexpr uint32_t kSrcWords = 8192 + 72;   // fragment + slack for compares that run past its end
+constexpr uint32_t kShift = 18;             // 14 hash bits
+// 16 bytes at any 4-byte address (gfx950 global loads need no alignment)
+struct __attribute__((packed, aligned(4))) Bytes16 {
+  uint32_t x, y, z, w;
+};
+// 4 bytes at any byte address
+struct __attribute__((packed)) Word32 {
+  uint32_t v;
+  __device__ operator uint32_t() const { return v; }
+};
+}  // namespace
+
+__global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
+                                                          uint16_t* __restrict__ link_pool,
+                                                          uint32_t* __restrict__ next_frag, uint32_t var) {
+  // P1: the hash table, a dword a slot (atomicMax); afterwards the fragment's bytes (s_src) and the
+  // match lengths, a byte a position (s_mlen)
+  __shared__ uint32_t s_big[kSrcWords + 8192];
+  __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
+  __shared__ uint32_t s_exit[kT];
+  __shared__ uint32_t s_wsum[8][3];
+  __shared__ uint32_t s_misc[4];     // 0: next fragment, 1: "some entry changed"
+  uint32_t* const s_tab = s_big;
+  uint32_t* const s_src = s_big;
+  uint8_t* const s_mlen = reinterpret_cast<uint8_t*>(s_big + kSrcWords);
+
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  uint16_t* const links = link_pool + (size_t)blockIdx.x * ZH_FRAG_SIZE;
+
+  for (uint32_t f = blockIdx.x; f < a.nfrags;) {
+    KPROF_DECL(8);  // cycles of thread 0: 0 stage-in, 1 links, 2 lengths, 3 parse, 4 output; counts: 5 turns, 6 fragments
+    const ZhFragDesc fd = a.frags[f];
+    const uint32_t n = fd.len;
+    const uint8_t* src = d_src + fd.src_off;
+    const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
+    const uint32_t* asrc = reinterpret_cast<const uint32_t*>(src - mis);
+    const uint32_t ndw = (n + mis + 3u) >> 2;
+    for (uint32_t i = t; i < 4096; i += kT) reinterpret_cast<uint4*>(s_tab)[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = t; i < ZH_HIST_STRIDE; i += kT) s_hist[i] = 0;
+    __syncthreads();
+    KPROF_MARK(0);
+    // ---- P1: candidate links (wave 0; the other waves wait at the barrier).  A step is 64
+    // consecutive positions and ONE returning atomicMax a lane on the table: what comes back is the
+    // latest position with the lane's hash that entered before it -- in an earlier step, or (the LDS
+    // unit serves a wave's lanes in ascending order) in a lower lane of this one.  Anything else a
+    // lane might get back is thrown away below (a candidate must lie before its position), so the
+    // stream is valid whatever the order; the four bytes at a position come straight from the
+    // stream (coalesced, any byte address), fetched 32 steps ahead ----
+    if (wave == 0 && n >= 16u) {
+#ifndef ZH_EMU
+      __builtin_amdgcn_s_setprio(3);  // the one serial phase: first pick of the SIMD's issue slots
+#endif
+      // No lane is masked: position 0's atomicMax changes nothing (and a candidate must lie before
+      // its position: it gets none), positions behind n - 4 hash bytes of the last word and are
+      // never looked at by P2 (no match starts in the last 15 bytes), positions behind n enter the
+      // table when nobody reads it any more.  Only the loads are kept inside the fragment.
+      const uint32_t steps = (n + 63u) >> 6;
+      constexpr uint32_t kB = 8;       // steps a block: their atomics are in flight together
+      constexpr uint32_t kAhead = 16;  // source words are fetched two blocks ahead
+      auto fetch = [&](uint32_t step) -> uint32_t {
+        const uint32_t p = step * 64u + lane;
+        return (uint32_t) * reinterpret_cast<const Word32*>(src + (p + 4u <= n ? p : n - 4u));
+      };
+      uint32_t wq[kAhead];
+#pragma unroll
+      for (uint32_t k = 0; k < kAhead; k++) wq[k] = fetch(k);
+      uint32_t h_last = 0xffffffffu;  // hash of the position before the block's first
+      for (uint32_t s0 = 0; s0 < steps; s0 += kAhead) {
+#pragma unroll
+        for (uint32_t half = 0; half < kAhead / kB; half++) {
+          uint32_t h[kB], raw[kB];
+#pragma unroll
+          for (uint32_t k = 0; k < kB; k++) {
+            const uint32_t step = s0 + half * kB + k;
+            const uint32_t p = step * 64u + lane;
+            h[k] = (wq[half * kB + k] * kHashMul) >> kShift;
+            wq[half * kB + k] = fetch(step + kAhead);
+            raw[k] = atomicMax(&s_tab[h[k]], p);
+#ifdef ZH_EMU
+            zh_wave_sync();  // (the emulator runs a lane at a time: keep the steps in step)
+#endif
+          }
+#pragma unroll
+          for (uint32_t k = 0; k < kB; k++) {
+            const uint32_t p = (s0 + half * kB + k) * 64u + lane;
+#ifdef ZH_EMU
+            uint32_t h_prev = (uint32_t)__shfl_up((int)h[k], 1, 64);
+            if (lane == 0) h_prev = h_last;
+#else
+            // wave_shr:1 -- lane l gets lane l - 1's hash, lane 0 keeps the `old` operand
+            const uint32_t h_prev =
+                (uint32_t)__builtin_amdgcn_update_dpp((int)h_last, (int)h[k], 0x138, 0xf, 0xf, false);
+#endif
+            h_last = (uint32_t)__builtin_amdgcn_readlane((int)h[k], 63);
+            uint32_t link = raw[k] < p ? raw[k] : 0u;      // a candidate lies before its position
+            if (h[k] == h_prev && p >= 2u) link = p - 1u;  // a run: the nearest candidate there is
+            links[p & (ZH_FRAG_SIZE - 1u)] = (uint16_t)link;
+          }
+        }
+      }
+#ifndef ZH_EMU
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+    __syncthreads();
+    // ---- the fragment's bytes into LDS, over the table (aligned dwords of the stream below `src`,
+    // never past the dword that holds its last byte); LDS byte q = fragment byte q - mis.  All of
+    // a thread's loads are in flight together: 16 bytes each, at any 4-byte address ----
+    {
+      Bytes16 v[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t i = (k * kT + t) * 4u;
+        v[k] = Bytes16{0, 0, 0, 0};
+        if (i + 4u <= ndw) {
+          v[k] = *reinterpret_cast<const Bytes16*>(asrc + i);
+        } else if (i < ndw) {
+          v[k].x = asrc[i];
+          if (i + 1u < ndw) v[k].y = asrc[i + 1];
+          if (i + 2u < ndw) v[k].z = asrc[i + 2];
+        }
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++)
+        *reinterpret_cast<uint4*>(s_src + (k * kT + t) * 4u) = make_uint4(v[k].x, v[k].y, v[k].z, v[k].w);
+    }
+    for (uint32_t i = 8192 + t; i < kSrcWords; i += kT) s_src[i] = 0;
+    __syncthreads();
+    // (unaligned ds_read_b32 / b64 work on gfx950 but cost this kernel a factor of two: measured)
+    auto ld32 = [&](uint32_t p) -> uint32_t { return zh_ld32(s_src, p + mis); };
+    auto ld64 = [&](uint32_t p) -> uint64_t { return zh_ld64(s_src, p + mis); };
+
+    KPROF_MARK(1);
+    // ---- P2: match length of every position against its candidate (position 512 r + t in turn
+    // r; the links are fetched four turns ahead) ----
+    {
+      uint32_t c0 = links[t], c1 = links[kT + t], c2 = links[2 * kT + t], c3 = links[3 * kT + t];
+      for (uint32_t r = 0; r < ZH_FRAG_SIZE / kT; r++) {
+        const uint32_t p = r * kT + t;
+        const uint32_t c = c0;
+        c0 = c1;
+        c1 = c2;
+        c2 = c3;
+        c3 = links[(r + 4u < ZH_FRAG_SIZE / kT ? r + 4u : r) * kT + t];
+        uint32_t m = 0;
+        if (p + 16u <= n && c && !(var & 8u)) {  // no match starts in the last 15 bytes (the reference's ip_limit)
+          if (ld32(p) == ld32(c)) {
+            const uint32_t lim = n - p < 258u ? n - p : 258u;  // snappy.nim:110
+            m = 4;
+            while (m < lim && !(var & 4u)) {
+              const uint64_t x = ld64(p + m) ^ ld64(c + m);
+              if (x) {
+                m += (uint32_t)(__ffsll((long long)x) - 1) >> 3;
+                break;
+              }
+              m += 8;
+            }
+            if (m > lim) m = lim;
+          }
+        }
+        s_mlen[p] = (uint8_t)(m ? m - 3u : 0u);
+      }
+    }
+    __syncthreads();
+
+    KPROF_MARK(2);
+    // ---- P3: greedy parse.  step(p) = length of the match at p, or 1 ----
+    const uint32_t lo = t * kChunk, hi = lo + kChunk < n ? lo + kChunk : n;
+    auto walk = [&](uint32_t p, uint32_t end) -> uint32_t {
+      while (p < end) {
+        const uint32_t m = s_mlen[p];
+        p += m ? m + 3u : 1u;
+      }
+      return p;
+    };
+    uint32_t entry = 0, ex = 0;
+    if (lo < n) {
+      entry = t ? walk(lo - kChunk, lo) : 0u;  // guessed: as if the chunk before were entered at its first byte
+      ex = walk(entry, hi);
+    }
+    s_exit[t] = ex;
+    for (;;) {
+      __syncthreads();
+      const uint32_t want = t && lo < n ? s_exit[t - 1] : entry;
+      if (t == 0) s_misc[1] = 0;
+      __syncthreads();
+      if (want != entry) {
+        entry = want;
+        ex = walk(entry, hi);
+        s_exit[t] = ex;
+        s_misc[1] = 1;
+      }
+      __syncthreads();
+      KPROF_COUNT(5, 1);
+      if (!s_misc[1]) break;
+    }
+    KPROF_MARK(3);
+
+    // ---- P4: records and statistics ----
+    uint32_t nm = 0, nl = 0;
+    if (lo < n) {
+      uint32_t p = entry;
+      while (p < hi) {
+        const uint32_t m = s_mlen[p];
+        if (m) {
+          nm++;
+          p += m + 3u;
+        } else {
+          nl++;
+          p++;
+        }
+      }
+    }
+    // exclusive prefix of the match counts over the workgroup
+    const uint32_t incl = zh_wave_scan(nm);
+    if (lane == 63) s_wsum[wave][0] = incl;
+    __syncthreads();
+    uint32_t mbase = incl - nm, total_m = 0;
+    for (uint32_t w = 0; w < kT / 64; w++) {
+      const uint32_t c = s_wsum[w][0];
+      if (w < wave) mbase += c;
+      total_m += c;
+    }
+    uint16_t* m_pos = a.m_pos + (size_t)f * ZH_MAX_MATCHES_PER_FRAG;
+    uint16_t* m_len = a.m_len + (size_t)f * ZH_MAX_MATCHES_PER_FRAG;
+    uint16_t* m_off = a.m_off + (size_t)f * ZH_MAX_MATCHES_PER_FRAG;
+    if (lo < n) {
+      uint32_t p = entry, k = mbase;
+      while (p < hi) {
+        const uint32_t m = s_mlen[p];
+        if (m) {
+          const uint32_t len = m + 3u;
+          m_pos[k] = (uint16_t)p;
+          m_len[k] = (uint16_t)len;
+          k++;
+          atomicAdd(&s_hist[257 + zh_len_code(len)], 1u);
+          p += len;
+        } else {
+          atomicAdd(&s_hist[zh_ld8(s_src, p + mis)], 1u);
+          p++;
+        }
+      }
+    }
+    __syncthreads();  // (records and links were written by this workgroup: its CU's L1 has them)
+    // distances: a thread per match, so that the scattered reads of the links are all in flight at once
+    uint32_t extra_bits = 0;
+    for (uint32_t k = t; k < total_m; k += kT) {
+      const uint32_t p = m_pos[k], len = m_len[k];
+      const uint32_t off = p - links[p];
+      m_off[k] = (uint16_t)off;
+      const uint32_t di = zh_dist_code(off);
+      atomicAdd(&s_hist[ZH_NUM_LITLEN + di], 1u);
+      extra_bits += zh_len_extra_bits(zh_len_code(len)) + zh_dist_extra_bits(di);
+    }
+    extra_bits = zh_wave_sum(extra_bits);
+    nl = zh_wave_sum(nl);
+    if (lane == 0) {
+      s_wsum[wave][1] = extra_bits;
+      s_wsum[wave][2] = nl;
+    }
+    __syncthreads();
+    uint16_t* hist_out = a.f_hist + (size_t)f * ZH_HIST_STRIDE;
+    for (uint32_t i = t; i < ZH_HIST_STRIDE; i += kT) hist_out[i] = (uint16_t)s_hist[i];
+    if (t == 0) {
+      uint32_t eb = 0, lits = 0;
+      for (uint32_t w = 0; w < kT / 64; w++) {
+        eb += s_wsum[w][1];
+        lits += s_wsum[w][2];
+      }
+      a.f_nmatch[f] = total_m;
+      a.f_spill[f] = 0;
+      a.f_nlit[f] = lits;
+      a.f_extra_bits[f] = eb;
+      s_misc[0] = atomicAdd(next_frag, 1u);
+    }
+    __syncthreads();
+    KPROF_MARK(4);
+    KPROF_COUNT(6, 1);
+    if (t == 0) KPROF_FLUSH(0, 8);
+    f = s_misc[0];
+    __syncthreads();
+  }
+}
+
+// workgroups that share the link pool: two per CU (64.6 KiB of LDS each)
+extern "C" uint32_t zh_l1p_slots(void) {
+  static const uint32_t slots = [] {
+    const char* e = getenv("ZH_L1P_SLOTS");
+    const long v = e ? atol(e) : 0;
+    return v >= 1 && v <= 4096 ? (uint32_t)v : 512u;
+  }();
+  return slots;
+}
+
+__global__ void zh_l1p_set_counter_kernel(uint32_t* next_frag, uint32_t v) { *next_frag = v; }
+
+extern "C" void zh_launch_l1p_match(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
+                                    uint16_t* link_pool, uint32_t* next_frag) {
+  if (!a.nfrags) return;
+  const uint32_t slots = zh_l1p_slots();
+  const uint32_t grid = a.nfrags < slots ? a.nfrags : slots;
+  hipLaunchKernelGGL(zh_l1p_set_counter_kernel, dim3(1), dim3(1), 0, stream, next_frag, grid);
+  static const uint32_t var = getenv("ZH_L1P_VAR") ? (uint32_t)atoi(getenv("ZH_L1P_VAR")) : 0u;
+  hipLaunchKernelGGL(zh_l1p_match_kernel, dim3(grid), dim3(kT), 0, stream, d_src, a, link_pool, next_frag, var);
+}
