@@ -52,7 +52,7 @@ struct __attribute__((packed)) Word32 {
 
 __global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
                                                           uint16_t* __restrict__ link_pool,
-                                                          uint32_t* __restrict__ next_frag, uint32_t var) {
+                                                          uint32_t* __restrict__ next_frag) {
   // P1: the hash table, a dword a slot (atomicMax); afterwards the fragment's bytes (s_src) and the
   // match lengths, a byte a position (s_mlen)
   __shared__ uint32_t s_big[kSrcWords + 8192];
@@ -113,9 +113,12 @@ __global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __re
           for (uint32_t k = 0; k < kB; k++) {
             const uint32_t step = s0 + half * kB + k;
             const uint32_t p = step * 64u + lane;
-            h[k] = (wq[half * kB + k] * kHashMul) >> kShift;
+            // a table entry is position << 16 | the 16 bits of the hash product below the slot's 14:
+            // the maximum is still the latest position, and a candidate whose 30 bits agree has the
+            // position's four bytes but for one case in 65 536 -- which P2's compare settles
+            h[k] = wq[half * kB + k] * kHashMul;
             wq[half * kB + k] = fetch(step + kAhead);
-            raw[k] = atomicMax(&s_tab[h[k]], p);
+            raw[k] = atomicMax(&s_tab[h[k] >> kShift], (p << 16) | ((h[k] >> 2) & 0xffffu));
 #ifdef ZH_EMU
             zh_wave_sync();  // (the emulator runs a lane at a time: keep the steps in step)
 #endif
@@ -132,8 +135,10 @@ __global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __re
                 (uint32_t)__builtin_amdgcn_update_dpp((int)h_last, (int)h[k], 0x138, 0xf, 0xf, false);
 #endif
             h_last = (uint32_t)__builtin_amdgcn_readlane((int)h[k], 63);
-            uint32_t link = raw[k] < p ? raw[k] : 0u;      // a candidate lies before its position
-            if (h[k] == h_prev && p >= 2u) link = p - 1u;  // a run: the nearest candidate there is
+            // bit 15 of a link: the candidate's 30 hash bits are the position's
+            const uint32_t q = raw[k] >> 16;
+            uint32_t link = q < p ? q | ((((raw[k] ^ (h[k] >> 2)) & 0xffffu) == 0u) << 15) : 0u;  // a candidate lies before its position
+            if ((h[k] >> 2) == (h_prev >> 2) && p >= 2u) link = (p - 1u) | 0x8000u;  // a run: the nearest candidate there is
             links[p & (ZH_FRAG_SIZE - 1u)] = (uint16_t)link;
           }
         }
@@ -172,32 +177,102 @@ __global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __re
 
     KPROF_MARK(1);
     // ---- P2: match length of every position against its candidate (position 512 r + t in turn
-    // r; the links are fetched four turns ahead) ----
+    // r; the links are fetched four turns ahead).  The SIMDs are busy issuing here, so the work is
+    // cut to what the parse can need: a candidate whose hash bits differ is no match; in a stretch
+    // of positions with the same distance to their candidates (a repeat) only the first one -- the
+    // head -- compares, the others' lengths follow from its length; a head compares 16 bytes by
+    // itself, and the few that are longer are finished one after the other by the whole wave, a
+    // lane four bytes ----
     {
+      // wave-wide: common prefix of positions p and c (wave-uniform) from byte m0 on, at most lim
+      auto finish = [&](uint32_t p, uint32_t c, uint32_t m0, uint32_t lim) -> uint32_t {
+        for (;;) {
+          const uint32_t o = m0 + 4u * lane;
+          const uint32_t x = o < lim ? zh_ld32(s_src, p + o + mis) ^ zh_ld32(s_src, c + o + mis) : 1u;
+          const uint64_t stop = __ballot(x != 0u);
+          if (stop) {
+            const uint32_t fl = (uint32_t)__ffsll((long long)stop) - 1u;
+            const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane((int)x, fl);
+            const uint32_t os = m0 + 4u * fl;
+            const uint32_t m = os < lim ? os + (((uint32_t)__ffs((int)xs) - 1u) >> 3) : lim;
+            return m > lim ? lim : m;
+          }
+          m0 += 256;  // (lim <= 258: one more turn at most)
+        }
+      };
       uint32_t c0 = links[t], c1 = links[kT + t], c2 = links[2 * kT + t], c3 = links[3 * kT + t];
       for (uint32_t r = 0; r < ZH_FRAG_SIZE / kT; r++) {
         const uint32_t p = r * kT + t;
-        const uint32_t c = c0;
+        const uint32_t lk = c0;
         c0 = c1;
         c1 = c2;
         c2 = c3;
         c3 = links[(r + 4u < ZH_FRAG_SIZE / kT ? r + 4u : r) * kT + t];
+        const uint32_t c = lk & 0x7fffu;
+        // no match starts in the last 15 bytes (the reference's ip_limit)
+        const bool cand = p + 16u <= n && (lk >> 15) != 0u && c != 0u;
+        const uint32_t lim = n - p < 258u ? n - p : 258u;  // snappy.nim:110 (>= 16 for a candidate)
+        const uint32_t off = cand ? p - c : 0u;
+        uint32_t off_prev = (uint32_t)__shfl_up((int)off, 1, 64);
+        if (lane == 0) off_prev = 0;
+        const bool follower = cand && off == off_prev;
+        const bool head = cand && !follower;
         uint32_t m = 0;
-        if (p + 16u <= n && c && !(var & 8u)) {  // no match starts in the last 15 bytes (the reference's ip_limit)
-          if (ld32(p) == ld32(c)) {
-            const uint32_t lim = n - p < 258u ? n - p : 258u;  // snappy.nim:110
-            m = 4;
-            while (m < lim && !(var & 4u)) {
-              const uint64_t x = ld64(p + m) ^ ld64(c + m);
-              if (x) {
-                m += (uint32_t)(__ffsll((long long)x) - 1) >> 3;
-                break;
-              }
-              m += 8;
-            }
-            if (m > lim) m = lim;
-          }
+        bool open = false;  // equal so far and not at the limit: the wave finishes it
+        if (head) {
+          // 16 bytes: both streams as aligned dwords shifted into place
+          const uint32_t ab = p + mis, bb = c + mis, as = ab & 3u, bs = bb & 3u;
+          const uint32_t* ap = s_src + (ab >> 2);
+          const uint32_t* bp = s_src + (bb >> 2);
+          uint32_t x[4];
+#pragma unroll
+          for (uint32_t i = 0; i < 4; i++)
+            x[i] = __builtin_amdgcn_alignbyte(ap[i + 1], ap[i], as) ^ __builtin_amdgcn_alignbyte(bp[i + 1], bp[i], bs);
+          m = 16;
+#pragma unroll
+          for (uint32_t i = 4; i-- > 0;)
+            if (x[i]) m = 4u * i + (((uint32_t)__ffs((int)x[i]) - 1u) >> 3);
+          open = m == 16u && lim > 16u;
         }
+        uint32_t m0 = 16;
+        auto finish_open = [&]() {  // the open ones, one after the other, by the whole wave
+          for (uint64_t todo = __ballot(open); todo; todo &= todo - 1) {
+            const uint32_t g = (uint32_t)__ffsll((long long)todo) - 1u;
+            const uint32_t mg = finish((uint32_t)__builtin_amdgcn_readlane((int)p, g), (uint32_t)__builtin_amdgcn_readlane((int)c, g),
+                                       (uint32_t)__builtin_amdgcn_readlane((int)m0, g), (uint32_t)__builtin_amdgcn_readlane((int)lim, g));
+            if (lane == g) m = mg;
+          }
+          open = false;
+        };
+        finish_open();
+        if (__ballot(follower)) {
+          // A head that stopped at 258 bytes, not at a difference: its followers reach further (each
+          // to its own 258 bytes) through the same bytes -- how many more of them are equal, once
+          uint32_t ext = 0;
+          for (uint64_t todo = __ballot(head && m == 258u); todo; todo &= todo - 1) {
+            const uint32_t g = (uint32_t)__ffsll((long long)todo) - 1u;
+            const uint32_t pg = (uint32_t)__builtin_amdgcn_readlane((int)p, g);
+            const uint32_t room = n - pg < 322u ? n - pg : 322u;
+            const uint32_t eg = finish(pg, (uint32_t)__builtin_amdgcn_readlane((int)c, g), 258u, room) - 258u;
+            if (lane == g) ext = eg;
+          }
+          // followers: the same bytes against the same bytes, k positions behind the head of the stretch
+          const uint32_t hl = zh_wave_scan_max(head ? lane : 0u);
+          const uint32_t mh = (uint32_t)__shfl((int)m, (int)hl, 64);
+          const uint32_t exth = (uint32_t)__shfl((int)ext, (int)hl, 64);
+          const uint32_t k = lane - hl;
+          if (follower) {
+            if (mh > k) {
+              m = mh - k + exth;
+              if (m > lim) m = lim;
+            } else {  // the head's match ends before this position: nothing is known about it
+              open = true;
+              m0 = 0;
+            }
+          }
+          finish_open();
+        }
+        if (m < 4u) m = 0;
         s_mlen[p] = (uint8_t)(m ? m - 3u : 0u);
       }
     }
@@ -286,7 +361,7 @@ __global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __re
     uint32_t extra_bits = 0;
     for (uint32_t k = t; k < total_m; k += kT) {
       const uint32_t p = m_pos[k], len = m_len[k];
-      const uint32_t off = p - links[p];
+      const uint32_t off = p - (links[p] & 0x7fffu);
       m_off[k] = (uint16_t)off;
       const uint32_t di = zh_dist_code(off);
       atomicAdd(&s_hist[ZH_NUM_LITLEN + di], 1u);
@@ -340,6 +415,5 @@ extern "C" void zh_launch_l1p_match(hipStream_t stream, const uint8_t* d_src, Zh
   const uint32_t slots = zh_l1p_slots();
   const uint32_t grid = a.nfrags < slots ? a.nfrags : slots;
   hipLaunchKernelGGL(zh_l1p_set_counter_kernel, dim3(1), dim3(1), 0, stream, next_frag, grid);
-  static const uint32_t var = getenv("ZH_L1P_VAR") ? (uint32_t)atoi(getenv("ZH_L1P_VAR")) : 0u;
-  hipLaunchKernelGGL(zh_l1p_match_kernel, dim3(grid), dim3(kT), 0, stream, d_src, a, link_pool, next_frag, var);
+  hipLaunchKernelGGL(zh_l1p_match_kernel, dim3(grid), dim3(kT), 0, stream, d_src, a, link_pool, next_frag);
 }
