@@ -55,7 +55,8 @@ void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, u
                           uint64_t* prevw);
 void zh_launch_chain_search(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
                             int max_chain, const uint64_t* prevw, uint32_t* best);
-void zh_launch_chain_select(hipStream_t, ZhCompressArgs a, const uint32_t* best);
+void zh_launch_chain_select(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
+                            int max_chain, const uint64_t* prevw, uint32_t* best);
 void zh_launch_frag_stats(hipStream_t, const uint8_t* d_src, ZhCompressArgs a);
 void zh_launch_huffman(hipStream_t, ZhCompressArgs a);
 void zh_launch_layout(hipStream_t, uint8_t* d_dst, ZhCompressArgs a, const uint32_t* buf_crc,
@@ -1086,10 +1087,10 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       ZH_HIP(ctx, hipMemsetAsync(p->head_scratch, 0, p->head_bytes, s));
       prof_mark(p, "zh_chain_prev_kernel");
       zh_launch_chain_prev(s, d_src, a, p->head_scratch, p->chain_prev);
-      prof_mark(p, "zh_chain_search_kernel");
+      prof_mark(p, "zh_chain_walk_kernel");
       zh_launch_chain_search(s, d_src, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
       prof_mark(p, "zh_chain_select_kernel");
-      zh_launch_chain_select(s, a, p->chain_best);
+      zh_launch_chain_select(s, d_src, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
       prof_mark(p, "zh_frag_stats_kernel");
       zh_launch_frag_stats(s, d_src, a);
     }
@@ -2272,7 +2273,7 @@ extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int lev
     ZH_HIP(ctx, hipMemsetAsync(p->head_scratch, 0, p->head_bytes, s));
     zh_launch_chain_prev(s, d_src.p, a, p->head_scratch, p->chain_prev);
     zh_launch_chain_search(s, d_src.p, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
-    zh_launch_chain_select(s, a, p->chain_best);
+    zh_launch_chain_select(s, d_src.p, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
   }
   const size_t nf = a.nfrags;
   std::vector<uint32_t> nmatch(nf);

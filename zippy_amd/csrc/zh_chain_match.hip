@@ -100,7 +100,73 @@ __global__ __launch_bounds__(64) void zh_chain_prev_kernel(const uint8_t* __rest
   }
 }
 
-// ---- 2. best match of every position (lz77.nim:83-112) ----
+// ---- 2. best match of a position (lz77.nim:83-112) ----
+// `pos` is block-relative, `pw` the block's links (kernel 1).  Returns length | offset << 16, or 0
+// when the longest match is not longer than 4 (lz77.nim:114).
+__device__ __forceinline__ uint32_t zh_chain_search_one(const uint8_t* __restrict__ src,
+                                                        const uint64_t* __restrict__ pw, uint32_t pos,
+                                                        uint32_t block_len, int good, int nice, int max_chain) {
+  if (pos + 4u >= block_len) return 0;
+  const uint32_t window_pos = pos & 32767u;
+  const uint32_t limit = block_len < pos + 258u ? block_len : pos + 258u;
+  uint32_t hash_pos = (uint32_t)pw[pos] & 0xffffu;
+  // the position's own first bytes: every candidate is compared against them, first through the
+  // six bytes that travel with the candidate's chain link (one gather decides most candidates)
+  const bool wide = pos + 8u <= limit;
+  const uint64_t own6 = wide ? load64u(src + pos) & 0xffffffffffffull : 0ull;
+  int tries = max_chain;
+  int prev_offset = 0, longest_offset = 0, longest_len = 0;
+  while (tries > 0 && hash_pos != 0) {
+    tries--;
+    const int offset = hash_pos <= window_pos ? (int)(window_pos - hash_pos)
+                                              : (int)(window_pos - hash_pos + 32768u);
+    if (offset <= 0 || offset < prev_offset) break;
+    prev_offset = offset;
+    // determineMatchLength(src, pos - offset, pos, limit), internal.nim:251-270
+    const uint64_t entry = pw[pos - (uint32_t)offset];  // chain[hashPos] | the candidate's six bytes << 16
+    const uint8_t* s1 = src + (pos - (uint32_t)offset);
+    uint32_t s2 = pos;
+    int match_len = 0;
+    bool done = false;
+    if (wide) {
+      const uint64_t x6 = (entry >> 16) ^ own6;
+      if (x6 != 0) {
+        match_len = (int)((uint32_t)__builtin_ctzll(x6) >> 3);
+        done = true;
+      }
+    }
+    while (!done && s2 + 8u <= limit) {
+      const uint64_t x = load64u(src + s2) ^ load64u(s1 + match_len);
+      if (x != 0) {
+        match_len += (int)((uint32_t)__builtin_ctzll(x) >> 3);
+        done = true;
+        break;
+      }
+      s2 += 8;
+      match_len += 8;
+    }
+    if (!done)
+      while (s2 < limit && src[s2] == s1[match_len]) {
+        s2++;
+        match_len++;
+      }
+    if (match_len > longest_len) {
+      if (match_len >= good) tries >>= 2;
+      longest_len = match_len;
+      longest_offset = offset;
+    }
+    // chain[hashPos]: the value stored when the position in that window slot was inserted
+    const uint32_t nxt = (uint32_t)entry & 0xffffu;
+    if (longest_len >= nice || hash_pos == nxt) break;
+    hash_pos = nxt;
+  }
+  return longest_len > 4 ? (uint32_t)longest_len | ((uint32_t)longest_offset << 16) : 0u;
+}
+
+// best[] entries: bit 31 = "worked out" (length in bits 0-15, offset in bits 16-30)
+constexpr uint32_t kBestKnown = 0x80000000u;
+
+// ---- 2a. every position (ZH_CHAIN_SEARCH=dense: cross-check and measurement) ----
 __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __restrict__ d_src,
                                                               ZhCompressArgs a, int good, int nice,
                                                               int max_chain,
@@ -112,68 +178,48 @@ __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __r
   const ZhFragDesc fd = a.frags[f];
   if (local >= fd.len) return;
   const ZhBlockDesc bd = a.blocks[fd.block];
-  const uint8_t* src = d_src + bd.src_off;
-  const uint32_t block_len = (uint32_t)bd.len;
   const uint32_t pos = (f - bd.first_frag) * ZH_FRAG_SIZE + local;  // block-relative
   const uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
-  uint32_t result = 0;
-  if (pos + 4u < block_len) {
-    const uint32_t window_pos = pos & 32767u;
-    const uint32_t limit = block_len < pos + 258u ? block_len : pos + 258u;
-    uint32_t hash_pos = (uint32_t)pw[pos] & 0xffffu;
-    // the position's own first bytes: every candidate is compared against them, first through the
-    // six bytes that travel with the candidate's chain link (one gather decides most candidates)
-    const bool wide = pos + 8u <= limit;
-    const uint64_t own6 = wide ? load64u(src + pos) & 0xffffffffffffull : 0ull;
-    int tries = max_chain;
-    int prev_offset = 0, longest_offset = 0, longest_len = 0;
-    while (tries > 0 && hash_pos != 0) {
-      tries--;
-      const int offset = hash_pos <= window_pos ? (int)(window_pos - hash_pos)
-                                                : (int)(window_pos - hash_pos + 32768u);
-      if (offset <= 0 || offset < prev_offset) break;
-      prev_offset = offset;
-      // determineMatchLength(src, pos - offset, pos, limit), internal.nim:251-270
-      const uint64_t entry = pw[pos - (uint32_t)offset];  // chain[hashPos] | the candidate's six bytes << 16
-      const uint8_t* s1 = src + (pos - (uint32_t)offset);
-      uint32_t s2 = pos;
-      int match_len = 0;
-      bool done = false;
-      if (wide) {
-        const uint64_t x6 = (entry >> 16) ^ own6;
-        if (x6 != 0) {
-          match_len = (int)((uint32_t)__builtin_ctzll(x6) >> 3);
-          done = true;
-        }
-      }
-      while (!done && s2 + 8u <= limit) {
-        const uint64_t x = load64u(src + s2) ^ load64u(s1 + match_len);
-        if (x != 0) {
-          match_len += (int)((uint32_t)__builtin_ctzll(x) >> 3);
-          done = true;
-          break;
-        }
-        s2 += 8;
-        match_len += 8;
-      }
-      if (!done)
-        while (s2 < limit && src[s2] == s1[match_len]) {
-          s2++;
-          match_len++;
-        }
-      if (match_len > longest_len) {
-        if (match_len >= good) tries >>= 2;
-        longest_len = match_len;
-        longest_offset = offset;
-      }
-      // chain[hashPos]: the value stored when the position in that window slot was inserted
-      const uint32_t nxt = (uint32_t)entry & 0xffffu;
-      if (longest_len >= nice || hash_pos == nxt) break;
-      hash_pos = nxt;
+  best[(size_t)bd.first_frag * ZH_FRAG_SIZE + pos] =
+      kBestKnown | zh_chain_search_one(d_src + bd.src_off, pw, pos, (uint32_t)bd.len, good, nice, max_chain);
+}
+
+// ---- 2b. the positions a greedy walk comes by ----
+// The parse (kernel 3) only ever asks for the positions it visits -- about a third of them -- and
+// a walk p -> p + (length ? length : 1) falls in step with the true one quickly wherever it
+// starts.  So a thread walks a 128-position chunk from its first byte and works out the best match
+// of what it visits, on to the first position behind its chunk that the next chunk's walk has
+// already done (there the two walks have met) or 1024 positions at most.  Whatever the true walk
+// visits and no walk here did is worked out by kernel 3 when it gets there: the values are those of
+// kernel 2a either way, only fewer.
+__global__ __launch_bounds__(256) void zh_chain_walk_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
+                                                            int good, int nice, int max_chain,
+                                                            const uint64_t* __restrict__ prevw,
+                                                            uint32_t* __restrict__ best, uint32_t first_frag) {
+  constexpr uint32_t kChunk = 128;
+  const uint32_t f = first_frag + blockIdx.x / (ZH_FRAG_SIZE / kChunk / 256u);
+  const uint32_t local = ((blockIdx.x % (ZH_FRAG_SIZE / kChunk / 256u)) * 256u + threadIdx.x) * kChunk;
+  const ZhFragDesc fd = a.frags[f];
+  if (local >= fd.len) return;
+  const ZhBlockDesc bd = a.blocks[fd.block];
+  const uint8_t* src = d_src + bd.src_off;
+  const uint32_t block_len = (uint32_t)bd.len;
+  const uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  uint32_t* bst = best + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  const uint32_t nmain = block_len > 4u ? block_len - 4u : 0u;  // lz77.nim:74-76: behind it only literals
+  uint32_t pos = (f - bd.first_frag) * ZH_FRAG_SIZE + local;    // block-relative
+  const uint32_t end = pos + kChunk, stop = end + 1024u;
+  while (pos < nmain && pos < stop) {
+    uint32_t r = __hip_atomic_load(bst + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (r & kBestKnown) {
+      if (pos >= end) break;  // the next chunk's walk has been here: the two have met
+    } else {
+      r = zh_chain_search_one(src, pw, pos, block_len, good, nice, max_chain);
+      __hip_atomic_store(bst + pos, r | kBestKnown, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (longest_len > 4) result = (uint32_t)longest_len | ((uint32_t)longest_offset << 16);  // lz77.nim:114
+    const uint32_t len = r & 0xffffu;
+    pos += len ? len : 1u;
   }
-  best[(size_t)bd.first_frag * ZH_FRAG_SIZE + pos] = result;
 }
 
 // ---- 3. the greedy parse (lz77.nim:73-130) over the per-position results ----
@@ -204,7 +250,7 @@ __global__ __launch_bounds__(64) void zh_chain_select_kernel(ZhCompressArgs a,
     const uint32_t v = base + lane < nmain ? bst[base + lane] : 0u;
     uint32_t cur = pos - base;
     while (cur < 64u && base + cur < nmain) {
-      const uint32_t r = __builtin_amdgcn_readlane(v, cur);
+      const uint32_t r = __builtin_amdgcn_readlane(v, cur) & ~kBestKnown;  // (every position is worked out: dense search)
       const uint32_t len = r & 0xffffu;
       if (len) {
         const uint32_t p = base + cur, frag = p >> 15;
@@ -240,8 +286,10 @@ __global__ __launch_bounds__(64) void zh_chain_select_kernel(ZhCompressArgs a,
 // whose walks never meet (a run parsed into back-to-back maximal matches) makes the final prefix
 // grow one chunk a turn: thread 0 then simply finishes the walk through LDS alone.  Counts are
 // prefix-summed and a last walk files the matches.  Same match list as zh_chain_select_kernel.
-__global__ __launch_bounds__(256) void zh_chain_select_par_kernel(ZhCompressArgs a,
-                                                                  const uint32_t* __restrict__ best) {
+__global__ __launch_bounds__(256) void zh_chain_select_par_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
+                                                                  int good, int nice, int max_chain,
+                                                                  const uint64_t* __restrict__ prevw,
+                                                                  uint32_t* __restrict__ best) {
   constexpr uint32_t kT = 256, kChunk = ZH_FRAG_SIZE / kT;  // 128 positions per thread
   __shared__ uint8_t s_len[ZH_FRAG_SIZE];  // 0: literal, else match length - 4 (5..258 -> 1..254)
   __shared__ uint32_t s_end[kT];
@@ -252,7 +300,9 @@ __global__ __launch_bounds__(256) void zh_chain_select_par_kernel(ZhCompressArgs
   const uint32_t b = blockIdx.x;
   const ZhBlockDesc bd = a.blocks[b];
   const uint32_t block_len = (uint32_t)bd.len;
-  const uint32_t* bst = best + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  uint32_t* bst = best + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  const uint8_t* src = d_src + bd.src_off;
+  const uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
   // lz77.nim:54-56,74-76: the last four positions (and blocks of <= 4 bytes) are literals
   const uint32_t nmain = block_len > 4u ? block_len - 4u : 0u;
   uint32_t entry = 0;  // block-relative position at which the walk enters the next fragment
@@ -262,18 +312,31 @@ __global__ __launch_bounds__(256) void zh_chain_select_par_kernel(ZhCompressArgs
     const uint32_t npos = nmain > base ? (nmain - base < ZH_FRAG_SIZE ? nmain - base : ZH_FRAG_SIZE) : 0u;
     __syncthreads();  // (the previous fragment's walks are done with s_len)
     for (uint32_t i = tid; i < ZH_FRAG_SIZE; i += kT) {
-      const uint32_t len = i < npos ? bst[base + i] & 0xffffu : 0u;
-      s_len[i] = (uint8_t)(len ? len - 4u : 0u);
+      const uint32_t v = i < npos ? bst[base + i] : kBestKnown;
+      const uint32_t len = v & 0xffffu;
+      s_len[i] = (uint8_t)(v & kBestKnown ? (len ? len - 4u : 0u) : 255u);  // 255: nobody came by here yet
     }
     if (tid == 0) s_first_dirty[0] = s_first_dirty[1] = kT;
     __syncthreads();
     // walks are in fragment-relative positions; one that enters behind the fragment passes through
     const uint32_t rel0 = entry > base ? entry - base : 0u;
     const uint32_t limit = (tid + 1u) * kChunk;
+    // match length - 4 at fragment position p (0: literal); a position no walk of kernel 2b visited
+    // is worked out here and now (and kept: the other walks of this kernel may come by as well)
+    auto len_at = [&](uint32_t p) -> uint32_t {
+      uint32_t l = s_len[p];
+      if (l == 255u) {
+        const uint32_t r = zh_chain_search_one(src, pw, base + p, block_len, good, nice, max_chain);
+        __hip_atomic_store(bst + base + p, r | kBestKnown, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        l = (r & 0xffffu) ? (r & 0xffffu) - 4u : 0u;
+        s_len[p] = (uint8_t)l;
+      }
+      return l;
+    };
     auto walk = [&](uint32_t p, uint32_t* nmatch) -> uint32_t {
       uint32_t n = 0;
       while (p < limit && p < npos) {
-        const uint32_t l = s_len[p];
+        const uint32_t l = len_at(p);
         n += l != 0u;
         p += l ? l + 4u : 1u;
       }
@@ -308,7 +371,7 @@ __global__ __launch_bounds__(256) void zh_chain_select_par_kernel(ZhCompressArgs
         for (uint32_t t = fd; t < upto; t++) {
           const uint32_t lim = (t + 1u) * kChunk;
           while (p < lim && p < npos) {
-            const uint32_t l = s_len[p];
+            const uint32_t l = len_at(p);
             p += l ? l + 4u : 1u;
           }
           if (p < lim) p = lim;  // (behind the last walkable position)
@@ -339,12 +402,12 @@ __global__ __launch_bounds__(256) void zh_chain_select_par_kernel(ZhCompressArgs
       const size_t slot0 = (size_t)f * ZH_MAX_MATCHES_PER_FRAG + before;
       uint32_t k = 0, p = my_start;
       while (p < limit && p < npos) {
-        const uint32_t l = s_len[p];
+        const uint32_t l = s_len[p];  // (the last walk came by here: it is worked out)
         if (l) {
           const uint32_t len = l + 4u;
           a.m_pos[slot0 + k] = (uint16_t)p;
           a.m_len[slot0 + k] = (uint16_t)len;
-          a.m_off[slot0 + k] = (uint16_t)(bst[base + p] >> 16);
+          a.m_off[slot0 + k] = (uint16_t)((__hip_atomic_load(bst + base + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16) & 0x7fffu);
           k++;
           const uint32_t end = p + len;  // a match that reaches into the next fragment (lz77.nim's
           if (end > ZH_FRAG_SIZE && frag + 1u < bd.nfrag) a.f_spill[f + 1u] = end - ZH_FRAG_SIZE;  // spill)
@@ -428,26 +491,49 @@ extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, Z
   hipLaunchKernelGGL(zh_chain_prev_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a, head_scratch,
                      prevw);
 }
-extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
-                                       int good, int nice, int max_chain, const uint64_t* prevw,
-                                       uint32_t* best) {
-  // one thread per position: a launch takes at most 2^30 of them (a grid of 2^32 threads or more is
-  // refused), so batches of 1 GiB and more go in slices
-  constexpr uint32_t kSlice = 32768;  // fragments per launch
-  for (uint32_t f0 = 0; f0 < a.nfrags; f0 += kSlice) {
-    const uint32_t nf = a.nfrags - f0 < kSlice ? a.nfrags - f0 : kSlice;
-    hipLaunchKernelGGL(zh_chain_search_kernel, dim3(nf * (ZH_FRAG_SIZE / 256u)), dim3(256), 0, stream,
-                       d_src, a, good, nice, max_chain, prevw, best, f0);
-  }
-}
-extern "C" void zh_launch_chain_select(hipStream_t stream, ZhCompressArgs a, const uint32_t* best) {
-  if (!a.nblocks) return;
-  static const bool serial = [] {
+// ZH_CHAIN_SEARCH=dense: the best match of EVERY position (kernel 2a) instead of the walks of kernel
+// 2b; ZH_CHAIN_SELECT=serial (one wave per block, needs the dense search): cross-checks and measurement
+static bool chain_select_serial() {
+  static const bool on = [] {
     const char* e = getenv("ZH_CHAIN_SELECT");
     return e && strcmp(e, "serial") == 0;
   }();
-  if (serial) hipLaunchKernelGGL(zh_chain_select_kernel, dim3(a.nblocks), dim3(64), 0, stream, a, best);
-  else hipLaunchKernelGGL(zh_chain_select_par_kernel, dim3(a.nblocks), dim3(256), 0, stream, a, best);
+  return on;
+}
+static bool chain_search_dense() {
+  static const bool on = [] {
+    const char* e = getenv("ZH_CHAIN_SEARCH");
+    return e && strcmp(e, "dense") == 0;
+  }();
+  return on || chain_select_serial();
+}
+extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
+                                       int good, int nice, int max_chain, const uint64_t* prevw,
+                                       uint32_t* best) {
+  // a launch takes at most 2^30 positions (a grid of 2^32 threads or more is refused), so batches
+  // of 1 GiB and more go in slices
+  constexpr uint32_t kSlice = 32768;  // fragments per launch
+  for (uint32_t f0 = 0; f0 < a.nfrags; f0 += kSlice) {
+    const uint32_t nf = a.nfrags - f0 < kSlice ? a.nfrags - f0 : kSlice;
+    if (chain_search_dense()) {
+      hipLaunchKernelGGL(zh_chain_search_kernel, dim3(nf * (ZH_FRAG_SIZE / 256u)), dim3(256), 0, stream,
+                         d_src, a, good, nice, max_chain, prevw, best, f0);
+    } else {
+      // (nothing is worked out yet: the walks of one launch may look at the next launch's entries)
+      if (f0 == 0) (void)hipMemsetAsync(best, 0, (size_t)a.nfrags * ZH_FRAG_SIZE * 4u, stream);
+      hipLaunchKernelGGL(zh_chain_walk_kernel, dim3(nf), dim3(256), 0, stream, d_src, a, good, nice, max_chain,
+                         prevw, best, f0);
+    }
+  }
+}
+extern "C" void zh_launch_chain_select(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a, int good,
+                                       int nice, int max_chain, const uint64_t* prevw, uint32_t* best) {
+  if (!a.nblocks) return;
+  if (chain_select_serial())
+    hipLaunchKernelGGL(zh_chain_select_kernel, dim3(a.nblocks), dim3(64), 0, stream, a, best);
+  else
+    hipLaunchKernelGGL(zh_chain_select_par_kernel, dim3(a.nblocks), dim3(256), 0, stream, d_src, a, good, nice,
+                       max_chain, prevw, best);
 }
 extern "C" void zh_launch_frag_stats(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a) {
   if (!a.nfrags) return;
