@@ -171,6 +171,7 @@ inline void emu_amdgcn_wave_barrier() { uint64_t live; (void)emu::wave_exchange(
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))
 #define __hip_atomic_store(ptr, val, order, scope) (*(ptr) = (val))
+#define __hip_atomic_exchange(ptr, val, order, scope) atomicExch(ptr, val)
 // atomics: fibers are cooperative, so plain read-modify-write is atomic
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = (T)(o + v); return o; }
 template <class T> inline T atomicSub(T* p, T v) { T o = *p; *p = (T)(o - v); return o; }

@@ -51,7 +51,7 @@ uint32_t zh_l1_table_slots(void);
 void zh_launch_l1p_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint16_t* link_pool,
                          uint32_t* next_frag);
 uint32_t zh_l1p_slots(void);
-void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint16_t* head_scratch,
+void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint32_t* head_scratch,
                           uint64_t* prevw);
 void zh_launch_chain_search(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
                             int max_chain, const uint64_t* prevw, uint32_t* best);
@@ -324,7 +324,7 @@ struct zh_plan {
   uint32_t npieces = 0;
   uint32_t *piece_crc = nullptr, *piece_adler = nullptr, *piece_len = nullptr;
   uint32_t *buf_crc = nullptr, *buf_adler = nullptr;
-  uint16_t* head_scratch = nullptr;  // chain levels: `head` per block, previous-position links and
+  uint32_t* head_scratch = nullptr;  // chain levels: `head` per block, previous-position links and
   size_t head_bytes = 0;             // best match per position (zh_chain_match.hip)
   uint16_t* l1_tables = nullptr;  // BestSpeed: pool of per-wave hash tables (zh_l1_match.hip)
   uint32_t* l1_counter = nullptr; // ... and the counter its waves draw fragments from
@@ -520,7 +520,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
                o_bst = ar.reserve((nb + n) * 8);
   const size_t o_bcrc = ar.reserve(n * 4), o_bad = ar.reserve(n * 4), o_olen = ar.reserve(n * 8),
                o_st = ar.reserve(n * 4);
-  p->head_bytes = chain ? nb * ((size_t)2 << 17) : 0;
+  p->head_bytes = chain ? nb * ((size_t)ZH_CHAIN_HEAD_WORDS * 4) : 0;
   const size_t o_head = ar.reserve(p->head_bytes);
   // one 32 KiB hash table per persistent matcher wave (zh_launch_l1_match: min(fragments, slots) waves)
   // (the parallel parse, zh_launch_l1p_match, keeps 64 KiB of candidate links per workgroup there instead)
@@ -595,7 +595,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   p->buf_adler = carve<uint32_t>(base, o_bad);
   a.out_len = p->out_len = carve<uint64_t>(base, o_olen);
   a.status = p->status = carve<int32_t>(base, o_st);
-  p->head_scratch = carve<uint16_t>(base, o_head);
+  p->head_scratch = carve<uint32_t>(base, o_head);
   p->l1_tables = carve<uint16_t>(base, o_l1tab);
   p->l1_counter = carve<uint32_t>(base, o_l1ctr);
   p->chain_prev = carve<uint64_t>(base, o_cprev);

@@ -45,59 +45,103 @@ __device__ inline uint32_t load32u(const uint8_t* p) {
 }  // namespace
 
 // ---- 1. previous same-hash window position of every inserted position ----
-__global__ __launch_bounds__(64) void zh_chain_prev_kernel(const uint8_t* __restrict__ d_src,
-                                                           ZhCompressArgs a,
-                                                           uint16_t* __restrict__ head_scratch,
-                                                           uint64_t* __restrict__ prevw) {
-  __shared__ uint32_t s_cnt[1024];  // byte-wide counters of the group's hashes (12 bits)
+// One wave a block, 64 positions a step, in order.  `head` (a dword a slot, in L2) is only ever
+// EXCHANGED -- by the last lane of a step that has a hash; lanes that share one are sorted out
+// inside the wave -- and nothing waits for what an exchange returns: exchanges of one wave on one
+// address are served in program order, so the steps of a block of sixteen are issued back to back
+// and their results picked up afterwards.  (The load / compare / store form this replaces paid
+// the L2's latency 16 384 times a MiB.)
+template <bool kTiny>  // kTiny: a block of fewer than eight bytes (its bytes are fetched one by one)
+__device__ __forceinline__ void zh_chain_prev_block(const uint8_t* __restrict__ d_src, const ZhCompressArgs& a,
+                                                    uint32_t* __restrict__ head_scratch,
+                                                    uint64_t* __restrict__ prevw, uint32_t* s_cnt, uint32_t b,
+                                                    const ZhBlockDesc& bd) {
+  constexpr uint32_t kDepth = 16;  // steps in flight (an exchange takes ~4 500 cycles to come back, a step ~900)
   const unsigned lane = zh_lane();
-  const uint32_t b = blockIdx.x;
-  const ZhBlockDesc bd = a.blocks[b];
   const uint8_t* src = d_src + bd.src_off;
   const uint32_t block_len = (uint32_t)bd.len;
-  uint16_t* head = head_scratch + ((size_t)b << kHashBits);  // zeroed by the host before launch
+  uint32_t* head = head_scratch + (size_t)b * ZH_CHAIN_HEAD_WORDS;  // zeroed by the host before launch
   uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
   const uint32_t nins = block_len > 4u ? block_len - 4u : 0u;  // positions with pos + 4 < block end
   for (uint32_t i = lane; i < 1024; i += 64) s_cnt[i] = 0;
   zh_wave_sync();
-  for (uint32_t base = 0; base < nins; base += 64) {
+  // the eight bytes at a position (zeros behind the block's end), a block of steps ahead.  Every
+  // memory operation of the loop is unconditional -- addresses are clamped -- so that the compiler
+  // counts what is in flight instead of waiting for all of it.
+  auto fetch = [&](uint32_t base) -> uint64_t {
     const uint32_t P = base + lane;
-    const bool valid = P < nins;
-    const uint32_t h = valid ? (load32u(src + P) * kHashMul) >> (32 - kHashBits) : 0u;
-    // `head` lives in HBM/L2; read and written past this CU's L1 so that the next turn sees it
-    uint32_t old = valid ? __hip_atomic_load(head + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    const uint32_t ck = (h & 4095u) >> 2, cs = (h & 3u) * 8u;
-    if (valid) atomicAdd(&s_cnt[ck], 1u << cs);
-    zh_wave_sync();
-    const uint32_t cnt = valid ? (s_cnt[ck] >> cs) & 255u : 0u;
-    zh_wave_sync();
-    if (valid) s_cnt[ck] = 0;
-    bool last = true;  // last position of the group with this hash: it ends up in `head`
-    uint64_t cc = __ballot(cnt > 1u);
-    while (cc) {  // groups of lanes that may share a hash: resolve exactly, in position order
-      const uint32_t jx = (uint32_t)__ffsll((long long)cc) - 1u;
-      const uint32_t hj = __builtin_amdgcn_readlane(h, jx);
-      const uint64_t same = __ballot(valid && h == hj);
-      if ((same >> lane) & 1ull) {
-        const uint64_t below = same & zh_lanemask_lt();
-        if (below) old = (base + 63u - (uint32_t)__clzll((long long)below)) & 32767u;
-        last = (same >> lane) >> 1 == 0;
-      }
-      cc &= ~same;
+    const uint32_t Pc = P < nins ? P : nins - 1u;
+    if (kTiny) {
+      uint64_t v = 0;
+      for (uint32_t j = 0; j < 8u && Pc + j < block_len; j++) v |= (uint64_t)src[Pc + j] << (8u * j);
+      return v;
     }
-    if (valid) {
-      // the link and the position's first six bytes in one word: the search reads both with one gather
-      uint64_t six = 0;
-      if (P + 8u <= block_len) {
-        six = load64u(src + P) & 0xffffffffffffull;
-      } else {
-        for (uint32_t k = 0; k < 6u && P + k < block_len; k++) six |= (uint64_t)src[P + k] << (8u * k);
+    const uint32_t at = Pc + 8u <= block_len ? Pc : block_len - 8u;
+    return load64u(src + at) >> (8u * (Pc - at));
+  };
+  uint64_t wq[kDepth];
+#pragma unroll
+  for (uint32_t k = 0; k < kDepth; k++) wq[k] = nins ? fetch(64u * k) : 0ull;
+  for (uint32_t base0 = 0; base0 < nins; base0 += 64 * kDepth) {
+    uint32_t ret[kDepth], link_in[kDepth], from[kDepth];
+    uint64_t six[kDepth];
+#pragma unroll
+    for (uint32_t k = 0; k < kDepth; k++) {
+      const uint32_t base = base0 + 64u * k;
+      const uint32_t P = base + lane;
+      const bool valid = P < nins;
+      const uint64_t w8 = wq[k];
+      wq[k] = fetch(base + 64u * kDepth);
+      const uint32_t h = ((uint32_t)w8 * kHashMul) >> (32 - kHashBits);
+      const uint32_t ck = (h & 4095u) >> 2, cs = (h & 3u) * 8u;
+      if (valid) atomicAdd(&s_cnt[ck], 1u << cs);
+      zh_wave_sync();
+      const uint32_t cnt = valid ? (s_cnt[ck] >> cs) & 255u : 0u;
+      zh_wave_sync();
+      if (valid) s_cnt[ck] = 0;
+      bool last = true;             // last position of the step with this hash: it ends up in `head`
+      uint32_t in_step = 0xffffffffu;  // the link, if an earlier lane of the step has the hash
+      uint32_t last_lane = lane;       // ... else what `head` held: the last lane of the group gets it back
+      uint64_t cc = __ballot(cnt > 1u);
+      while (cc) {  // groups of lanes that may share a hash: resolve exactly, in position order
+        const uint32_t jx = (uint32_t)__ffsll((long long)cc) - 1u;
+        const uint32_t hj = __builtin_amdgcn_readlane(h, jx);
+        const uint64_t same = __ballot(valid && h == hj);
+        if ((same >> lane) & 1ull) {
+          const uint64_t below = same & zh_lanemask_lt();
+          if (below) in_step = (base + 63u - (uint32_t)__clzll((long long)below)) & 32767u;
+          last = (same >> lane) >> 1 == 0;
+          last_lane = 63u - (uint32_t)__clzll((long long)same);
+        }
+        cc &= ~same;
       }
-      pw[P] = (uint64_t)(old & 0xffffu) | (six << 16);
-      if (last) __hip_atomic_store(head + h, (uint16_t)(P & 32767u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ret[k] = __hip_atomic_exchange(head + (valid && last ? h : (1u << kHashBits) + lane), P & 32767u,
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      link_in[k] = in_step;
+      from[k] = last_lane;
+      // the position's first six bytes travel with its link: the search reads both with one gather
+      six[k] = w8 & 0xffffffffffffull;
     }
-    zh_wave_sync();
+#pragma unroll
+    for (uint32_t k = 0; k < kDepth; k++) {
+      const uint32_t P = base0 + 64u * k + lane;
+      const uint32_t got = (uint32_t)__shfl((int)ret[k], (int)from[k], 64);
+      const uint32_t old = link_in[k] != 0xffffffffu ? link_in[k] : got;
+      // (positions behind the last inserted one: a slot nobody reads)
+      pw[P < nins ? P : nins] = (uint64_t)(old & 0xffffu) | (six[k] << 16);
+    }
   }
+}
+
+__global__ __launch_bounds__(64) void zh_chain_prev_kernel(const uint8_t* __restrict__ d_src,
+                                                           ZhCompressArgs a,
+                                                           uint32_t* __restrict__ head_scratch,
+                                                           uint64_t* __restrict__ prevw) {
+  __shared__ uint32_t s_cnt[1024];  // byte-wide counters of the group's hashes (12 bits)
+  const uint32_t b = blockIdx.x;
+  const ZhBlockDesc bd = a.blocks[b];
+  if (bd.len < 8u) zh_chain_prev_block<true>(d_src, a, head_scratch, prevw, s_cnt, b, bd);
+  else zh_chain_prev_block<false>(d_src, a, head_scratch, prevw, s_cnt, b, bd);
 }
 
 // ---- 2. best match of a position (lz77.nim:83-112) ----
@@ -486,7 +530,7 @@ __global__ __launch_bounds__(64) void zh_frag_stats_kernel(const uint8_t* __rest
 }
 
 extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
-                                     uint16_t* head_scratch, uint64_t* prevw) {
+                                     uint32_t* head_scratch, uint64_t* prevw) {
   if (!a.nblocks) return;
   hipLaunchKernelGGL(zh_chain_prev_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a, head_scratch,
                      prevw);

@@ -22,6 +22,7 @@
 #define ZH_HDR_WORDS 256             // dynamic block header bit string, <= 1 KiB
 #define ZH_NUM_LITLEN 286
 #define ZH_NUM_DIST 30
+#define ZH_CHAIN_HEAD_WORDS ((1u << 17) + 64u)  // chain levels: a block's `head` (lz77.nim:5-6) + a scratch slot a lane
 
 enum { ZH_MODE_STORED = 0, ZH_MODE_FIXED = 1, ZH_MODE_DYNAMIC = 2 };
 
