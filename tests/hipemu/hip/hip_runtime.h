@@ -74,6 +74,7 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = 0) { me
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = 0; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }

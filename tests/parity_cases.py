@@ -81,6 +81,57 @@ def check_parallel_parse(eng, inputs, formats=(oracle.dfGzip,), margin=1.02):
     return dev, ref
 
 
+def wide_length_count_input():
+    """deflate.nim:136-139 counts the symbols of a code length in a uint8, which
+    wraps when 256 or more share one length.  3000 bytes at level -2 (Huffman only, no stored
+    fallback, dynamic codes because the block is longer than 2048 bytes): one byte value 2745
+    times, the other 255 values once each -- with the end-of-block symbol that is 256 symbols of
+    frequency 1 under one subtree: 256 codes of length 9."""
+    rnd = random.Random(95)
+    body = [0x41] * 2745 + [v for v in range(256) if v != 0x41]
+    rnd.shuffle(body)
+    return bytes(body)
+
+
+def check_wide_code_length_counts(eng):
+    """The case of SURVEY.md 9.5 through device, oracle and zlib: oracle and kernel count in wide
+    integers on purpose (the reference's wrap would emit a stream that does not decode)."""
+    import heapq
+    src = wide_length_count_input()
+    # the premise, worked out independently: Huffman code lengths of the literal/length alphabet
+    freq = [0] * 286
+    for b in src:
+        freq[b] += 1
+    freq[256] = 1
+    heap = [(f, i, None, None) for i, f in enumerate(freq) if f]
+    heapq.heapify(heap)
+    n = 286
+    while len(heap) > 1:
+        a, b = heapq.heappop(heap), heapq.heappop(heap)
+        heapq.heappush(heap, (a[0] + b[0], n, a, b))
+        n += 1
+    depth = {}
+
+    def walk(node, d):
+        if node[2] is None:
+            depth[node[1]] = d
+        else:
+            walk(node[2], d + 1)
+            walk(node[3], d + 1)
+    walk(heap[0], 0)
+    per_len = {}
+    for d in depth.values():
+        per_len[d] = per_len.get(d, 0) + 1
+    assert max(per_len.values()) >= 256, per_len
+    eng.set_gzip_fname_len(0)
+    for fmt in (oracle.dfGzip, oracle.dfDeflate):
+        out = eng.compress(src, -2, fmt)
+        assert out == oracle.compress(src, -2, fmt, fname_len=0)
+        assert zlib.decompress(out, WBITS[fmt]) == src
+        assert oracle.uncompress(out, fmt) == src
+        assert eng.uncompress(out, fmt) == src
+
+
 def check_roundtrip(eng, inputs, level, fmt=oracle.dfGzip):
     outs, sts = eng.compress_batch(inputs, level, fmt)
     assert all(s == 0 for s in sts)
@@ -460,6 +511,31 @@ def check_ragged_staging(eng, scale):
         back, sts = eng.uncompress_batch(outs, fmt)
         assert all(s == 0 for s in sts), sts
         assert back == bufs, level
+        if fmt == oracle.dfGzip:
+            # the same batch as pipelined groups (uncompress_batch_pipelined: gzip members carry their
+            # size): identical results; then one member whose ISIZE promises too little -- the group it
+            # is in outgrows its slot and the whole batch is sent down the plain path, which sizes and
+            # retries: same bytes, that member's status from the ISIZE check like the plain path's
+            try:
+                eng.set_host_pipeline(1, 150000 * scale)
+                back2, sts2 = eng.uncompress_batch(outs, fmt)
+                liar = list(outs)
+                k = 7
+                small = (len(bufs[k]) // 2).to_bytes(4, "little")
+                liar[k] = liar[k][:-4] + small
+                back3, sts3 = eng.uncompress_batch(liar, fmt)
+                bad7 = list(outs)
+                bad7[k] = bad7[k][:len(bad7[k]) // 2] + bytes([bad7[k][len(bad7[k]) // 2] ^ 0x55]) + bad7[k][len(bad7[k]) // 2 + 1:]
+                back4, sts4 = eng.uncompress_batch(bad7, fmt)
+            finally:
+                eng.set_host_pipeline(1 << 60, 0)
+            assert sts2 == sts and back2 == back, "pipelined uncompress differs"
+            plain3, psts3 = eng.uncompress_batch(liar, fmt)
+            plain4, psts4 = eng.uncompress_batch(bad7, fmt)
+            eng.set_host_pipeline(0, 0)
+            assert sts3 == psts3 and back3 == plain3 and sts3[k] != 0, (sts3, psts3)
+            assert sts4 == psts4 and back4 == plain4 and sts4[k] != 0
+            assert [b for i, b in enumerate(back3) if i != k] == [b for i, b in enumerate(bufs) if i != k]
         if fmt == oracle.dfGzip:  # a damaged member in the middle only fails its own slot
             bad = list(outs)
             bad[7] = bad[7][:len(bad[7]) // 2] + bytes([bad[7][len(bad[7]) // 2] ^ 0x55]) + bad[7][len(bad[7]) // 2 + 1:]

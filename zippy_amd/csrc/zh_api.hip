@@ -145,6 +145,12 @@ static hipError_t ctx_malloc(zh_ctx* ctx, void** out, size_t bytes) {
 }
 static void ctx_free(zh_ctx* ctx, void* p) {
   if (!p) return;
+  // A block given back may be handed out again at once: safe for what is ordered on ctx->stream,
+  // not for transfers still queued on the copy stream of the pipelined host calls -- wait for those.
+  if (ctx->copy_stream && hipStreamQuery(ctx->copy_stream) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(ctx->copy_stream);
+  }
   for (size_t i = 0; i < ctx->dev_blocks.size(); i++) {
     zh_ctx::DevBlock& b = ctx->dev_blocks[i];
     if (b.p != p) continue;
@@ -1008,6 +1014,10 @@ static bool plan_token_pool(zh_plan* p) {
     (void)hipGetLastError();
     p->tok_pool = nullptr;
     p->tok_failed = true;
+    // not an error (the serial decoder gives the same bytes), but several times slower: leave a note
+    p->ctx->last_error = "note: no memory for a token pool of " + std::to_string(p->tok_words * 4) +
+                         " bytes; this plan decodes with the serial kernel (zh_inflate_kernel)";
+    if (getenv("ZH_TRACE")) fprintf(stderr, "zippy_hip: %s\n", p->ctx->last_error.c_str());
     return false;
   }
   if (p->segmented) {  // without its buffers the plan simply is not segmented
@@ -1021,6 +1031,9 @@ static bool plan_token_pool(zh_plan* p) {
       p->sg_windows = nullptr;
       p->sg_winsym = nullptr;
       p->segmented = false;
+      p->ctx->last_error = "note: no memory for the segment-wise decode's buffers; large streams of this plan "
+                           "are decoded by one workgroup each";
+      if (getenv("ZH_TRACE")) fprintf(stderr, "zippy_hip: %s\n", p->ctx->last_error.c_str());
     } else {
       p->sg.sym = p->sg_sym;
       p->sg.windows = p->sg_windows;
@@ -1072,8 +1085,11 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     if (p->dst_dense) {
       ZH_HIP(ctx, hipMemsetAsync(d_dst + p->dst_lo, 0, p->dst_hi - p->dst_lo, s));
     } else {
-      const uint32_t gy = (uint32_t)std::min<uint64_t>(64, (p->dst_max_cap >> 16) + 1);
+      uint32_t gy = (uint32_t)std::min<uint64_t>(64, (p->dst_max_cap >> 16) + 1);
+      while (gy > 1 && (uint64_t)p->n * gy > 0x7fffffffull) gy >>= 1;  // (a grid has fewer than 2^31 workgroups)
+      if ((uint64_t)p->n * gy > 0x7fffffffull) return ZH_ERR_ARGUMENT;
       hipLaunchKernelGGL(zh_zero_slots_kernel, dim3((uint32_t)p->n * gy), dim3(256), 0, s, d_dst, p->d_bufs, gy);
+      ZH_HIP(ctx, hipGetLastError());
     }
     if (p->level == 1 && l1_parallel(ctx)) {
       prof_mark(p, "zh_l1p_match_kernel");
