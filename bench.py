@@ -58,12 +58,24 @@ def _stats(times, nbytes):
             "GiBps_at_min": round(nbytes / GIB / min(times), 4), "GiBps_at_avg": round(nbytes / GIB / avg, 4)}
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(bufs, level, cores, reps=10):
     """The oracle (C restatement of zippy, oracle/zippy_oracle.c) timed on the host cores the way
     the reference times itself (tests/bench.nim:27-28,63-64 with benchy: warm-up, >= 10 repetitions,
     min / avg / sd): compress(level, gzip) and uncompress (CRC verified), one buffer per task, on
-    1 thread and on `cores` threads; system zlib at the matching level as the second yardstick
-    (tests/bench.nim:30-34,66-70)."""
+    1 thread and on `cores` worker threads -- C threads inside the library, each pinned to its own
+    core, the clock around the parallel region only (oracle.batch_mt); system zlib at the matching
+    level as the second yardstick (tests/bench.nim:30-34,66-70; Python threads, zlib releases the GIL)."""
     import zlib
     import oracle
     from concurrent.futures import ThreadPoolExecutor
@@ -73,24 +85,30 @@ def cpu_baseline(bufs, level, cores, reps=10):
     def leg(sample, threads):
         nbytes = sum(len(b) for b in sample)
         out = {}
+        _, blobs = oracle.batch_mt(sample, 0, level, oracle.dfGzip, threads, keep=True)  # warm-up
+        _, back = oracle.batch_mt(blobs, 1, level, oracle.dfGzip, threads, keep=True)
+        assert back == sample
+        tc = [oracle.batch_mt(sample, 0, level, oracle.dfGzip, threads)[0] for _ in range(reps)]
+        tu = [oracle.batch_mt(blobs, 1, level, oracle.dfGzip, threads)[0] for _ in range(reps)]
+        out["oracle"] = {"compress": _stats(tc, nbytes), "uncompress": _stats(tu, nbytes),
+                         "both_GiBps_at_avg": round(nbytes / GIB / (sum(tc) / reps + sum(tu) / reps), 4),
+                         "both_GiBps_at_min": round(nbytes / GIB / (min(tc) + min(tu)), 4),
+                         "ratio": round(nbytes / sum(len(z) for z in blobs), 4)}
         with ThreadPoolExecutor(threads) as ex:
-            for tag, comp, unc in (("oracle", lambda b: oracle.compress(b, level, oracle.dfGzip, fname_len=0),
-                                    oracle.uncompress),
-                                   ("zlib", lambda b: zlib.compress(b, zl), zlib.decompress)):
-                blobs = list(ex.map(comp, sample))  # warm-up
-                assert unc(blobs[0]) == sample[0]
-                tc, tu = [], []
-                for _ in range(reps):
-                    t0 = time.perf_counter()
-                    blobs = list(ex.map(comp, sample))
-                    t1 = time.perf_counter()
-                    list(ex.map(unc, blobs))
-                    t2 = time.perf_counter()
-                    tc.append(t1 - t0)
-                    tu.append(t2 - t1)
-                out[tag] = {"compress": _stats(tc, nbytes), "uncompress": _stats(tu, nbytes),
-                            "both_GiBps_at_avg": round(nbytes / GIB / (sum(tc) / reps + sum(tu) / reps), 4),
-                            "ratio": round(nbytes / sum(len(z) for z in blobs), 4)}
+            comp, unc = (lambda b: zlib.compress(b, zl)), zlib.decompress
+            blobs = list(ex.map(comp, sample))  # warm-up
+            tc, tu = [], []
+            for _ in range(max(3, reps // 2)):
+                t0 = time.perf_counter()
+                blobs = list(ex.map(comp, sample))
+                t1 = time.perf_counter()
+                list(ex.map(unc, blobs))
+                t2 = time.perf_counter()
+                tc.append(t1 - t0)
+                tu.append(t2 - t1)
+            out["zlib"] = {"compress": _stats(tc, nbytes), "uncompress": _stats(tu, nbytes),
+                           "both_GiBps_at_avg": round(nbytes / GIB / (sum(tc) / len(tc) + sum(tu) / len(tu)), 4),
+                           "ratio": round(nbytes / sum(len(z) for z in blobs), 4)}
         out["threads"] = threads
         out["sample_bytes"] = nbytes
         return out
@@ -99,13 +117,16 @@ def cpu_baseline(bufs, level, cores, reps=10):
     many = leg(bufs, cores)
     return {
         "value": many["oracle"]["both_GiBps_at_avg"],
+        "value_at_min": many["oracle"]["both_GiBps_at_min"],
         "unit": "GiB/s",
         "cores": cores,
+        "cpu": cpu_model(),
         "kind": "port",
         "sample": "%d x %d B of the same G-mix batch (1 thread: %d B), oracle = C restatement of zippy: "
-                  "compress(level %d, gzip) + uncompress(CRC verified), one buffer per task, %d repetitions "
-                  "after a warm-up; value = uncompressed bytes / (avg compress + avg uncompress) on %d threads" % (
-                      len(bufs), len(bufs[0]), one["sample_bytes"], level, reps, cores),
+                  "compress(level %d, gzip) + uncompress(CRC verified), one buffer per task on %d pinned C "
+                  "threads (first come, first served), %d repetitions after a warm-up; value = uncompressed "
+                  "bytes / (avg compress + avg uncompress), value_at_min the same with the best repetitions" % (
+                      len(bufs), len(bufs[0]), one["sample_bytes"], level, cores, reps),
         "value_1_thread": one["oracle"]["both_GiBps_at_avg"],
         "all_cores": many,
         "one_thread": one,

@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libzippy_oracle.so")
+# ZIPPY_ORACLE_LIB: another build of the same source (tests/test_oracle_sanitizers.py: ASan/UBSan)
+_LIB_PATH = os.environ.get("ZIPPY_ORACLE_LIB") or os.path.join(_HERE, "libzippy_oracle.so")
 
 dfDetect, dfZlib, dfGzip, dfDeflate = 0, 1, 2, 3
 NoCompression, BestSpeed, BestCompression, DefaultCompression, HuffmanOnly = 0, 1, 9, -1, -2
@@ -27,7 +28,7 @@ def build(force=False):
     src = os.path.join(_HERE, "zippy_oracle.c")
     if (force or not os.path.exists(_LIB_PATH)
             or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
-        subprocess.check_call(["make", "-C", _HERE, "libzippy_oracle.so"],
+        subprocess.check_call(["make", "-C", _HERE, os.path.basename(_LIB_PATH)],
                               stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -77,8 +78,32 @@ def lib():
         L.zo_huffman_codes.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, ctypes.POINTER(ctypes.c_uint16),
                                        ctypes.POINTER(ctypes.c_uint8)]
+        L.zo_batch_mt.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t),
+                                  ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.POINTER(_Buf), ctypes.POINTER(ctypes.c_double)]
         _lib = L
     return _lib
+
+
+def batch_mt(bufs, direction, level=BestSpeed, dataFormat=dfGzip, threads=1, keep=False):
+    """bench.py's cpu_baseline: compress (direction 0) or uncompress (1) every buffer of `bufs` on
+    `threads` pinned worker threads inside the C library.  -> (seconds of the parallel region,
+    results or None)."""
+    n = len(bufs)
+    arr = (ctypes.c_char_p * n)(*bufs)
+    lens = (ctypes.c_size_t * n)(*[len(b) for b in bufs])
+    outs = (_Buf * n)() if keep else None
+    sec = ctypes.c_double(0.0)
+    st = lib().zo_batch_mt(arr, lens, n, direction, level, dataFormat, threads, outs, ctypes.byref(sec))
+    res = None
+    if keep:
+        res = [ctypes.string_at(o.data, o.len) if o.len else b"" for o in outs]
+        for o in outs:
+            if o.data:
+                lib().zo_free(o.data)
+    if st != 0:
+        raise ZippyError(st, lib().zo_strerror(st).decode())
+    return sec.value, res
 
 
 def _take(buf, status):

@@ -1,3 +1,4 @@
+#define _GNU_SOURCE /* pthread_setaffinity_np, CPU_SET (zo_batch_mt) */
 /*
  * zippy_oracle.c -- TEST INFRASTRUCTURE ONLY (see zippy_oracle.h).
  *
@@ -16,6 +17,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <stddef.h>
 
 /* ------------------------------------------------------------------ */
 /* internal.nim:9-24 constants                                          */
@@ -1195,6 +1197,13 @@ static int out_reserve(zo_buf *o, size_t need) {
   return 0;
 }
 
+/* internal.nim:233-241 copy64: eight bytes, any alignment, source read before the store */
+static inline void copy64(uint8_t *d, size_t to, size_t from) {
+  uint64_t v;
+  memcpy(&v, d + from, 8);
+  memcpy(d + to, &v, 8);
+}
+
 /* inflate.nim:104-250 */
 static int inflate_block(zo_buf *dst, bit_reader *b, size_t *op_io, int fixed_codes) {
   huffman lit, dist;
@@ -1263,10 +1272,28 @@ static int inflate_block(zo_buf *dst, bit_reader *b, size_t *op_io, int fixed_co
       if (distance > op) return ZO_ERR_INVALID_BUFFER; /* :224-225 */
       if (op + copy_length + 13 > dst->cap && out_reserve(dst, (op + copy_length) * 2 + 10))
         return ZO_ERR_NOMEM;
-      /* :231-249: the copy64 warm-up/stride loops are equivalent to the
-       * byte-sequential LZ77 copy below (overlap replicates the pattern). */
+      /* :231-249, as written there: eight bytes at a time (the 13 bytes of room reserved above
+       * are what the last copy64 may overwrite behind the match); a short distance first doubles
+       * the pattern until source and destination are eight bytes apart */
       uint8_t *d = dst->data;
-      for (size_t k = 0; k < copy_length; k++) d[op + k] = d[op + k - distance];
+      if (copy_length <= 16 && distance >= 8) {
+        copy64(d, op, op - distance);
+        copy64(d, op + 8, op - distance + 8);
+      } else {
+        size_t copy_from = op - distance, copy_to = op;
+        ptrdiff_t remaining = (ptrdiff_t)copy_length;
+        while (copy_to - copy_from < 8) {
+          copy64(d, copy_to, copy_from);
+          remaining -= (ptrdiff_t)(copy_to - copy_from);
+          copy_to += copy_to - copy_from;
+        }
+        while (remaining > 0) {
+          copy64(d, copy_to, copy_from);
+          copy_from += 8;
+          copy_to += 8;
+          remaining -= 8;
+        }
+      }
       op += copy_length;
     }
   }
@@ -1476,4 +1503,88 @@ const char *zo_strerror(int status) {
     case ZO_ERR_NOMEM: return "out of memory";
     default: return "unknown status";
   }
+}
+
+/* ---- cpu_baseline support (bench.py): one compress() or uncompress() per buffer of a batch on
+ * `threads` worker threads, each pinned to its own core, buffers handed out first come, first
+ * served; the time of the parallel region (tests/bench.nim times single calls; a batch on all cores
+ * is what the GPU path is compared with).  dir 0: compress(level, fmt) of srcs;
+ * dir 1: uncompress(fmt) of srcs.  Results are kept in outs[] (owned by the caller: zo_free)
+ * when outs != NULL, otherwise freed.  Returns the first non-zero status, 0 if none. ---- */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <pthread.h>
+#include <sched.h>
+#include <time.h>
+
+typedef struct {
+  const uint8_t *const *srcs;
+  const size_t *lens;
+  size_t n;
+  int dir, level, fmt, threads, id;
+  zo_buf *outs;
+  size_t *next;
+  int *status;
+  pthread_barrier_t *bar;
+} zo_mt_job;
+
+static void *zo_mt_worker(void *arg) {
+  zo_mt_job *j = (zo_mt_job *)arg;
+#ifdef __linux__
+  {
+    cpu_set_t allowed, one;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+      int want = j->id % CPU_COUNT(&allowed), seen = 0;
+      for (int c = 0; c < CPU_SETSIZE; c++)
+        if (CPU_ISSET(c, &allowed) && seen++ == want) {
+          CPU_ZERO(&one);
+          CPU_SET(c, &one);
+          (void)pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+          break;
+        }
+    }
+  }
+#endif
+  pthread_barrier_wait(j->bar); /* all pinned: the clock starts */
+  for (;;) {
+    size_t i = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
+    if (i >= j->n) break;
+    zo_buf out = {0, 0, 0};
+    int st = j->dir == 0 ? zo_compress(j->srcs[i], j->lens[i], j->level, j->fmt, 0, &out)
+                         : zo_uncompress(j->srcs[i], j->lens[i], j->fmt, &out);
+    if (st != ZO_OK) __atomic_store_n(j->status, st, __ATOMIC_RELAXED);
+    if (j->outs) j->outs[i] = out;
+    else free(out.data);
+  }
+  pthread_barrier_wait(j->bar); /* the clock stops */
+  return NULL;
+}
+
+int zo_batch_mt(const uint8_t *const *srcs, const size_t *lens, size_t n, int dir, int level, int fmt,
+                int threads, zo_buf *outs, double *seconds) {
+  if (threads < 1) threads = 1;
+  pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof *tid);
+  zo_mt_job *jobs = (zo_mt_job *)calloc((size_t)threads, sizeof *jobs);
+  pthread_barrier_t bar;
+  size_t next = 0;
+  int status = ZO_OK;
+  if (!tid || !jobs) return ZO_ERR_NOMEM;
+  pthread_barrier_init(&bar, NULL, (unsigned)threads + 1u);
+  for (int t = 0; t < threads; t++) {
+    zo_mt_job j = {srcs, lens, n, dir, level, fmt, threads, t, outs, &next, &status, &bar};
+    jobs[t] = j;
+    pthread_create(&tid[t], NULL, zo_mt_worker, &jobs[t]);
+  }
+  struct timespec t0, t1;
+  pthread_barrier_wait(&bar);
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  pthread_barrier_wait(&bar);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+  pthread_barrier_destroy(&bar);
+  free(tid);
+  free(jobs);
+  if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  return status;
 }

@@ -127,6 +127,11 @@ int zo_encode_block_tokens(const uint8_t *src, size_t block_start,
 int zo_huffman_codes(const uint32_t *freq, int num_freq, int min_codes,
                      int code_length_limit, uint16_t *codes, uint8_t *lens);
 
+/* bench.py's cpu_baseline: a batch on `threads` pinned worker threads (dir 0 compress, 1
+ * uncompress), the wall time of the parallel region in *seconds; results in outs[] if given. */
+int zo_batch_mt(const uint8_t *const *srcs, const size_t *lens, size_t n, int dir, int level, int fmt,
+                int threads, zo_buf *outs, double *seconds);
+
 #ifdef __cplusplus
 }
 #endif
