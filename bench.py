@@ -535,7 +535,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": scaling if world > 1 else None,  # one GPU: nothing is scaled
+            "scaling": scaling if world > 1 or args.scaling else None,  # one GPU: nothing is scaled
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic (G-mix: seeded slices of the reference's own test corpus, SURVEY.md 8d)",

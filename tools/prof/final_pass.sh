@@ -1,37 +1,28 @@
 #!/bin/bash
 # The per-round evidence under profiles/ (run on the GPU box from the repo root):
-#   bash tools/prof/final_pass.sh r02_a
-# -> gpurun_out/<tag>_bench.json (BASELINE metric), _c2/_c3/_c3own/_c4/_c4share/_c5 .json (the other
-#    BASELINE configs), _kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same bench command),
-#    _pytest_gpu.log, _host_api.json, _single_call.json, _one_stream.json, _fuzz_seg.log, hbm_traffic.json (two --pmc passes)
-R=$(pwd); T=${1:-r02}
+#   bash tools/prof/final_pass.sh r03_a
+# -> gpurun_out/<tag>_bench.json (BASELINE metric + configs 2-5 + the parallel-parse leg + cpu_baseline),
+#    _c4.json (DefaultCompression, whole batch on one GPU), _share512.json (one GPU's share of eight),
+#    _kernel_stats.csv (rocprofv3 --kernel-trace --stats of the bench command), _pytest_gpu.log,
+#    _host_api*.json, _single_call.json, _one_stream.json, hbm_traffic.json (two --pmc passes)
+R=$(pwd); T=${1:-r03}
 O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q > $O/${T}_pytest_gpu.log 2>&1
-timeout 600 python bench.py --steps 10 --warmup 2 2>/dev/null | tail -1 > $O/${T}_bench.json
-# config 2: 1024 x 64 KiB compress BestSpeed; config 3: 4096 x 1 MiB uncompress only (own streams, and
-# the foreign set: gzip members made by system zlib level 6); config 4: DefaultCompression, the whole
-# batch on one GPU and one GPU's share of eight (512 x 1 MiB); config 5: tools/bench_c5.py
-timeout 300 python bench.py --buffers 1024 --size 65536 --compress-only --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c2.json
-timeout 600 python bench.py --uncompress-only --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c3own.json
-timeout 900 python bench.py --foreign 6 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c3.json
+timeout 1200 python -m pytest tests -m gpu -q > $O/${T}_pytest_gpu.log 2>&1
+timeout 900 python bench.py --steps 10 --warmup 2 2>$O/${T}_bench.err | tail -1 > $O/${T}_bench.json
 timeout 600 python bench.py --level -1 --compress-only --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c4.json
-timeout 600 python bench.py --level -1 --buffers 512 --compress-only --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c4share.json
-timeout 300 python tools/bench_c5.py --plain 2>/dev/null | tail -1 > $O/${T}_c5.json
-timeout 300 python tools/bench_c5.py --level -1 --steps 2 2>/dev/null | tail -1 >> $O/${T}_c5.json
-timeout 300 python tools/bench_host_api.py --reps 2 2>/dev/null | tail -1 > $O/${T}_host_api.json
-timeout 300 python tools/bench_single_call.py 2>/dev/null | tail -1 > $O/${T}_single_call.json
 # one GPU's share of the batch when eight GPUs split it (strong scaling, 512 x 1 MiB)
-timeout 300 python bench.py --buffers 512 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_share512.json
+timeout 300 python bench.py --buffers 512 --steps 10 --warmup 2 --no-cpu-baseline --no-configs 2>/dev/null | tail -1 > $O/${T}_share512.json
+timeout 300 python tools/bench_host_api.py --reps 2 2>/dev/null | tail -1 > $O/${T}_host_api.json
 timeout 300 python tools/bench_host_api.py --reps 2 --buffers 4096 2>/dev/null | tail -1 > $O/${T}_host_api_4096.json
+timeout 300 python tools/bench_single_call.py 2>/dev/null | tail -1 > $O/${T}_single_call.json
 timeout 600 python tools/bench_one_stream.py 2>/dev/null | tail -1 > $O/${T}_one_stream.json
-timeout 600 python tools/gpu_fuzz.py --seg-mutations 4000 2>/dev/null | tail -3 > $O/${T}_fuzz_seg.log
 cd /tmp
 rm -rf /tmp/kt /tmp/pf /tmp/pw
-timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${T}_rocprof_bench.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o pf -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o pw -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $O/${T}_rocprof_bench.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o pf -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-configs --no-parallel-parse > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o pw -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-configs --no-parallel-parse > /dev/null 2>&1
 cd $R
 python tools/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) > $O/${T}_kernel_stats.csv 2>$O/${T}_summary.err
 python tools/pmc_traffic.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) --buffers 4096 --size 1048576 > $O/hbm_traffic.json 2>>$O/${T}_summary.err
-tail -2 $O/${T}_pytest_gpu.log; for f in bench c2 c3own c3 c4 c4share; do echo "== $f"; cut -c1-700 $O/${T}_$f.json; done; head -12 $O/${T}_kernel_stats.csv
+tail -2 $O/${T}_pytest_gpu.log; for f in bench c4 share512; do echo "== $f"; cut -c1-600 $O/${T}_$f.json; done; head -14 $O/${T}_kernel_stats.csv

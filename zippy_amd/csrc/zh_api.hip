@@ -53,6 +53,7 @@ void zh_launch_l1p_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, ui
 uint32_t zh_l1p_slots(void);
 void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint32_t* head_scratch,
                           uint64_t* prevw);
+uint32_t zh_chain_prev_slice(void);
 void zh_launch_chain_search(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
                             int max_chain, const uint64_t* prevw, uint32_t* best);
 void zh_launch_chain_select(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
@@ -526,7 +527,9 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
                o_bst = ar.reserve((nb + n) * 8);
   const size_t o_bcrc = ar.reserve(n * 4), o_bad = ar.reserve(n * 4), o_olen = ar.reserve(n * 8),
                o_st = ar.reserve(n * 4);
-  p->head_bytes = chain ? nb * ((size_t)ZH_CHAIN_HEAD_WORDS * 4) : 0;
+  p->head_bytes = !chain ? 0
+                  : nb <= zh_chain_prev_slice() ? nb * ((size_t)ZH_CHAIN_HEAD_WORDS * 4)
+                                                : nb * ((size_t)2 << 17);  // (zh_launch_chain_prev)
   const size_t o_head = ar.reserve(p->head_bytes);
   // one 32 KiB hash table per persistent matcher wave (zh_launch_l1_match: min(fragments, slots) waves)
   // (the parallel parse, zh_launch_l1p_match, keeps 64 KiB of candidate links per workgroup there instead)
@@ -1099,8 +1102,6 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       zh_launch_l1_match(s, d_src, a, p->level == -2, p->l1_tables, p->l1_counter);
     } else if (p->level != 0) {
       const int* cfg = kChainConfig[p->level == -1 ? 6 : p->level];
-      prof_mark(p, "memset_head");
-      ZH_HIP(ctx, hipMemsetAsync(p->head_scratch, 0, p->head_bytes, s));
       prof_mark(p, "zh_chain_prev_kernel");
       zh_launch_chain_prev(s, d_src, a, p->head_scratch, p->chain_prev);
       prof_mark(p, "zh_chain_walk_kernel");
@@ -2286,7 +2287,6 @@ extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int lev
     zh_launch_l1_match(s, d_src.p, a, level == -2, p->l1_tables, p->l1_counter);
   } else {
     const int* cfg = kChainConfig[level == -1 ? 6 : level];
-    ZH_HIP(ctx, hipMemsetAsync(p->head_scratch, 0, p->head_bytes, s));
     zh_launch_chain_prev(s, d_src.p, a, p->head_scratch, p->chain_prev);
     zh_launch_chain_search(s, d_src.p, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
     zh_launch_chain_select(s, d_src.p, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);

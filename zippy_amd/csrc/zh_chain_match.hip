@@ -53,14 +53,13 @@ __device__ inline uint32_t load32u(const uint8_t* p) {
 // the L2's latency 16 384 times a MiB.)
 template <bool kTiny>  // kTiny: a block of fewer than eight bytes (its bytes are fetched one by one)
 __device__ __forceinline__ void zh_chain_prev_block(const uint8_t* __restrict__ d_src, const ZhCompressArgs& a,
-                                                    uint32_t* __restrict__ head_scratch,
-                                                    uint64_t* __restrict__ prevw, uint32_t* s_cnt, uint32_t b,
+                                                    uint32_t* __restrict__ head,
+                                                    uint64_t* __restrict__ prevw, uint32_t* s_cnt,
                                                     const ZhBlockDesc& bd) {
   constexpr uint32_t kDepth = 16;  // steps in flight (an exchange takes ~4 500 cycles to come back, a step ~900)
   const unsigned lane = zh_lane();
   const uint8_t* src = d_src + bd.src_off;
   const uint32_t block_len = (uint32_t)bd.len;
-  uint32_t* head = head_scratch + (size_t)b * ZH_CHAIN_HEAD_WORDS;  // zeroed by the host before launch
   uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
   const uint32_t nins = block_len > 4u ? block_len - 4u : 0u;  // positions with pos + 4 < block end
   for (uint32_t i = lane; i < 1024; i += 64) s_cnt[i] = 0;
@@ -136,12 +135,70 @@ __device__ __forceinline__ void zh_chain_prev_block(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(64) void zh_chain_prev_kernel(const uint8_t* __restrict__ d_src,
                                                            ZhCompressArgs a,
                                                            uint32_t* __restrict__ head_scratch,
-                                                           uint64_t* __restrict__ prevw) {
+                                                           uint64_t* __restrict__ prevw, uint32_t first_block) {
   __shared__ uint32_t s_cnt[1024];  // byte-wide counters of the group's hashes (12 bits)
-  const uint32_t b = blockIdx.x;
-  const ZhBlockDesc bd = a.blocks[b];
-  if (bd.len < 8u) zh_chain_prev_block<true>(d_src, a, head_scratch, prevw, s_cnt, b, bd);
-  else zh_chain_prev_block<false>(d_src, a, head_scratch, prevw, s_cnt, b, bd);
+  const ZhBlockDesc bd = a.blocks[first_block + blockIdx.x];
+  uint32_t* head = head_scratch + (size_t)blockIdx.x * ZH_CHAIN_HEAD_WORDS;  // zeroed before the launch
+  if (bd.len < 8u) zh_chain_prev_block<true>(d_src, a, head, prevw, s_cnt, bd);
+  else zh_chain_prev_block<false>(d_src, a, head, prevw, s_cnt, bd);
+}
+
+// ---- 1b. the same links by load / compare / store on a 16-bit `head` ----
+// For batches of more than zh_chain_prev_slice() blocks: every lane of every step of the exchanging
+// form above pulls a line of its block's 512 KiB table through the fabric, and with thousands of
+// blocks in flight that traffic, not the latency, is what it waits for (4096 blocks: 204 ms against
+// 123 ms for this form, whose tables are half as large; 512 blocks: 21 ms against 31 ms).
+__global__ __launch_bounds__(64) void zh_chain_prev_ldst_kernel(const uint8_t* __restrict__ d_src,
+                                                                ZhCompressArgs a,
+                                                                uint16_t* __restrict__ head_scratch,
+                                                                uint64_t* __restrict__ prevw, uint32_t first_block) {
+  __shared__ uint32_t s_cnt[1024];  // byte-wide counters of the group's hashes (12 bits)
+  const unsigned lane = zh_lane();
+  const ZhBlockDesc bd = a.blocks[first_block + blockIdx.x];
+  const uint8_t* src = d_src + bd.src_off;
+  const uint32_t block_len = (uint32_t)bd.len;
+  uint16_t* head = head_scratch + ((size_t)blockIdx.x << kHashBits);  // zeroed before the launch
+  uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  const uint32_t nins = block_len > 4u ? block_len - 4u : 0u;  // positions with pos + 4 < block end
+  for (uint32_t i = lane; i < 1024; i += 64) s_cnt[i] = 0;
+  zh_wave_sync();
+  for (uint32_t base = 0; base < nins; base += 64) {
+    const uint32_t P = base + lane;
+    const bool valid = P < nins;
+    const uint32_t h = valid ? (load32u(src + P) * kHashMul) >> (32 - kHashBits) : 0u;
+    // `head` lives in HBM/L2; read and written past this CU's L1 so that the next turn sees it
+    uint32_t old = valid ? __hip_atomic_load(head + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const uint32_t ck = (h & 4095u) >> 2, cs = (h & 3u) * 8u;
+    if (valid) atomicAdd(&s_cnt[ck], 1u << cs);
+    zh_wave_sync();
+    const uint32_t cnt = valid ? (s_cnt[ck] >> cs) & 255u : 0u;
+    zh_wave_sync();
+    if (valid) s_cnt[ck] = 0;
+    bool last = true;  // last position of the group with this hash: it ends up in `head`
+    uint64_t cc = __ballot(cnt > 1u);
+    while (cc) {  // groups of lanes that may share a hash: resolve exactly, in position order
+      const uint32_t jx = (uint32_t)__ffsll((long long)cc) - 1u;
+      const uint32_t hj = __builtin_amdgcn_readlane(h, jx);
+      const uint64_t same = __ballot(valid && h == hj);
+      if ((same >> lane) & 1ull) {
+        const uint64_t below = same & zh_lanemask_lt();
+        if (below) old = (base + 63u - (uint32_t)__clzll((long long)below)) & 32767u;
+        last = (same >> lane) >> 1 == 0;
+      }
+      cc &= ~same;
+    }
+    if (valid) {
+      uint64_t six = 0;
+      if (P + 8u <= block_len) {
+        six = load64u(src + P) & 0xffffffffffffull;
+      } else {
+        for (uint32_t k = 0; k < 6u && P + k < block_len; k++) six |= (uint64_t)src[P + k] << (8u * k);
+      }
+      pw[P] = (uint64_t)(old & 0xffffu) | (six << 16);
+      if (last) __hip_atomic_store(head + h, (uint16_t)(P & 32767u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    zh_wave_sync();
+  }
 }
 
 // ---- 2. best match of a position (lz77.nim:83-112) ----
@@ -529,11 +586,22 @@ __global__ __launch_bounds__(64) void zh_frag_stats_kernel(const uint8_t* __rest
   }
 }
 
+// Up to this many blocks the exchanging kernel with its 512 KiB tables, beyond it the load / store
+// kernel with 256 KiB ones (the plan's scratch is sized for either).
+extern "C" uint32_t zh_chain_prev_slice(void) { return 1024u; }
 extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
                                      uint32_t* head_scratch, uint64_t* prevw) {
-  if (!a.nblocks) return;
-  hipLaunchKernelGGL(zh_chain_prev_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a, head_scratch,
-                     prevw);
+  const uint32_t slice = zh_chain_prev_slice();
+  if (a.nblocks <= slice) {
+    if (!a.nblocks) return;
+    (void)hipMemsetAsync(head_scratch, 0, (size_t)a.nblocks * ZH_CHAIN_HEAD_WORDS * 4u, stream);
+    hipLaunchKernelGGL(zh_chain_prev_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a, head_scratch, prevw, 0u);
+    return;
+  }
+  // (all blocks at once: this form lives on the number of loads in flight)
+  (void)hipMemsetAsync(head_scratch, 0, (size_t)a.nblocks << (kHashBits + 1), stream);
+  hipLaunchKernelGGL(zh_chain_prev_ldst_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a,
+                     reinterpret_cast<uint16_t*>(head_scratch), prevw, 0u);
 }
 // ZH_CHAIN_SEARCH=dense: the best match of EVERY position (kernel 2a) instead of the walks of kernel
 // 2b; ZH_CHAIN_SELECT=serial (one wave per block, needs the dense search): cross-checks and measurement
