@@ -35,8 +35,8 @@
 
 namespace {
 constexpr uint32_t kHashMul = 0x1e35a7bdu;  // snappy.nim:70-71
-constexpr uint32_t kT = 512;                // threads per workgroup
-constexpr uint32_t kChunk = 64;             // positions per parse thread (kT * kChunk = 32768)
+constexpr uint32_t kT = 1024;               // threads per workgroup
+constexpr uint32_t kChunk = 32;             // positions per parse thread (kT * kChunk = 32768)
 constexpr uint32_t kSrcWords = 8192 + 72;   // fragment + slack for compares that run past its end
 constexpr uint32_t kShift = 18;             // 14 hash bits
 // 16 bytes at any 4-byte address (gfx950 global loads need no alignment)
@@ -50,7 +50,7 @@ struct __attribute__((packed)) Word32 {
 };
 }  // namespace
 
-__global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
+__global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
                                                           uint16_t* __restrict__ link_pool,
                                                           uint32_t* __restrict__ next_frag) {
   // P1: the hash table, a dword a slot (atomicMax); afterwards the fragment's bytes (s_src) and the
@@ -58,14 +58,17 @@ __global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __re
   __shared__ uint32_t s_big[kSrcWords + 8192];
   __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
   __shared__ uint32_t s_exit[kT];
-  __shared__ uint32_t s_wsum[8][3];
+  __shared__ uint32_t s_wsum[kT / 64][3];
   __shared__ uint32_t s_misc[4];     // 0: next fragment, 1: "some entry changed"
   uint32_t* const s_tab = s_big;
   uint32_t* const s_src = s_big;
   uint8_t* const s_mlen = reinterpret_cast<uint8_t*>(s_big + kSrcWords);
 
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  uint16_t* const links = link_pool + (size_t)blockIdx.x * ZH_FRAG_SIZE;
+  // a workgroup's slot of the pool: what the table returned for every position (a dword each, P1 ->
+  // P2), then the candidates of the positions (a halfword each, P2 -> P4)
+  uint32_t* const raws = reinterpret_cast<uint32_t*>(link_pool + (size_t)blockIdx.x * (3u * ZH_FRAG_SIZE));
+  uint16_t* const links = link_pool + (size_t)blockIdx.x * (3u * ZH_FRAG_SIZE) + 2u * ZH_FRAG_SIZE;
 
   for (uint32_t f = blockIdx.x; f < a.nfrags;) {
     KPROF_DECL(8);  // cycles of thread 0: 0 stage-in, 1 links, 2 lengths, 3 parse, 4 output; counts: 5 turns, 6 fragments
@@ -95,8 +98,7 @@ __global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __re
       // never looked at by P2 (no match starts in the last 15 bytes), positions behind n enter the
       // table when nobody reads it any more.  Only the loads are kept inside the fragment.
       const uint32_t steps = (n + 63u) >> 6;
-      constexpr uint32_t kB = 8;       // steps a block: their atomics are in flight together
-      constexpr uint32_t kAhead = 16;  // source words are fetched two blocks ahead
+      constexpr uint32_t kAhead = 16;  // source words are fetched this many steps ahead
       auto fetch = [&](uint32_t step) -> uint32_t {
         const uint32_t p = step * 64u + lane;
         return (uint32_t) * reinterpret_cast<const Word32*>(src + (p + 4u <= n ? p : n - 4u));
@@ -104,44 +106,24 @@ __global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __re
       uint32_t wq[kAhead];
 #pragma unroll
       for (uint32_t k = 0; k < kAhead; k++) wq[k] = fetch(k);
-      uint32_t h_last = 0xffffffffu;  // hash of the position before the block's first
       for (uint32_t s0 = 0; s0 < steps; s0 += kAhead) {
+        uint32_t raw[kAhead];  // the atomics of a block are issued back to back, their results stored afterwards
 #pragma unroll
-        for (uint32_t half = 0; half < kAhead / kB; half++) {
-          uint32_t h[kB], raw[kB];
-#pragma unroll
-          for (uint32_t k = 0; k < kB; k++) {
-            const uint32_t step = s0 + half * kB + k;
-            const uint32_t p = step * 64u + lane;
-            // a table entry is position << 16 | the 16 bits of the hash product below the slot's 14:
-            // the maximum is still the latest position, and a candidate whose 30 bits agree has the
-            // position's four bytes but for one case in 65 536 -- which P2's compare settles
-            h[k] = wq[half * kB + k] * kHashMul;
-            wq[half * kB + k] = fetch(step + kAhead);
-            raw[k] = atomicMax(&s_tab[h[k] >> kShift], (p << 16) | ((h[k] >> 2) & 0xffffu));
+        for (uint32_t k = 0; k < kAhead; k++) {
+          const uint32_t step = s0 + k;
+          const uint32_t p = step * 64u + lane;
+          // a table entry is position << 16 | the 16 bits of the hash product below the slot's 14:
+          // the maximum is still the latest position, and a candidate whose 30 bits agree has the
+          // position's four bytes but for one case in 65 536 -- which P2's compare settles
+          const uint32_t h = wq[k] * kHashMul;
+          wq[k] = fetch(step + kAhead);
+          raw[k] = atomicMax(&s_tab[h >> kShift], (p << 16) | ((h >> 2) & 0xffffu));
 #ifdef ZH_EMU
-            zh_wave_sync();  // (the emulator runs a lane at a time: keep the steps in step)
+          zh_wave_sync();  // (the emulator runs a lane at a time: keep the steps in step)
 #endif
-          }
-#pragma unroll
-          for (uint32_t k = 0; k < kB; k++) {
-            const uint32_t p = (s0 + half * kB + k) * 64u + lane;
-#ifdef ZH_EMU
-            uint32_t h_prev = (uint32_t)__shfl_up((int)h[k], 1, 64);
-            if (lane == 0) h_prev = h_last;
-#else
-            // wave_shr:1 -- lane l gets lane l - 1's hash, lane 0 keeps the `old` operand
-            const uint32_t h_prev =
-                (uint32_t)__builtin_amdgcn_update_dpp((int)h_last, (int)h[k], 0x138, 0xf, 0xf, false);
-#endif
-            h_last = (uint32_t)__builtin_amdgcn_readlane((int)h[k], 63);
-            // bit 15 of a link: the candidate's 30 hash bits are the position's
-            const uint32_t q = raw[k] >> 16;
-            uint32_t link = q < p ? q | ((((raw[k] ^ (h[k] >> 2)) & 0xffffu) == 0u) << 15) : 0u;  // a candidate lies before its position
-            if ((h[k] >> 2) == (h_prev >> 2) && p >= 2u) link = (p - 1u) | 0x8000u;  // a run: the nearest candidate there is
-            links[p & (ZH_FRAG_SIZE - 1u)] = (uint16_t)link;
-          }
         }
+#pragma unroll
+        for (uint32_t k = 0; k < kAhead; k++) raws[((s0 + k) * 64u + lane) & (ZH_FRAG_SIZE - 1u)] = raw[k];
       }
 #ifndef ZH_EMU
       __builtin_amdgcn_s_setprio(0);
@@ -152,9 +134,9 @@ __global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __re
     // never past the dword that holds its last byte); LDS byte q = fragment byte q - mis.  All of
     // a thread's loads are in flight together: 16 bytes each, at any 4-byte address ----
     {
-      Bytes16 v[4];
+      Bytes16 v[8192 / 4 / kT];
 #pragma unroll
-      for (uint32_t k = 0; k < 4; k++) {
+      for (uint32_t k = 0; k < 8192 / 4 / kT; k++) {
         const uint32_t i = (k * kT + t) * 4u;
         v[k] = Bytes16{0, 0, 0, 0};
         if (i + 4u <= ndw) {
@@ -166,7 +148,7 @@ __global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __re
         }
       }
 #pragma unroll
-      for (uint32_t k = 0; k < 4; k++)
+      for (uint32_t k = 0; k < 8192 / 4 / kT; k++)
         *reinterpret_cast<uint4*>(s_src + (k * kT + t) * 4u) = make_uint4(v[k].x, v[k].y, v[k].z, v[k].w);
     }
     for (uint32_t i = 8192 + t; i < kSrcWords; i += kT) s_src[i] = 0;
@@ -200,17 +182,29 @@ __global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __re
           m0 += 256;  // (lim <= 258: one more turn at most)
         }
       };
-      uint32_t c0 = links[t], c1 = links[kT + t], c2 = links[2 * kT + t], c3 = links[3 * kT + t];
+      uint32_t c0 = raws[t], c1 = raws[kT + t], c2 = raws[2 * kT + t], c3 = raws[3 * kT + t];
       for (uint32_t r = 0; r < ZH_FRAG_SIZE / kT; r++) {
         const uint32_t p = r * kT + t;
-        const uint32_t lk = c0;
+        const uint32_t raw = c0;
         c0 = c1;
         c1 = c2;
         c2 = c3;
-        c3 = links[(r + 4u < ZH_FRAG_SIZE / kT ? r + 4u : r) * kT + t];
-        const uint32_t c = lk & 0x7fffu;
+        c3 = raws[(r + 4u < ZH_FRAG_SIZE / kT ? r + 4u : r) * kT + t];
+        // the candidate: the latest earlier position with the hash (a candidate lies before its
+        // position) -- or, in a run, the position right before: the nearest candidate there is
+        const uint32_t h = ld32(p) * kHashMul;
+        uint32_t h_prev = (uint32_t)__shfl_up((int)h, 1, 64);
+        if (lane == 0) h_prev = p ? ld32(p - 1u) * kHashMul : ~h;
+        uint32_t c = raw >> 16;
+        bool same = c < p && ((raw ^ (h >> 2)) & 0xffffu) == 0u;  // the candidate's 30 hash bits are the position's
+        if ((h >> 2) == (h_prev >> 2) && p >= 2u) {
+          c = p - 1u;
+          same = true;
+        }
+        if (c >= p) c = 0;
+        links[p] = (uint16_t)c;
         // no match starts in the last 15 bytes (the reference's ip_limit)
-        const bool cand = p + 16u <= n && (lk >> 15) != 0u && c != 0u;
+        const bool cand = p + 16u <= n && same && c != 0u;
         const uint32_t lim = n - p < 258u ? n - p : 258u;  // snappy.nim:110 (>= 16 for a candidate)
         const uint32_t off = cand ? p - c : 0u;
         uint32_t off_prev = (uint32_t)__shfl_up((int)off, 1, 64);
@@ -361,7 +355,7 @@ __global__ __launch_bounds__(kT, 4) void zh_l1p_match_kernel(const uint8_t* __re
     uint32_t extra_bits = 0;
     for (uint32_t k = t; k < total_m; k += kT) {
       const uint32_t p = m_pos[k], len = m_len[k];
-      const uint32_t off = p - (links[p] & 0x7fffu);
+      const uint32_t off = p - links[p];
       m_off[k] = (uint16_t)off;
       const uint32_t di = zh_dist_code(off);
       atomicAdd(&s_hist[ZH_NUM_LITLEN + di], 1u);
