@@ -219,7 +219,8 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
             e["uncompress_GiBps"] = round(nbytes / GIB / (tu * 1e-3), 3)
         return e
 
-    def batch(tag, workload, n, size, level, do_c, do_u, foreign=None, nsteps=steps):
+    def batch(tag, workload, n, size, level, do_c, do_u, foreign=None, nsteps=steps, l1_parse=-1):
+        eng.set_l1_parse(l1_parse)
         data = host.reshape(-1)[:n * size].reshape(n, size)
         d_src = torch.from_numpy(data.reshape(-1)).cuda()
         cap = size + size // 8 + 2048
@@ -282,9 +283,12 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
                 pl.close()
         del d_src, d_comp, d_back
         torch.cuda.empty_cache()
+        eng.set_l1_parse(-1)
 
     nb = host.shape[0]
     batch("c2", "config 2: 1024 x 64 KiB, compress BestSpeed gzip", min(1024, nb * 16), 65536, 1, True, False)
+    batch("c2_parallel_parse", "config 2 with the opt-in parallel BestSpeed parse (valid streams, not the "
+          "reference's bytes)", min(1024, nb * 16), 65536, 1, True, False, l1_parse=1)
     batch("c3_own", "config 3: %d x 1 MiB uncompress only (this library's BestSpeed streams), CRC-32 verified" % nb,
           nb, 1 << 20, 1, False, True)
     batch("c3_zlib6", "config 3: %d x 1 MiB uncompress only, gzip members made by system zlib level 6 "
