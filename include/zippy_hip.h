@@ -140,6 +140,22 @@ int zh_compress_batch(zh_ctx *ctx, const void *const *srcs, const size_t *lens, 
 int zh_uncompress_batch(zh_ctx *ctx, const void *const *srcs, const size_t *lens, size_t n,
                         int data_format, void **dsts, size_t *dst_lens, int32_t *statuses);
 
+/* The two calls above with the results in buffers of the CALLER'S: dsts[i] (caps[i] bytes) on
+ * entry.  No reference counterpart -- zippy returns fresh strings (zippy.nim:11-18,100-104) -- but
+ * what a binding that owns its strings wants: the shim allocates `newString(zh_compress_bound(n))`
+ * (or a string of ISIZE bytes), the library fills it, and the only copy left is the one from the
+ * pinned staging chunk.  A result that does not fit: statuses[i] = ZH_ERR_DST_TOO_SMALL and
+ * dst_lens[i] = the size it needs.  On return dsts[i] is the caller's pointer for every buffer that
+ * was filled and NULL otherwise; nothing here goes to zh_free.  For streams without a size field
+ * (zlib, raw deflate) caps[i] is also how much is decoded at most before the expansion bound is
+ * tried. */
+int zh_compress_batch_into(zh_ctx *ctx, const void *const *srcs, const size_t *lens, size_t n,
+                           int level, int data_format, void **dsts, const size_t *caps,
+                           size_t *dst_lens, int32_t *statuses);
+int zh_uncompress_batch_into(zh_ctx *ctx, const void *const *srcs, const size_t *lens, size_t n,
+                             int data_format, void **dsts, const size_t *caps, size_t *dst_lens,
+                             int32_t *statuses);
+
 /* One batch over several GPUs of a node.  zippy's compress()/uncompress() are pure functions of
  * one buffer (zippy.nim:11-16,100-104), so a batch shards by contiguous index ranges with no
  * exchange step: context r (one per device, made with zh_create(r, NULL, &ctx[r])) takes range r

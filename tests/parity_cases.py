@@ -544,6 +544,38 @@ def check_ragged_staging(eng, scale):
             assert [b for i, b in enumerate(back) if i != 7] == [b for i, b in enumerate(bufs) if i != 7]
 
 
+def check_batch_into(eng):
+    """zh_compress_batch_into / zh_uncompress_batch_into: the results of the ordinary calls, in
+    buffers of the caller's; one that is too small only fails its own slot and learns its size."""
+    from zippy_amd import synth
+    eng.set_gzip_fname_len(0)
+    bufs = [b.tobytes() for b in synth.gen_batch("mix", 5, 70001)] + [b"", b"x" * 300, synth.corpus_file("html")]
+    want, sts = eng.compress_batch(bufs, 1, oracle.dfGzip)
+    outs = [bytearray(eng.compress_bound(len(b))) for b in bufs]
+    outs[2] = bytearray(100)  # too small
+    lens, sts2, filled = eng.compress_batch_into(bufs, outs, 1, oracle.dfGzip)
+    for i, b in enumerate(bufs):
+        assert lens[i] == len(want[i]), i
+        if i == 2:
+            assert sts2[i] != 0 and not filled[i]
+        else:
+            assert sts2[i] == 0 and bytes(outs[i][:lens[i]]) == want[i], i
+    for fmt in (oracle.dfGzip, oracle.dfDeflate):
+        blobs, _ = eng.compress_batch(bufs, 1, fmt)
+        back = [bytearray(len(b)) for b in bufs]
+        back[4] = bytearray(len(bufs[4]) - 1)  # one byte short
+        blobs = list(blobs)
+        blobs[1] = blobs[1][:len(blobs[1]) // 2]  # and a damaged stream
+        lens, sts3, filled = eng.uncompress_batch_into(blobs, back, fmt)
+        for i, b in enumerate(bufs):
+            if i == 1:
+                assert sts3[i] != 0
+            elif i == 4:
+                assert sts3[i] != 0 and lens[i] == len(b), (fmt, sts3[i], lens[i])
+            else:
+                assert sts3[i] == 0 and lens[i] == len(b) and bytes(back[i]) == b, (fmt, i)
+
+
 def check_unsized_streams(eng):
     """zlib / raw deflate streams carry no size: the host call guesses 4x, and streams that
     outgrow the guess are sized and decoded again -- next to streams that fit, damaged ones and

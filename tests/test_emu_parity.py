@@ -132,6 +132,10 @@ def test_emu_wide_code_length_counts(eng):
     pc.check_wide_code_length_counts(eng)
 
 
+def test_emu_batch_into(eng):
+    pc.check_batch_into(eng)
+
+
 def test_emu_ragged_staging(eng):
     pc.check_ragged_staging(eng, 1)
 

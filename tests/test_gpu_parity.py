@@ -130,6 +130,10 @@ def test_gpu_wide_code_length_counts(eng):
     pc.check_wide_code_length_counts(eng)
 
 
+def test_gpu_batch_into(eng):
+    pc.check_batch_into(eng)
+
+
 def test_gpu_unsized_streams(eng, inflate_mode):
     pc.check_unsized_streams(eng)
 

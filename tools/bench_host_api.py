@@ -40,6 +40,7 @@ def main():
     cc, cu = c_abi_times(api.engine(), bufs, outs, args.reps)
     c_plain = c_abi_compress_time(api.engine(), bufs, args.reps, False)
     c_pipe = c_abi_compress_time(api.engine(), bufs, args.reps, True)
+    ic, iu = c_abi_into_times(api.engine(), bufs, outs, args.reps)
     print(json.dumps({
         "workload": "%d x %d B host buffers through zh_compress_batch / zh_uncompress_batch (level 1, gzip)" %
                     (args.buffers, args.size),
@@ -47,7 +48,10 @@ def main():
                   "both_GiBps": round(total / (cc + cu), 3),
                   "compress_one_plan_GiBps": round(total / c_plain, 3),
                   "compress_pipelined_groups_GiBps": round(total / c_pipe, 3),
-                  "note": "the C call alone: pageable host buffers in, malloc'ed results out"},
+                  "note": "the C call alone: pageable host buffers in, malloc'ed results out",
+                  "into_compress_GiBps": round(total / ic, 3), "into_uncompress_GiBps": round(total / iu, 3),
+                  "into_both_GiBps": round(total / (ic + iu), 3),
+                  "into_note": "zh_*_batch_into: results into buffers the caller owns and has touched before"},
         "python_mirror": {"compress_GiBps": round(total / tc, 3), "uncompress_GiBps": round(total / tu, 3),
                           "both_GiBps": round(total / (tc + tu), 3),
                           "note": "adds the test mirror's ctypes marshalling (bytes objects in and out)"}}))
@@ -74,6 +78,36 @@ def c_abi_times(eng, bufs, blobs, reps):
     cc = min(call(eng.lib.zh_compress_batch, bufs, 1, 2) for _ in range(reps))
     cu = min(call(eng.lib.zh_uncompress_batch, blobs, 0) for _ in range(reps))
     return cc, cu
+
+
+def c_abi_into_times(eng, bufs, blobs, reps):
+    """zh_compress_batch_into / zh_uncompress_batch_into: output buffers allocated (and touched) by the
+    caller once, reused by every repetition."""
+    import ctypes as c
+
+    def call(fn, items, out_sizes, *mid):
+        n = len(items)
+        srcs = (c.c_void_p * n)(*[c.cast(c.c_char_p(k), c.c_void_p) for k in items])
+        lens = (c.c_size_t * n)(*[len(k) for k in items])
+        outs = [bytearray(sz) for sz in out_sizes]  # (zero-filled: the pages exist)
+        views = [(c.c_char * len(o)).from_buffer(o) for o in outs]
+        caps = (c.c_size_t * n)(*out_sizes)
+        best = 1e9
+        for _ in range(reps):
+            dsts = (c.c_void_p * n)(*[c.addressof(v) for v in views])
+            dlens, sts = (c.c_size_t * n)(), (c.c_int32 * n)()
+            t = time.perf_counter()
+            rc = fn(eng._h, srcs, lens, n, *mid, dsts, caps, dlens, sts)
+            best = min(best, time.perf_counter() - t)
+            assert rc == 0 and not any(sts)
+        return best, outs, list(dlens)
+
+    bound = [eng.compress_bound(len(b)) for b in bufs]
+    ic, outs, dl = call(eng.lib.zh_compress_batch_into, bufs, bound, 1, 2)
+    assert bytes(outs[0][:dl[0]]) == blobs[0]
+    iu, back, _ = call(eng.lib.zh_uncompress_batch_into, blobs, [len(b) for b in bufs], 0)
+    assert bytes(back[-1]) == bufs[-1]
+    return ic, iu
 
 
 def c_abi_compress_time(eng, bufs, reps, pipelined):

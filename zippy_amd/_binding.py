@@ -25,6 +25,14 @@ _SIGS = {
     "zh_compress_batch": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
                                      _c.c_size_t, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p),
                                      _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_int32)]),
+    "zh_compress_batch_into": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
+                                          _c.c_size_t, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p),
+                                          _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t),
+                                          _c.POINTER(_c.c_int32)]),
+    "zh_uncompress_batch_into": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
+                                            _c.c_size_t, _c.c_int, _c.POINTER(_c.c_void_p),
+                                            _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t),
+                                            _c.POINTER(_c.c_int32)]),
     "zh_uncompress_batch": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_void_p),
                                        _c.POINTER(_c.c_size_t), _c.c_size_t, _c.c_int,
                                        _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
@@ -361,6 +369,27 @@ class Engine:
 
     def uncompress_batch(self, bufs, data_format=dfDetect):
         return self._batch(self.lib.zh_uncompress_batch, bufs, data_format)
+
+    def _batch_into(self, fn, bufs, outs, *mid):
+        """`outs`: writable buffers (bytearray / ctypes arrays) the library fills.
+        -> (lengths, statuses): lengths[i] is the result's size, also when it did not fit."""
+        n = len(bufs)
+        keep = [bytes(b) if not isinstance(b, bytes) else b for b in bufs]
+        srcs = (_c.c_void_p * n)(*[_c.cast(_c.c_char_p(k), _c.c_void_p) for k in keep])
+        lens = (_c.c_size_t * n)(*[len(k) for k in keep])
+        views = [(_c.c_char * len(o)).from_buffer(o) if len(o) else None for o in outs]
+        dsts = (_c.c_void_p * n)(*[_c.addressof(v) if v is not None else None for v in views])
+        caps = (_c.c_size_t * n)(*[len(o) for o in outs])
+        dlens, sts = (_c.c_size_t * n)(), (_c.c_int32 * n)()
+        self._check(fn(self._h, srcs, lens, n, *mid, dsts, caps, dlens, sts))
+        filled = [dsts[i] is not None or dlens[i] == 0 for i in range(n)]
+        return list(dlens), list(sts), filled
+
+    def compress_batch_into(self, bufs, outs, level=DefaultCompression, data_format=dfGzip):
+        return self._batch_into(self.lib.zh_compress_batch_into, bufs, outs, level, data_format)
+
+    def uncompress_batch_into(self, bufs, outs, data_format=dfDetect):
+        return self._batch_into(self.lib.zh_uncompress_batch_into, bufs, outs, data_format)
 
     def _raise_first(self, outs, sts):
         for st in sts:

@@ -86,6 +86,11 @@ struct zh_ctx {
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   bool pin_busy[2] = {false, false};
   hipStream_t copy_stream = nullptr;  // transfers of a pipelined batch, next to `stream`'s kernels
+  // zh_*_batch_into: the caller's output buffers and their sizes for the call in progress
+  // (into_base: the dsts array the batch functions were handed, to find a buffer's index again)
+  void* const* into_ptrs = nullptr;
+  const size_t* into_caps = nullptr;
+  void** into_base = nullptr;
   uint64_t pipe_min = 0, pipe_group = 0;  // zh_set_host_pipeline (0: ZH_PIPE_MIN / ZH_PIPE_GROUP / default)
   // device memory the context has freed, kept for its next call (ctx_malloc / ctx_free)
   struct DevBlock {
@@ -1496,6 +1501,16 @@ int download_pack(zh_ctx* ctx, hipStream_t stream, Download& dl, const uint8_t* 
   dl.total = total;
   for (size_t i = 0; i < n; i++) {
     if (!take[i]) continue;
+    if (ctx->into_ptrs) {  // the caller's buffer, if the result fits (its size is reported either way)
+      const size_t gi = (size_t)((dsts + i) - ctx->into_base);
+      dst_lens[i] = olen[i];
+      if (olen[i] > ctx->into_caps[gi] || (!ctx->into_ptrs[gi] && olen[i])) {
+        statuses[i] = ZH_ERR_DST_TOO_SMALL;
+        continue;
+      }
+      dsts[i] = ctx->into_ptrs[gi];
+      continue;
+    }
     dsts[i] = malloc(olen[i] ? olen[i] : 1);
     if (!dsts[i]) {
       statuses[i] = ZH_ERR_NOMEM;
@@ -1656,7 +1671,7 @@ int compress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, const size_t*
     (void)hipStreamSynchronize(ks);
     for (int k = 0; k < 2; k++) ctx->pin_busy[k] = false;
     for (size_t i = 0; i < n; i++) {
-      free(dsts[i]);
+      if (!ctx->into_ptrs) free(dsts[i]);  // (zh_*_batch_into: the buffers are the caller's)
       dsts[i] = nullptr;
       dst_lens[i] = 0;
       statuses[i] = ZH_OK;
@@ -1769,6 +1784,26 @@ extern "C" int zh_compress_batch(zh_ctx* ctx, const void* const* srcs, const siz
                                  int32_t* statuses) {
   return compress_batch_impl(ctx, srcs, lens, n, level, data_format, dsts, dst_lens, statuses, nullptr);
 }
+// Results into buffers of the caller's: dsts[i] / caps[i] on entry.  A result that does not fit
+// gets ZH_ERR_DST_TOO_SMALL and its size in dst_lens[i]; on return dsts[i] is the caller's pointer
+// for every buffer that was filled and NULL otherwise.  Nothing here is to be given to zh_free.
+struct IntoScope {
+  zh_ctx* ctx;
+  std::vector<void*> ptrs;
+  IntoScope(zh_ctx* c, void** dsts, const size_t* caps, size_t n) : ctx(c), ptrs(dsts, dsts + n) {
+    ctx->into_ptrs = ptrs.data();
+    ctx->into_caps = caps;
+    ctx->into_base = dsts;
+  }
+  ~IntoScope() { ctx->into_ptrs = nullptr, ctx->into_caps = nullptr, ctx->into_base = nullptr; }
+};
+extern "C" int zh_compress_batch_into(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
+                                      int level, int data_format, void** dsts, const size_t* caps,
+                                      size_t* dst_lens, int32_t* statuses) {
+  if (!ctx || (n && (!dsts || !caps))) return ZH_ERR_ARGUMENT;
+  IntoScope scope(ctx, dsts, caps, n);
+  return compress_batch_impl(ctx, srcs, lens, n, level, data_format, dsts, dst_lens, statuses, nullptr);
+}
 extern "C" int zh_compress_batch_crc32(zh_ctx* ctx, const void* const* srcs, const size_t* lens,
                                        size_t n, int level, int data_format, void** dsts,
                                        size_t* dst_lens, int32_t* statuses, uint32_t* crcs) {
@@ -1862,7 +1897,7 @@ static int uncompress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, cons
     (void)hipStreamSynchronize(ks);
     for (int k = 0; k < 2; k++) ctx->pin_busy[k] = false;
     for (size_t i = 0; i < n; i++) {
-      free(dsts[i]);
+      if (!ctx->into_ptrs) free(dsts[i]);  // (zh_*_batch_into: the buffers are the caller's)
       dsts[i] = nullptr;
       dst_lens[i] = 0;
       statuses[i] = ZH_OK;
@@ -2023,6 +2058,15 @@ extern "C" int zh_uncompress_batch(zh_ctx* ctx, const void* const* srcs, const s
                                    size_t n, int data_format, void** dsts, size_t* dst_lens,
                                    int32_t* statuses) {
   return uncompress_batch_impl(ctx, srcs, lens, n, data_format, nullptr, dsts, dst_lens, statuses, nullptr);
+}
+extern "C" int zh_uncompress_batch_into(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
+                                        int data_format, void** dsts, const size_t* caps, size_t* dst_lens,
+                                        int32_t* statuses) {
+  if (!ctx || (n && (!dsts || !caps))) return ZH_ERR_ARGUMENT;
+  IntoScope scope(ctx, dsts, caps, n);
+  // (the capacities double as size hints: a stream without a size field is decoded into as much)
+  std::vector<uint64_t> hints(caps, caps + n);
+  return uncompress_batch_impl(ctx, srcs, lens, n, data_format, hints.data(), dsts, dst_lens, statuses, nullptr);
 }
 extern "C" int zh_uncompress_batch_sized(zh_ctx* ctx, const void* const* srcs, const size_t* lens,
                                          size_t n, int data_format, const uint64_t* size_hints,
