@@ -54,6 +54,32 @@ def main(first, count):
                 print("COMPRESS MISMATCH seed", seed, "case", i, len(src), st)
         back, sts = eng.uncompress_batch(outs)
         bad += sum(1 for s, b, st in zip(bufs, back, sts) if st != 0 or b != s)
+        # the opt-in parallel parse: valid streams (oracle + zlib decode them), no larger than 1.02 x the
+        # oracle's in total, the same bytes twice
+        eng.set_l1_parse(1)
+        try:
+            po, ps = eng.compress_batch(bufs, 1, oracle.dfGzip)
+            po2, _ = eng.compress_batch(bufs, 1, oracle.dfGzip)
+        finally:
+            eng.set_l1_parse(-1)
+        tot_p = tot_o = 0
+        for i, (src, out, st, ref) in enumerate(zip(bufs, po, ps, outs)):
+            ok = st == 0 and zlib.decompress(out, 31) == src
+            if ok:
+                try:
+                    ok = oracle.uncompress(out, oracle.dfGzip) == src
+                except oracle.ZippyError:
+                    ok = False
+            if not ok:
+                bad += 1
+                print("PARALLEL PARSE INVALID seed", seed, "case", i, len(src), st)
+            tot_p += len(out)
+            tot_o += len(ref)
+        if po != po2 or tot_p > 1.02 * tot_o:
+            bad += 1
+            print("PARALLEL PARSE seed", seed, "deterministic", po == po2, "size", tot_p, "oracle", tot_o)
+        pb, pst = eng.uncompress_batch(po)
+        bad += sum(1 for s_, b_, st in zip(bufs, pb, pst) if st != 0 or b_ != s_)
         # a few buffers at other levels
         for level in (-1, 9, -2, 0):
             pick = [bufs[i] for i in rnd.sample(range(len(bufs)), 4)]
