@@ -55,6 +55,45 @@ int main(void) {
     if (back_len[i] != lens[i] || memcmp(back[i], text[i], lens[i]) != 0) return fail("round trip differs", -1);
   }
 
+  /* the same two calls with the results in buffers of this program's (zh_*_batch_into), and with
+   * the parallel BestSpeed parse switched on: other bytes, the same round trip */
+  {
+    static unsigned char cbuf[N][2 * 70000 + 8192], ubuf[N][70000];
+    void *cd[N], *ud[N];
+    size_t ccap[N], ucap[N], clen[N], ulen[N];
+    int pass;
+    for (pass = 0; pass < 2; pass++) {
+      zh_set_l1_parse(ctx, pass);
+      for (i = 0; i < N; i++) {
+        cd[i] = cbuf[i];
+        ccap[i] = zh_compress_bound(lens[i], ZH_DF_GZIP);
+        if (ccap[i] > sizeof cbuf[i]) return fail("zh_compress_bound", -1);
+        ud[i] = ubuf[i];
+        ucap[i] = lens[i];
+      }
+      rc = zh_compress_batch_into(ctx, srcs, lens, N, 1, ZH_DF_GZIP, cd, ccap, clen, st);
+      if (rc != ZH_OK) return fail("zh_compress_batch_into", rc);
+      for (i = 0; i < N; i++) {
+        if (st[i] != ZH_OK || cd[i] != (void *)cbuf[i]) return fail("compress_into status", st[i]);
+        if (pass == 0 && (clen[i] != comp_len[i] || memcmp(cbuf[i], comp[i], clen[i]) != 0))
+          return fail("compress_into differs from compress", -1);
+      }
+      rc = zh_uncompress_batch_into(ctx, (const void *const *)cd, clen, N, ZH_DF_GZIP, ud, ucap, ulen, st);
+      if (rc != ZH_OK) return fail("zh_uncompress_batch_into", rc);
+      for (i = 0; i < N; i++)
+        if (st[i] != ZH_OK || ulen[i] != lens[i] || memcmp(ubuf[i], text[i], lens[i]) != 0)
+          return fail("into round trip differs", st[i]);
+    }
+    zh_set_l1_parse(ctx, -1);
+    /* a buffer that is too small only fails its own slot and learns its size */
+    for (i = 0; i < N; i++) cd[i] = cbuf[i];
+    ccap[3] = 10;
+    rc = zh_compress_batch_into(ctx, srcs, lens, N, 1, ZH_DF_GZIP, cd, ccap, clen, st);
+    if (rc != ZH_OK || st[3] != ZH_ERR_DST_TOO_SMALL || cd[3] != NULL || clen[3] != comp_len[3])
+      return fail("compress_into with a small buffer", rc ? rc : st[3]);
+    if (st[4] != ZH_OK) return fail("neighbour of a small buffer", st[4]);
+  }
+
   /* a damaged member fails its own slot with the reference's error, the others still decode */
   ((unsigned char *)comp[3])[comp_len[3] / 2] ^= 0x10;
   for (i = 0; i < N; i++) zh_free(back[i]);
