@@ -323,6 +323,26 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
     return out
 
 
+def pp_fields(pp, N, comp_rank_exact, roof):
+    """The parallel-parse leg's fields of the result line (whole-job numbers; kernel times rank 0's)."""
+    total, steps = pp["total"], pp["steps"]
+    pk = pp["kernels"]
+    return {
+        "value_parallel_parse": round(total * steps / GIB / pp["elapsed"], 3),
+        "ratio_parallel_parse": round(total / pp["comp_all"], 4),
+        "parallel_parse": {
+            "what": "same step, BestSpeed matcher = zh_l1p_match_kernel (not the reference's token stream; round "
+                    "trip verified on device + zlib sample)",
+            "ms_per_step": round(pp["elapsed"] * 1e3 / steps, 3),
+            "compress_GiBps": round(total / GIB / (pp["tc"] * 1e-3), 3),
+            "uncompress_GiBps": round(total / GIB / (pp["tu"] * 1e-3), 3),
+            "size_vs_exact_parse": round(pp["comp_rank"] / comp_rank_exact, 5),
+            "kernels_ms": {k: round(v, 4) for k, v in sorted(pk.items(), key=lambda kv: -kv[1]) if k != "end"},
+            "roofline_matcher": roof(N, pk["zh_l1p_match_kernel"], "zh_l1p_match_kernel"),
+        },
+    }
+
+
 def relaunch_under_torchrun(args):
     import socket
     import subprocess
@@ -502,6 +522,48 @@ def main():
     value = total_uncompressed * args.steps / GIB / elapsed
     ms_per_step = elapsed * 1e3 / args.steps
 
+    # ---- the same step with the opt-in PARALLEL BestSpeed parse (zh_set_l1_parse(ctx, 1),
+    # csrc/zh_l1p_match.hip): valid streams that are not the reference's bytes, under the north star's
+    # encoder contract (round trip exact, size within 2 % of zippy's).  `value` stays the
+    # byte-identical parse.  Every rank, timed like the headline (barrier, max over ranks). ----
+    pp = None
+    if do_c and do_u and args.foreign is None and args.level == 1 and not args.no_parallel_parse:
+        import zlib
+        eng.set_l1_parse(1)
+        pstate = {}
+
+        def verify_pp():
+            plens, psts = cplan.results()
+            assert all(x == 0 for x in psts), "parallel parse: compress statuses"
+            ul, us = uplan.results()
+            assert all(x == 0 for x in us) and ul == [size] * n, "parallel parse: uncompress statuses"
+            assert torch.equal(d_back, d_src), "parallel parse: round trip mismatch"
+            for i in range(0, n, max(1, n // 8)):  # a sample through system zlib as well
+                z = d_comp[i * slot:i * slot + plens[i]].cpu().numpy().tobytes()
+                assert zlib.decompress(z, 31) == host[i].tobytes(), "parallel parse: zlib disagrees"
+            pstate["C"] = sum(plens)
+        time_plans(torch, stream, cplan, uplan, (d_src, d_comp, d_back), 0, max(args.warmup, 1), verify_pp)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ptc, ptu, pk = time_plans(torch, stream, cplan, uplan, (d_src, d_comp, d_back), args.steps, 0)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        p_elapsed = time.perf_counter() - t0
+        eng.set_l1_parse(-1)
+        p_comp = pstate["C"]
+        if use_dist:
+            t = torch.tensor([p_elapsed, ptc, ptu], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            p_elapsed, ptc, ptu = (float(x) for x in t.tolist())
+            c = torch.tensor([p_comp], device="cuda", dtype=torch.int64)
+            dist.all_reduce(c)
+            p_comp = int(c.item())
+        pp = {"elapsed": p_elapsed, "tc": ptc, "tu": ptu, "kernels": pk, "comp_all": p_comp,
+              "comp_rank": pstate["C"], "total": total_uncompressed, "steps": args.steps}
+
     # ---- N > 1: the batch lives on rank 0 and comes home to rank 0 (RCCL over xGMI) ----
     transfer = None
     if use_dist and scaling == "strong" and not args.no_transfer and do_c and do_u:
@@ -569,39 +631,8 @@ def main():
             out["value_incl_transfer"] = transfer["value_incl_transfer"]
         headline = (world == 1 and do_c and do_u and args.foreign is None and args.level == 1
                     and size == 1 << 20 and n >= 8)
-        if do_c and do_u and args.foreign is None and args.level == 1 and not args.no_parallel_parse:
-            # the same step with the opt-in PARALLEL BestSpeed parse (zh_set_l1_parse(ctx, 1),
-            # csrc/zh_l1p_match.hip): valid streams that are not the reference's bytes, under the
-            # north star's encoder contract (round trip exact, size within 2 % of zippy's).
-            # `value` above stays the byte-identical parse.
-            import zlib
-            eng.set_l1_parse(1)
-
-            def verify_pp():
-                plens, psts = cplan.results()
-                assert all(x == 0 for x in psts), "parallel parse: compress statuses"
-                ul, us = uplan.results()
-                assert all(x == 0 for x in us) and ul == [size] * n, "parallel parse: uncompress statuses"
-                assert torch.equal(d_back, d_src), "parallel parse: round trip mismatch"
-                for i in range(0, n, max(1, n // 8)):  # a sample through system zlib as well
-                    z = d_comp[i * slot:i * slot + plens[i]].cpu().numpy().tobytes()
-                    assert zlib.decompress(z, 31) == host[i].tobytes(), "parallel parse: zlib disagrees"
-                verify_pp.C = sum(plens)
-            ptc, ptu, pk = time_plans(torch, stream, cplan, uplan, (d_src, d_comp, d_back), args.steps,
-                                      max(args.warmup, 1), verify_pp)
-            eng.set_l1_parse(-1)
-            out["value_parallel_parse"] = round(n * size / GIB / ((ptc + ptu) * 1e-3), 3)
-            out["ratio_parallel_parse"] = round(n * size / verify_pp.C, 4)
-            out["parallel_parse"] = {
-                "what": "same step, BestSpeed matcher = zh_l1p_match_kernel (not the reference's token stream; "
-                        "round trip verified on device + zlib sample; size vs the exact parse: %.4f)" % (
-                            verify_pp.C / comp_total),
-                "ms_per_step": round(ptc + ptu, 3), "compress_GiBps": round(n * size / GIB / (ptc * 1e-3), 3),
-                "uncompress_GiBps": round(n * size / GIB / (ptu * 1e-3), 3),
-                "size_vs_exact_parse": round(verify_pp.C / comp_total, 5),
-                "kernels_ms": {k: round(v, 4) for k, v in sorted(pk.items(), key=lambda kv: -kv[1]) if k != "end"},
-                "roofline_matcher": roof(N, pk["zh_l1p_match_kernel"], "zh_l1p_match_kernel"),
-            }
+        if pp:
+            out.update(pp_fields(pp, N, comp_total, roof))
         if headline and not args.no_configs:
             # the other BASELINE configs, so that the driver's line carries all five
             cplan.close()
