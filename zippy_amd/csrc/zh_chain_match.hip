@@ -288,18 +288,26 @@ __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __r
 // ---- 2b. the positions a greedy walk comes by ----
 // The parse (kernel 3) only ever asks for the positions it visits -- about a third of them -- and
 // a walk p -> p + (length ? length : 1) falls in step with the true one quickly wherever it
-// starts.  So a thread walks a 128-position chunk from its first byte and works out the best match
+// starts.  So a thread walks a 32-position chunk from its first byte and works out the best match
 // of what it visits, on to the first position behind its chunk that the next chunk's walk has
 // already done (there the two walks have met) or 1024 positions at most.  Whatever the true walk
 // visits and no walk here did is worked out by kernel 3 when it gets there: the values are those of
 // kernel 2a either way, only fewer.
-__global__ __launch_bounds__(256) void zh_chain_walk_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
+#ifndef ZH_WALK_CHUNK
+#define ZH_WALK_CHUNK 32
+#endif
+namespace {
+constexpr uint32_t kWalkChunk = ZH_WALK_CHUNK;  // positions a walk starts at the first of (512 x 1 MiB, walk + parse ms: 16: 67.5, 32: 63.3, 64: 64.5, 128: 70.7, 256: 89.8)
+constexpr uint32_t kWalkThreads = ZH_FRAG_SIZE / kWalkChunk < 256u ? ZH_FRAG_SIZE / kWalkChunk : 256u;
+constexpr uint32_t kWalkGroups = ZH_FRAG_SIZE / kWalkChunk / kWalkThreads;  // workgroups a fragment
+}  // namespace
+__global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
                                                             int good, int nice, int max_chain,
                                                             const uint64_t* __restrict__ prevw,
                                                             uint32_t* __restrict__ best, uint32_t first_frag) {
-  constexpr uint32_t kChunk = 128;
-  const uint32_t f = first_frag + blockIdx.x / (ZH_FRAG_SIZE / kChunk / 256u);
-  const uint32_t local = ((blockIdx.x % (ZH_FRAG_SIZE / kChunk / 256u)) * 256u + threadIdx.x) * kChunk;
+  constexpr uint32_t kChunk = kWalkChunk;
+  const uint32_t f = first_frag + blockIdx.x / kWalkGroups;
+  const uint32_t local = ((blockIdx.x % kWalkGroups) * kWalkThreads + threadIdx.x) * kChunk;
   const ZhFragDesc fd = a.frags[f];
   if (local >= fd.len) return;
   const ZhBlockDesc bd = a.blocks[fd.block];
@@ -633,7 +641,7 @@ extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src,
     } else {
       // (nothing is worked out yet: the walks of one launch may look at the next launch's entries)
       if (f0 == 0) (void)hipMemsetAsync(best, 0, (size_t)a.nfrags * ZH_FRAG_SIZE * 4u, stream);
-      hipLaunchKernelGGL(zh_chain_walk_kernel, dim3(nf), dim3(256), 0, stream, d_src, a, good, nice, max_chain,
+      hipLaunchKernelGGL(zh_chain_walk_kernel, dim3(nf * kWalkGroups), dim3(kWalkThreads), 0, stream, d_src, a, good, nice, max_chain,
                          prevw, best, f0);
     }
   }
