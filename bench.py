@@ -166,7 +166,7 @@ def time_plans(torch, stream, cplan, uplan, bufs, steps, warmup, verify=None):
     """`warmup` untimed passes (verified by `verify`), then `steps` timed ones with HIP events on
     the launch stream: (compress ms, uncompress ms, per-kernel average ms)."""
     d_src, d_comp, d_back = bufs
-    for _ in range(max(warmup, 1)):
+    for _ in range(warmup):
         if cplan is not None:
             cplan.run(d_src.data_ptr(), d_comp.data_ptr())
         if uplan is not None:
