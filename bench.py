@@ -409,7 +409,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus
 
-    from zippy_amd import api, sharding, synth
+    import synth
+    from zippy_amd import api, sharding
     from zippy_amd._binding import Engine
 
     scaling = args.scaling or ("strong" if world > 1 else "weak")

@@ -12,7 +12,8 @@ it into seeded buffers:
   G-rand  uniform bytes (forces the stored-block path, deflate.nim:274-277).
   G-zero  all zeros (max-length matches at distance 1).
 
-Nothing here touches the oracle or the GPU.
+Test and benchmark data only (bench.py, tests/, tools/): not part of the product package zippy_amd,
+which never imports it.  Nothing here touches the oracle or the GPU.
 """
 import functools
 import json
@@ -21,7 +22,7 @@ import zlib
 
 import numpy as np
 
-_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
 
 SEED_BASE = 0x5A49505059000000  # "ZIPPY"
 

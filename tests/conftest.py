@@ -14,7 +14,7 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def manifest():
-    from zippy_amd import synth
+    import synth
     return synth.manifest()
 
 
@@ -22,7 +22,7 @@ def manifest():
 def golds(manifest):
     """name -> uncompressed bytes for every corpus/gold file of the reference's
     tests (tests/test.nim:16-39), rebuilt from the committed fixtures."""
-    from zippy_amd import synth
+    import synth
     out = {}
     for fx, meta in manifest["fixtures"].items():
         if meta["gold"] and fx.endswith(".gz") and meta["gold"] not in out:

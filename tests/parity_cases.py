@@ -10,7 +10,7 @@ import zlib
 import numpy as np
 
 import oracle
-from zippy_amd import synth
+import synth
 
 WBITS = {oracle.dfDeflate: -15, oracle.dfZlib: 15, oracle.dfGzip: 31}
 FORMATS = (oracle.dfDeflate, oracle.dfZlib, oracle.dfGzip)
@@ -486,7 +486,7 @@ def check_ragged_staging(eng, scale):
     """Host-buffer calls whose buffers straddle the staging chunks (upload) and whose results
     straddle them again (download): ragged sizes, empty buffers in between, one buffer of
     several chunks.  `scale` stretches the sizes (1 for the emulator's 128 KiB chunks)."""
-    from zippy_amd import synth
+    import synth
     sizes = [0, 70001, 1, 262144 + 13, 0, 0, 4095, 400000 + 7, 65536, 131072, 3, 0, 99999, 0]
     pool = synth.gen_batch("mix", 8, 1 << 20).tobytes()
     bufs, at = [], 0
@@ -547,7 +547,7 @@ def check_ragged_staging(eng, scale):
 def check_batch_into(eng):
     """zh_compress_batch_into / zh_uncompress_batch_into: the results of the ordinary calls, in
     buffers of the caller's; one that is too small only fails its own slot and learns its size."""
-    from zippy_amd import synth
+    import synth
     eng.set_gzip_fname_len(0)
     bufs = [b.tobytes() for b in synth.gen_batch("mix", 5, 70001)] + [b"", b"x" * 300, synth.corpus_file("html")]
     want, sts = eng.compress_batch(bufs, 1, oracle.dfGzip)
@@ -581,7 +581,7 @@ def check_unsized_streams(eng):
     outgrow the guess are sized and decoded again -- next to streams that fit, damaged ones and
     (for dfDetect) gzip members, in one call."""
     import zlib
-    from zippy_amd import synth
+    import synth
     text = synth.corpus_file("alice29.txt")[:90000]
     plain = [b"", b"a", text, b"\x00" * 300000, bytes(range(256)) * 40, b"ab" * 70000, text[:777],
              b"\xff" * 1000000]

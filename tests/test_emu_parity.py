@@ -7,7 +7,7 @@ import pytest
 import emu
 import oracle
 import parity_cases as pc
-from zippy_amd import synth
+import synth
 
 
 @pytest.fixture(scope="module")

@@ -9,7 +9,7 @@ import pytest
 
 import oracle
 import parity_cases as pc
-from zippy_amd import synth
+import synth
 
 pytestmark = pytest.mark.gpu
 

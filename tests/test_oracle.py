@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
-from zippy_amd import synth
+import synth
 
 # tests/test.nim:16-39
 TEST_GOLDS = ["randtest1.gold", "randtest2.gold", "randtest3.gold", "rfctest1.gold",

@@ -15,7 +15,7 @@ CHILD = r"""
 import random, sys, zlib
 sys.path.insert(0, %(root)r)
 import oracle
-from zippy_amd import synth
+import synth
 rnd = random.Random(7)
 inputs = [b"", b"a", b"abcd" * 5, bytes(range(256)) * 3, synth.corpus_file("alice29.txt")[:70000],
           synth.gen_batch("mix", 1, 150000)[0].tobytes(), synth.gen_batch("runs", 1, 40000)[0].tobytes(),

@@ -27,7 +27,8 @@ def _worker(rank, world, port, n_buffers, buf_bytes, result_path):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     import emu
     import oracle
-    from zippy_amd import sharding, synth
+    import synth
+    from zippy_amd import sharding
     eng = emu.engine()
     batch = None
     if rank == 0:

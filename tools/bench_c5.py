@@ -25,7 +25,8 @@ def main():
     ap.add_argument("--plain", action="store_true")
     args = ap.parse_args()
     import torch
-    from zippy_amd import api, synth
+    import synth
+    from zippy_amd import api
     from zippy_amd._binding import Engine
 
     size = args.mib << 20

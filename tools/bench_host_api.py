@@ -21,7 +21,8 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
     import torch  # noqa: F401  (initialises the HIP runtime the library shares)
-    from zippy_amd import api, synth
+    import synth
+    from zippy_amd import api
     bufs = [b.tobytes() for b in synth.gen_batch("mix", args.buffers, args.size)]
     total = args.buffers * args.size / 2.0**30
     api.engine().set_gzip_fname_len(0)

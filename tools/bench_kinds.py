@@ -18,7 +18,8 @@ def main():
     ap.add_argument("--kinds", default="mix,rand,zero,runs")
     args = ap.parse_args()
     import torch
-    from zippy_amd import api, synth
+    import synth
+    from zippy_amd import api
     from zippy_amd._binding import Engine
     n, size = args.buffers, args.size
     stream = torch.cuda.current_stream()

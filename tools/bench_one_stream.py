@@ -17,7 +17,8 @@ def main():
     ap.add_argument("--mib", type=int, default=128)
     args = ap.parse_args()
     import torch
-    from zippy_amd import api, synth
+    import synth
+    from zippy_amd import api
     from zippy_amd._binding import Engine
     stream = torch.cuda.current_stream()
     eng = Engine(api.LIB_PATH, stream=stream.cuda_stream)

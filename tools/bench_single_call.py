@@ -17,7 +17,8 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     args = ap.parse_args()
     import torch  # noqa: F401
-    from zippy_amd import api, synth
+    import synth
+    from zippy_amd import api
     eng = api.engine()
     eng.set_gzip_fname_len(0)
     src = synth.gen_batch("mix", 1, args.size)[0].tobytes()

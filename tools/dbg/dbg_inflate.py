@@ -2,7 +2,8 @@ import sys, zlib
 sys.path.insert(0, '/root/repo')
 import torch
 torch.cuda.init()
-from zippy_amd import api, synth
+import synth
+from zippy_amd import api
 import os
 from zippy_amd._binding import Engine
 eng = Engine(os.environ.get('ZH_LIB', api.LIB_PATH))

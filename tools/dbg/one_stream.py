@@ -1,7 +1,8 @@
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import torch
-from zippy_amd import api, synth
+import synth
+from zippy_amd import api
 from zippy_amd._binding import Engine
 import zlib
 stream = torch.cuda.current_stream()

@@ -1,7 +1,7 @@
 """Pure-Python RFC 1951 token tracer (debug aid): lists tokens around an output offset."""
 import sys
 sys.path.insert(0, '/root/repo')
-from zippy_amd import synth
+import synth
 
 LBASE=[3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258]
 LEXT=[0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0]

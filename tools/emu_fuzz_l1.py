@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import emu  # noqa: E402
 import oracle  # noqa: E402
-from zippy_amd import synth  # noqa: E402
+import synth  # noqa: E402
 
 
 def main(seed):

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle  # noqa: E402
-from zippy_amd import api, synth  # noqa: E402
+import synth  # noqa: E402
+from zippy_amd import api  # noqa: E402
 
 
 def inputs(seed):

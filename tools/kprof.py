@@ -49,7 +49,8 @@ def main():
     ap.add_argument("--l1-parse", type=int, default=-1, help="1: the parallel BestSpeed parse (zh_l1p_match_kernel)")
     args = ap.parse_args()
     import torch
-    from zippy_amd import api, synth
+    import synth
+    from zippy_amd import api
     from zippy_amd._binding import Engine
     lib_path = api.LIB_PATH.replace(".so", "_kprof.so")
     n, size = args.buffers, args.size

@@ -18,7 +18,8 @@ def main():
     ap.add_argument("--tgz", action="store_true")
     args = ap.parse_args()
     import torch
-    from zippy_amd import api, synth
+    import synth
+    from zippy_amd import api
     from zippy_amd._binding import Engine
     from kprof import show
     eng = Engine(api.LIB_PATH.replace(".so", "_kprof.so"), stream=torch.cuda.current_stream().cuda_stream)
