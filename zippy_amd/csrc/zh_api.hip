@@ -983,6 +983,11 @@ extern "C" int zh_plan_uncompress_indexed(zh_ctx* ctx, uint64_t src_off, uint64_
 extern "C" int zh_plan_set_src_lens_device(zh_plan* plan, const uint64_t* d_lens) {
   if (!plan || plan->is_compress) return ZH_ERR_ARGUMENT;
   plan->ia.src_len_dev = d_lens;
+  // The segment geometry of a plan (zh_inflate_seg.hip: where block starts are searched for, where
+  // the last block may begin, the token regions) was laid over the HOST lengths -- here the slots'
+  // capacities, not the streams: segments over padding, the tail window in the wrong place.  Such
+  // a plan decodes with one workgroup a stream.
+  if (d_lens) plan->segmented = false;
   return ZH_OK;
 }
 
