@@ -359,6 +359,7 @@ struct zh_plan {
   uint64_t tok_words = 0;
   const uint64_t *tok_off = nullptr, *tok_cap = nullptr;
   bool tok_failed = false;
+  bool tok_borrowed = false;  // the pool belongs to the caller (pipelined groups share one)
   ZhInflateArgs seg{};
   uint8_t* seg_arena = nullptr;
   // large streams decoded segment-wise (zh_inflate_seg.hip); the symbol and window buffers come
@@ -419,7 +420,7 @@ extern "C" void zh_plan_destroy(zh_plan* p) {
   (void)hipStreamSynchronize(p->ctx->stream);
   if (p->arena) ctx_free(p->ctx, p->arena);
   if (p->seg_arena) ctx_free(p->ctx, p->seg_arena);
-  if (p->tok_pool) ctx_free(p->ctx, p->tok_pool);
+  if (p->tok_pool && !p->tok_borrowed) ctx_free(p->ctx, p->tok_pool);
   if (p->sg_arena) ctx_free(p->ctx, p->sg_arena);
   if (p->sg_sym) ctx_free(p->ctx, p->sg_sym);
   if (p->sg_windows) ctx_free(p->ctx, p->sg_windows);
@@ -1021,19 +1022,20 @@ extern "C" void zh_set_inflate_mode(zh_ctx* ctx, int mode) {
 // the token pool of a plan, allocated when it first runs in split mode; a failed allocation
 // (it is several times the output) sends the plan to the serial kernel for good
 static bool plan_token_pool(zh_plan* p) {
-  if (p->tok_pool) return true;
-  if (p->tok_failed || !p->tok_words) return false;
-  if (ctx_malloc(p->ctx, (void**)&p->tok_pool, p->tok_words * 4) != hipSuccess) {
-    (void)hipGetLastError();
-    p->tok_pool = nullptr;
-    p->tok_failed = true;
-    // not an error (the serial decoder gives the same bytes), but several times slower: leave a note
-    p->ctx->last_error = "note: no memory for a token pool of " + std::to_string(p->tok_words * 4) +
-                         " bytes; this plan decodes with the serial kernel (zh_inflate_kernel)";
-    if (getenv("ZH_TRACE")) fprintf(stderr, "zippy_hip: %s\n", p->ctx->last_error.c_str());
-    return false;
+  if (!p->tok_pool) {
+    if (p->tok_failed || !p->tok_words) return false;
+    if (ctx_malloc(p->ctx, (void**)&p->tok_pool, p->tok_words * 4) != hipSuccess) {
+      (void)hipGetLastError();
+      p->tok_pool = nullptr;
+      p->tok_failed = true;
+      // not an error (the serial decoder gives the same bytes), but several times slower: leave a note
+      p->ctx->last_error = "note: no memory for a token pool of " + std::to_string(p->tok_words * 4) +
+                           " bytes; this plan decodes with the serial kernel (zh_inflate_kernel)";
+      if (getenv("ZH_TRACE")) fprintf(stderr, "zippy_hip: %s\n", p->ctx->last_error.c_str());
+      return false;
+    }
   }
-  if (p->segmented) {  // without its buffers the plan simply is not segmented
+  if (p->segmented && !p->sg_sym) {  // without its buffers the plan simply is not segmented
     if (ctx_malloc(p->ctx, (void**)&p->sg_sym, p->sg_sym_count * 2) != hipSuccess ||
         ctx_malloc(p->ctx, (void**)&p->sg_windows, (size_t)p->sg.nsegs * 32768u) != hipSuccess ||
         ctx_malloc(p->ctx, (void**)&p->sg_winsym, (size_t)p->sg.nsegs * 65536u) != hipSuccess) {
@@ -1054,6 +1056,13 @@ static bool plan_token_pool(zh_plan* p) {
     }
   }
   return true;
+}
+// A token pool that outlives the plan and is shared with other plans whose kernels run on the same
+// stream one after the other (the pool is scratch of a run: tokens kernel -> writer).
+static void plan_lend_token_pool(zh_plan* p, uint32_t* pool, uint64_t words) {
+  if (p->tok_pool || p->tok_failed || !p->tok_words || p->tok_words > words) return;
+  p->tok_pool = pool;
+  p->tok_borrowed = true;
 }
 
 // Output slots start out zeroed (every shared output word is OR-ed into place).  Slots that tile
@@ -1595,7 +1604,6 @@ struct PipeGroup {
   size_t i0 = 0, n = 0;
   std::vector<uint64_t> soff, slen, doff, dcap;
   uint64_t src_total = 0, dst_total = 0;
-  DevBuf d_src, d_dst, d_pack;
   PlanGuard pg;
   hipEvent_t uploaded = nullptr, packed = nullptr;
   Download dl;
@@ -1632,7 +1640,13 @@ int compress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, const size_t*
   Trace tr;
   std::vector<PipeGroup> gs(G);
   int st;
-  for (size_t g = 0; g < G; g++) {  // every allocation up front: hipFree would serialise the pipeline
+  // The groups take turns in TWO sets of source / output / pack buffers (group g uses set g % 2: by
+  // the time group g + 2 touches a buffer of the set, group g's last use of it lies before it on the
+  // same stream or has been waited for on the host -- see the loop below); only the plans' own
+  // scratch (match lists, histograms) is per group.  Everything is allocated before the pipeline
+  // starts: hipMalloc / hipFree in the middle would serialise it.
+  uint64_t set_src[2] = {0, 0}, set_dst[2] = {0, 0};
+  for (size_t g = 0; g < G; g++) {
     PipeGroup& q = gs[g];
     q.i0 = cut[g];
     q.n = cut[g + 1] - cut[g];
@@ -1644,12 +1658,19 @@ int compress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, const size_t*
       q.dcap[i] = typical_cap(lens[q.i0 + i], data_format);
       q.dst_total += (q.dcap[i] + 255) & ~(uint64_t)255;
     }
-    if (dev_alloc(ctx, q.d_src, q.src_total + 256) != hipSuccess ||
-        dev_alloc(ctx, q.d_dst, q.dst_total + 256) != hipSuccess ||
-        dev_alloc(ctx, q.d_pack, q.dst_total + 256) != hipSuccess) {
+    set_src[g & 1] = std::max(set_src[g & 1], q.src_total);
+    set_dst[g & 1] = std::max(set_dst[g & 1], q.dst_total);
+  }
+  DevBuf b_src[2], b_dst[2], b_pack[2];
+  for (int k = 0; k < 2; k++)
+    if (dev_alloc(ctx, b_src[k], set_src[k] + 256) != hipSuccess ||
+        dev_alloc(ctx, b_dst[k], set_dst[k] + 256) != hipSuccess ||
+        dev_alloc(ctx, b_pack[k], set_dst[k] + 256) != hipSuccess) {
       (void)hipGetLastError();
       return kPipeFallback;
     }
+  for (size_t g = 0; g < G; g++) {
+    PipeGroup& q = gs[g];
     ZH_HIP(ctx, hipEventCreate(&q.uploaded));
     ZH_HIP(ctx, hipEventCreate(&q.packed));
     st = zh_plan_compress(ctx, q.n, q.soff.data(), q.slen.data(), q.doff.data(), q.dcap.data(), level,
@@ -1661,7 +1682,7 @@ int compress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, const size_t*
   ZH_HIP(ctx, hipStreamSynchronize(ks));  // the plans' descriptors are in place
   auto up = [&](size_t g) -> int {
     PipeGroup& q = gs[g];
-    int e = upload_slices(ctx, cs, srcs + q.i0, q.soff, q.slen, q.src_total, q.d_src.p);
+    int e = upload_slices(ctx, cs, srcs + q.i0, q.soff, q.slen, q.src_total, b_src[g & 1].p);
     if (e) return e;
     ZH_HIP(ctx, hipEventRecord(q.uploaded, cs));
     return ZH_OK;
@@ -1669,7 +1690,7 @@ int compress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, const size_t*
   auto run = [&](size_t g) -> int {
     PipeGroup& q = gs[g];
     ZH_HIP(ctx, hipStreamWaitEvent(ks, q.uploaded, 0));
-    return zh_plan_run(q.pg.p, q.d_src.p, q.d_dst.p);
+    return zh_plan_run(q.pg.p, b_src[g & 1].p, b_dst[g & 1].p);
   };
   auto give_up = [&](int code) -> int {  // nothing is handed out from a failed call
     (void)hipStreamSynchronize(cs);
@@ -1697,7 +1718,7 @@ int compress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, const size_t*
       statuses[q.i0 + i] = ost[i];
       take[i] = ost[i] == ZH_OK;
     }
-    st = download_pack(ctx, ks, q.dl, q.d_dst.p, q.n, q.doff, olen, take, q.d_pack.p, dsts + q.i0,
+    st = download_pack(ctx, ks, q.dl, b_dst[g & 1].p, q.n, q.doff, olen, take, b_pack[g & 1].p, dsts + q.i0,
                        dst_lens + q.i0, statuses + q.i0);
     if (st) return give_up(st);
     if (hipEventRecord(q.packed, ks) != hipSuccess) return give_up(ZH_ERR_DEVICE);
@@ -1857,7 +1878,14 @@ static int uncompress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, cons
   Trace tr;
   std::vector<PipeGroup> gs(G);
   int st;
-  for (size_t g = 0; g < G; g++) {  // every allocation up front: hipMalloc / hipFree would serialise the pipeline
+  // Device memory is bounded by two groups, not by the batch: the groups take turns in TWO sets of
+  // source / output / pack buffers (group g uses set g % 2: by the time group g + 2 touches a buffer
+  // of the set, group g's last use of it lies before it on the same stream or has been waited for on
+  // the host -- see the loop below), and ONE token pool serves every group (scratch of a run, and the
+  // runs follow each other on `ks`).  Everything is allocated before the pipeline starts:
+  // hipMalloc / hipFree in the middle would serialise it.
+  uint64_t set_src[2] = {0, 0}, set_dst[2] = {0, 0};
+  for (size_t g = 0; g < G; g++) {
     PipeGroup& q = gs[g];
     q.i0 = cut[g];
     q.n = cut[g + 1] - cut[g];
@@ -1869,25 +1897,42 @@ static int uncompress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, cons
       q.dcap[i] = cap[q.i0 + i];
       q.dst_total += (q.dcap[i] + 255) & ~(uint64_t)255;
     }
-    if (dev_alloc(ctx, q.d_src, q.src_total + 256) != hipSuccess ||
-        dev_alloc(ctx, q.d_dst, q.dst_total + 256) != hipSuccess ||
-        dev_alloc(ctx, q.d_pack, q.dst_total + 256) != hipSuccess) {
+    set_src[g & 1] = std::max(set_src[g & 1], q.src_total);
+    set_dst[g & 1] = std::max(set_dst[g & 1], q.dst_total);
+  }
+  DevBuf b_src[2], b_dst[2], b_pack[2];
+  for (int k = 0; k < 2; k++)
+    if (dev_alloc(ctx, b_src[k], set_src[k] + 256) != hipSuccess ||
+        dev_alloc(ctx, b_dst[k], set_dst[k] + 256) != hipSuccess ||
+        dev_alloc(ctx, b_pack[k], set_dst[k] + 256) != hipSuccess) {
       (void)hipGetLastError();
       return kPipeFallback;
     }
+  uint64_t tok_words = 0;
+  for (size_t g = 0; g < G; g++) {
+    PipeGroup& q = gs[g];
     ZH_HIP(ctx, hipEventCreate(&q.uploaded));
     ZH_HIP(ctx, hipEventCreate(&q.packed));
     st = zh_plan_uncompress(ctx, q.n, q.soff.data(), q.slen.data(), q.doff.data(), q.dcap.data(), data_format,
                             &q.pg.p);
     if (st == ZH_ERR_NOMEM) return kPipeFallback;
     if (st) return st;
-    if (inflate_split_enabled(ctx)) (void)plan_token_pool(q.pg.p);  // (now, not in the middle of the pipeline)
+    tok_words = std::max(tok_words, q.pg.p->tok_words);
     if (crcs) zh_plan_request_crc32(q.pg.p, 1);
+  }
+  DevBuf b_tok;
+  if (inflate_split_enabled(ctx) && tok_words) {
+    // (a pool that cannot be had leaves the plans to their own devices: plan_token_pool notes the fallback)
+    if (dev_alloc(ctx, b_tok, tok_words * 4) != hipSuccess) (void)hipGetLastError();
+    for (size_t g = 0; g < G; g++) {
+      if (b_tok.p) plan_lend_token_pool(gs[g].pg.p, (uint32_t*)b_tok.p, tok_words);
+      (void)plan_token_pool(gs[g].pg.p);  // (now, not in the middle of the pipeline)
+    }
   }
   ZH_HIP(ctx, hipStreamSynchronize(ks));  // the plans' descriptors are in place
   auto up = [&](size_t g) -> int {
     PipeGroup& q = gs[g];
-    int e = upload_slices(ctx, cs, srcs + q.i0, q.soff, q.slen, q.src_total, q.d_src.p);
+    int e = upload_slices(ctx, cs, srcs + q.i0, q.soff, q.slen, q.src_total, b_src[g & 1].p);
     if (e) return e;
     ZH_HIP(ctx, hipEventRecord(q.uploaded, cs));
     return ZH_OK;
@@ -1895,7 +1940,7 @@ static int uncompress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, cons
   auto run = [&](size_t g) -> int {
     PipeGroup& q = gs[g];
     ZH_HIP(ctx, hipStreamWaitEvent(ks, q.uploaded, 0));
-    return zh_plan_run(q.pg.p, q.d_src.p, q.d_dst.p);
+    return zh_plan_run(q.pg.p, b_src[g & 1].p, b_dst[g & 1].p);
   };
   auto give_up = [&](int code) -> int {  // nothing is handed out from a failed call
     (void)hipStreamSynchronize(cs);
@@ -1923,7 +1968,7 @@ static int uncompress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, cons
       statuses[q.i0 + i] = ost[i];
       take[i] = ost[i] == ZH_OK;
     }
-    st = download_pack(ctx, ks, q.dl, q.d_dst.p, q.n, q.doff, olen, take, q.d_pack.p, dsts + q.i0,
+    st = download_pack(ctx, ks, q.dl, b_dst[g & 1].p, q.n, q.doff, olen, take, b_pack[g & 1].p, dsts + q.i0,
                        dst_lens + q.i0, statuses + q.i0);
     if (st) return give_up(st);
     if (hipEventRecord(q.packed, ks) != hipSuccess) return give_up(ZH_ERR_DEVICE);
