@@ -304,10 +304,16 @@ constexpr uint32_t kWalkGroups = ZH_FRAG_SIZE / kWalkChunk / kWalkThreads;  // w
 __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
                                                             int good, int nice, int max_chain,
                                                             const uint64_t* __restrict__ prevw,
-                                                            uint32_t* __restrict__ best, uint32_t first_frag) {
+                                                            uint32_t* __restrict__ best, uint32_t first_frag,
+                                                            uint32_t ngroups) {
   constexpr uint32_t kChunk = kWalkChunk;
-  const uint32_t f = first_frag + blockIdx.x / kWalkGroups;
-  const uint32_t local = ((blockIdx.x % kWalkGroups) * kWalkThreads + threadIdx.x) * kChunk;
+  // Workgroups go to the eight XCDs round robin.  Each XCD takes a contiguous eighth of the launch, so that
+  // the workgroups of a fragment -- and of its neighbours, whose windows overlap -- gather through ONE L2
+  // instead of eight (512 x 1 MiB: 56.0 -> 51.7 ms, 2048 x 1 MiB: 236.5 -> 204.1 ms).  gridDim.x is a multiple of 8.
+  const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (bid >= ngroups) return;
+  const uint32_t f = first_frag + bid / kWalkGroups;
+  const uint32_t local = ((bid % kWalkGroups) * kWalkThreads + threadIdx.x) * kChunk;
   const ZhFragDesc fd = a.frags[f];
   if (local >= fd.len) return;
   const ZhBlockDesc bd = a.blocks[fd.block];
@@ -641,8 +647,9 @@ extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src,
     } else {
       // (nothing is worked out yet: the walks of one launch may look at the next launch's entries)
       if (f0 == 0) (void)hipMemsetAsync(best, 0, (size_t)a.nfrags * ZH_FRAG_SIZE * 4u, stream);
-      hipLaunchKernelGGL(zh_chain_walk_kernel, dim3(nf * kWalkGroups), dim3(kWalkThreads), 0, stream, d_src, a, good, nice, max_chain,
-                         prevw, best, f0);
+      const uint32_t ng = nf * kWalkGroups;
+      hipLaunchKernelGGL(zh_chain_walk_kernel, dim3((ng + 7u) & ~7u), dim3(kWalkThreads), 0, stream, d_src, a, good, nice,
+                         max_chain, prevw, best, f0, ng);
     }
   }
 }
