@@ -293,27 +293,24 @@ __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __r
 // already done (there the two walks have met) or 1024 positions at most.  Whatever the true walk
 // visits and no walk here did is worked out by kernel 3 when it gets there: the values are those of
 // kernel 2a either way, only fewer.
-#ifndef ZH_WALK_CHUNK
-#define ZH_WALK_CHUNK 32
-#endif
 namespace {
-constexpr uint32_t kWalkChunk = ZH_WALK_CHUNK;  // positions a walk starts at the first of (512 x 1 MiB, walk + parse ms: 16: 67.5, 32: 63.3, 64: 64.5, 128: 70.7, 256: 89.8)
-constexpr uint32_t kWalkThreads = ZH_FRAG_SIZE / kWalkChunk < 256u ? ZH_FRAG_SIZE / kWalkChunk : 256u;
-constexpr uint32_t kWalkGroups = ZH_FRAG_SIZE / kWalkChunk / kWalkThreads;  // workgroups a fragment
+constexpr uint32_t kWalkThreads = 256u;
 }  // namespace
+// kChunk: positions a walk starts at the first of (512 x 1 MiB, this kernel in ms: 16: 40.3, 32: 36.8, 64: 40.7, 128: 47.4)
+template <uint32_t kChunk>
 __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
                                                             int good, int nice, int max_chain,
                                                             const uint64_t* __restrict__ prevw,
                                                             uint32_t* __restrict__ best, uint32_t first_frag,
                                                             uint32_t ngroups) {
-  constexpr uint32_t kChunk = kWalkChunk;
+  constexpr uint32_t kGroups = ZH_FRAG_SIZE / kChunk / kWalkThreads;  // workgroups a fragment
   // Workgroups go to the eight XCDs round robin.  Each XCD takes a contiguous eighth of the launch, so that
   // the workgroups of a fragment -- and of its neighbours, whose windows overlap -- gather through ONE L2
   // instead of eight (512 x 1 MiB: 56.0 -> 51.7 ms, 2048 x 1 MiB: 236.5 -> 204.1 ms).  gridDim.x is a multiple of 8.
   const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   if (bid >= ngroups) return;
-  const uint32_t f = first_frag + bid / kWalkGroups;
-  const uint32_t local = ((bid % kWalkGroups) * kWalkThreads + threadIdx.x) * kChunk;
+  const uint32_t f = first_frag + bid / kGroups;
+  const uint32_t local = ((bid % kGroups) * kWalkThreads + threadIdx.x) * kChunk;
   const ZhFragDesc fd = a.frags[f];
   if (local >= fd.len) return;
   const ZhBlockDesc bd = a.blocks[fd.block];
@@ -324,16 +321,117 @@ __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8
   const uint32_t nmain = block_len > 4u ? block_len - 4u : 0u;  // lz77.nim:74-76: behind it only literals
   uint32_t pos = (f - bd.first_frag) * ZH_FRAG_SIZE + local;    // block-relative
   const uint32_t end = pos + kChunk, stop = end + 1024u;
-  while (pos < nmain && pos < stop) {
-    uint32_t r = __hip_atomic_load(bst + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (r & kBestKnown) {
-      if (pos >= end) break;  // the next chunk's walk has been here: the two have met
-    } else {
-      r = zh_chain_search_one(src, pw, pos, block_len, good, nice, max_chain);
-      __hip_atomic_store(bst + pos, r | kBestKnown, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // The walk as ONE loop whose turn is one round trip to memory for every lane, whatever the lane is
+  // doing: looking at a position (T: its entry of best[] and of pw[]), following a chain link (C: the
+  // candidate's entry), comparing on (E: eight bytes of either side).  Chain lengths are very uneven
+  // (1 MiB of the bench data: 15.8 links a visited position on average, two thirds of the positions
+  // under eight, one in twenty-three all 128): with a loop per search inside a loop per position a wave
+  // stayed in every search as long as its longest lane -- almost always 128 links -- at an eighth of its
+  // lanes busy.  Here a lane that is done with a search goes on to its next position while the others
+  // follow their chains; the values are zh_chain_search_one's, decision for decision.
+  enum : uint32_t { kT = 0, kC = 1, kE = 2, kF = 3, kDone = 4 };
+  uint32_t st = kT;
+  uint32_t hash_pos = 0, nxt = 0, limit = 0, window_pos = 0;
+  int tries = 0, prev_offset = 0, longest_len = 0, longest_offset = 0, offset = 0, m = 0;
+  uint64_t own6 = 0;
+  bool wide = false;
+  const uint64_t* bst2 = reinterpret_cast<const uint64_t*>(bst);  // (the block's part of best[] starts 8-byte aligned)
+  while (st != kDone) {
+    // ---- what ends without a load: a chain's end, a finished search, the walk's end ----
+    if (st == kC) {
+      if (!(tries > 0 && hash_pos != 0)) {
+        st = kF;
+      } else {
+        tries--;
+        offset = hash_pos <= window_pos ? (int)(window_pos - hash_pos) : (int)(window_pos - hash_pos + 32768u);
+        if (offset <= 0 || offset < prev_offset) st = kF;
+        else prev_offset = offset;
+      }
     }
-    const uint32_t len = r & 0xffffu;
-    pos += len ? len : 1u;
+    if (st == kF) {
+      const uint32_t r = longest_len > 4 ? (uint32_t)longest_len | ((uint32_t)longest_offset << 16) : 0u;
+      __hip_atomic_store(bst + pos, r | kBestKnown, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pos += longest_len > 4 ? (uint32_t)longest_len : 1u;
+      st = kT;
+    }
+    if (st == kT && !(pos < nmain && pos < stop)) st = kDone;
+    // ---- the turn's loads (a lane that has just finished reads its block's first entry) ----
+    const uint32_t cand = pos - (uint32_t)offset;
+    const uint8_t* a1 = reinterpret_cast<const uint8_t*>(pw);
+    const uint8_t* a2 = a1;
+    if (st == kT) {
+      a1 = reinterpret_cast<const uint8_t*>(pw + pos);
+      a2 = reinterpret_cast<const uint8_t*>(bst2 + (pos >> 1));
+    } else if (st == kC) {
+      a1 = reinterpret_cast<const uint8_t*>(pw + cand);
+    } else if (st == kE && pos + (uint32_t)m + 8u <= limit) {  // (the block's last bytes are read one by one below)
+      a1 = src + pos + (uint32_t)m;
+      a2 = src + cand + (uint32_t)m;
+    }
+    const uint64_t v1 = load64u(a1);
+    // (past the L1: best[] entries come from other workgroups, too; eight bytes at any address)
+    const uint64_t v2 = __hip_atomic_load(reinterpret_cast<const uint64_t*>(a2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- what they mean ----
+    bool decided = false;  // a candidate's match length `m` is known
+    if (st == kT) {
+      const uint32_t r = (uint32_t)(v2 >> ((pos & 1u) * 32u));
+      if (r & kBestKnown) {
+        if (pos >= end) {
+          st = kDone;  // the next chunk's walk has been here: the two have met
+        } else {
+          const uint32_t len = r & 0xffffu;
+          pos += len ? len : 1u;
+        }
+      } else {  // zh_chain_search_one(src, pw, pos, ...) starts (pos < nmain: pos + 4 < block_len)
+        window_pos = pos & 32767u;
+        limit = block_len < pos + 258u ? block_len : pos + 258u;
+        wide = pos + 8u <= limit;
+        own6 = wide ? v1 >> 16 : 0ull;  // (the position's own six bytes travel with its link, too)
+        hash_pos = (uint32_t)v1 & 0xffffu;
+        tries = max_chain;
+        prev_offset = 0;
+        longest_len = 0;
+        longest_offset = 0;
+        st = kC;
+      }
+    } else if (st == kC) {
+      nxt = (uint32_t)v1 & 0xffffu;
+      const uint64_t x6 = (v1 >> 16) ^ own6;
+      m = 0;
+      if (wide && x6 != 0) {
+        m = (int)((uint32_t)__builtin_ctzll(x6) >> 3);
+        decided = true;
+      } else {
+        st = kE;
+      }
+    } else if (st == kE) {
+      if (pos + (uint32_t)m + 8u <= limit) {
+        const uint64_t x = v1 ^ v2;
+        if (x != 0) {
+          m += (int)((uint32_t)__builtin_ctzll(x) >> 3);
+          decided = true;
+        } else {
+          m += 8;
+        }
+      } else {  // the block's last bytes, one by one
+        uint32_t s2 = pos + (uint32_t)m;
+        while (s2 < limit && src[s2] == src[cand + (uint32_t)m]) {
+          s2++;
+          m++;
+        }
+        decided = true;
+      }
+    }
+    if (decided) {  // lz77.nim:104-112
+      st = kC;
+      if (m > longest_len) {
+        if (m >= good) tries >>= 2;
+        longest_len = m;
+        longest_offset = offset;
+      }
+      if (longest_len >= nice || hash_pos == nxt) st = kF;
+      else hash_pos = nxt;
+    }
   }
 }
 
@@ -647,9 +745,10 @@ extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src,
     } else {
       // (nothing is worked out yet: the walks of one launch may look at the next launch's entries)
       if (f0 == 0) (void)hipMemsetAsync(best, 0, (size_t)a.nfrags * ZH_FRAG_SIZE * 4u, stream);
-      const uint32_t ng = nf * kWalkGroups;
-      hipLaunchKernelGGL(zh_chain_walk_kernel, dim3((ng + 7u) & ~7u), dim3(kWalkThreads), 0, stream, d_src, a, good, nice,
-                         max_chain, prevw, best, f0, ng);
+      constexpr uint32_t kChunk = 32;
+      const uint32_t ng = nf * (ZH_FRAG_SIZE / kChunk / kWalkThreads);
+      hipLaunchKernelGGL(zh_chain_walk_kernel<kChunk>, dim3((ng + 7u) & ~7u), dim3(kWalkThreads), 0, stream, d_src, a, good,
+                         nice, max_chain, prevw, best, f0, ng);
     }
   }
 }
