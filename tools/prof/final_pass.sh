@@ -2,7 +2,7 @@
 # The per-round evidence under profiles/ (run on the GPU box from the repo root):
 #   bash tools/prof/final_pass.sh r03_a
 # -> gpurun_out/<tag>_bench.json (BASELINE metric + configs 2-5 + the parallel-parse leg + cpu_baseline),
-#    _c4.json (DefaultCompression, whole batch on one GPU), _share512.json (one GPU's share of eight),
+#    _c4.json / _c4share.json (DefaultCompression, whole batch on one GPU / 512 x 1 MiB), _share512.json (one GPU's share of eight),
 #    _kernel_stats.csv (rocprofv3 --kernel-trace --stats of the bench command), _pytest_gpu.log,
 #    _host_api*.json, _single_call.json, _one_stream.json, hbm_traffic.json (two --pmc passes)
 R=$(pwd); T=${1:-r03}
@@ -11,6 +11,7 @@ export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -q > $O/${T}_pytest_gpu.log 2>&1
 timeout 900 python bench.py --steps 10 --warmup 2 2>$O/${T}_bench.err | tail -1 > $O/${T}_bench.json
 timeout 600 python bench.py --level -1 --compress-only --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c4.json
+timeout 300 python bench.py --buffers 512 --level -1 --compress-only --steps 5 --warmup 1 --no-cpu-baseline --no-configs --no-parallel-parse 2>/dev/null | tail -1 > $O/${T}_c4share.json
 # one GPU's share of the batch when eight GPUs split it (strong scaling, 512 x 1 MiB)
 timeout 300 python bench.py --buffers 512 --steps 10 --warmup 2 --no-cpu-baseline --no-configs 2>/dev/null | tail -1 > $O/${T}_share512.json
 timeout 300 python tools/bench_host_api.py --reps 2 2>/dev/null | tail -1 > $O/${T}_host_api.json
