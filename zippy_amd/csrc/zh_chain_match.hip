@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __r
 // a walk p -> p + (length ? length : 1) falls in step with the true one quickly wherever it
 // starts.  So a thread walks a 32-position chunk from its first byte and works out the best match
 // of what it visits, on to the first position behind its chunk that the next chunk's walk has
-// already done (there the two walks have met) or 1024 positions at most.  Whatever the true walk
+// already done (there the two walks have met) or 16 384 positions at most.  Whatever the true walk
 // visits and no walk here did is worked out by kernel 3 when it gets there: the values are those of
 // kernel 2a either way, only fewer.
 namespace {
@@ -320,7 +320,11 @@ __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8
   uint32_t* bst = best + (size_t)bd.first_frag * ZH_FRAG_SIZE;
   const uint32_t nmain = block_len > 4u ? block_len - 4u : 0u;  // lz77.nim:74-76: behind it only literals
   uint32_t pos = (f - bd.first_frag) * ZH_FRAG_SIZE + local;    // block-relative
-  const uint32_t end = pos + kChunk, stop = end + 1024u;
+  // a walk goes on behind its chunk until it meets a position that is worked out -- or 16 384 positions at
+  // most (data whose walks never meet: runs).  What the parse then misses it works out itself, one search
+  // at a time, so the allowance is generous (512 x 1 MiB, walk + parse: 1024: 36.8 + 6.5 ms, 4096: 36.9 + 4.6,
+  // 16 384: 37.1 + 4.3, 32 768: 37.0 + 4.2; all zeros, 256 x 1 MiB: 5.1 + 18.9 -> 14.2 + 3.8)
+  const uint32_t end = pos + kChunk, stop = end + 16384u;
   // The walk as ONE loop whose turn is one round trip to memory for every lane, whatever the lane is
   // doing: looking at a position (T: its entry of best[] and of pw[]), following a chain link (C: the
   // candidate's entry), comparing on (E: eight bytes of either side).  Chain lengths are very uneven
