@@ -52,7 +52,7 @@ void zh_launch_l1p_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, ui
                          uint32_t* next_frag);
 uint32_t zh_l1p_slots(void);
 void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint32_t* head_scratch,
-                          uint64_t* prevw);
+                          uint64_t* prevw, uint32_t* lists);
 uint32_t zh_chain_prev_slice(void);
 void zh_launch_chain_search(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
                             int max_chain, const uint64_t* prevw, uint32_t* best);
@@ -1122,7 +1122,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     } else if (p->level != 0) {
       const int* cfg = kChainConfig[p->level == -1 ? 6 : p->level];
       prof_mark(p, "zh_chain_prev_kernel");
-      zh_launch_chain_prev(s, d_src, a, p->head_scratch, p->chain_prev);
+      zh_launch_chain_prev(s, d_src, a, p->head_scratch, p->chain_prev, p->chain_best);
       prof_mark(p, "zh_chain_walk_kernel");
       zh_launch_chain_search(s, d_src, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
       prof_mark(p, "zh_chain_select_kernel");
@@ -2381,7 +2381,7 @@ extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int lev
     zh_launch_l1_match(s, d_src.p, a, level == -2, p->l1_tables, p->l1_counter);
   } else {
     const int* cfg = kChainConfig[level == -1 ? 6 : level];
-    zh_launch_chain_prev(s, d_src.p, a, p->head_scratch, p->chain_prev);
+    zh_launch_chain_prev(s, d_src.p, a, p->head_scratch, p->chain_prev, p->chain_best);
     zh_launch_chain_search(s, d_src.p, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
     zh_launch_chain_select(s, d_src.p, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
   }

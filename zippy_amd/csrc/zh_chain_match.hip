@@ -201,6 +201,172 @@ __global__ __launch_bounds__(64) void zh_chain_prev_ldst_kernel(const uint8_t* _
   }
 }
 
+// ---- 1c. the same links, a block on many waves: positions sorted into hash classes first ----
+// The in-order kernels above walk a block with one wave: 16 384 steps a MiB whatever the batch, and a `head`
+// table of 256-512 KiB a block that lives in L2/MALL (a line through the fabric per lane and step).  A link
+// only ever connects positions of equal hash, so the positions of a block are first sorted -- stably: in
+// position order -- into kClasses classes by the low bits of their hash (a counting pass, a scan, a scatter,
+// all position-parallel), and each class is then linked by a wave of its own, in order, against its slots
+// of `head` in LDS (16-bit entries).  Same values as kernels 1 / 1b: the previous position of equal hash
+// (its low 15 bits), stale entries and all.
+// Scratch of a block: `cls` = per unit of kUnit positions the class counts (then: where the unit's
+// positions of a class go), followed by the classes' starts and sizes; the sorted positions themselves
+// borrow the block's part of best[] (cleared afterwards, before the walks, anyway).
+#ifndef ZH_CHAIN_CLASS_BITS
+#define ZH_CHAIN_CLASS_BITS 5
+#endif
+namespace {
+constexpr uint32_t kClassBits = ZH_CHAIN_CLASS_BITS;
+constexpr uint32_t kClasses = 1u << kClassBits;
+constexpr uint32_t kClsStride = 1u << 16;   // words of scratch a block: (4 MiB / kUnit) units x kClasses, + 2 x kClasses
+constexpr uint32_t kClsInfo = 1u << 15;     // ... of which [kClsInfo, kClsInfo + 2 kClasses): class starts and sizes
+constexpr uint32_t kUnit = 128u * kClasses; // positions a wave counts / scatters
+constexpr uint32_t kUnitsPerFrag = ZH_FRAG_SIZE / kUnit;
+constexpr uint32_t kClsWaves = kUnitsPerFrag < 4u ? kUnitsPerFrag : 4u;  // waves of a counting workgroup
+__device__ __forceinline__ uint32_t zh_chain_hash(uint32_t four) { return (four * kHashMul) >> (32 - kHashBits); }
+}  // namespace
+template <bool kScatter>
+__global__ __launch_bounds__(64 * kClsWaves) void zh_chain_class_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
+                                                                        uint32_t* __restrict__ cls_scratch,
+                                                                        uint32_t* __restrict__ lists) {
+  __shared__ uint32_t s_c[kClsWaves][kClasses];  // count / next free place of a class, a row a wave
+  const unsigned lane = zh_lane();
+  const uint32_t wv = threadIdx.x >> 6;
+  constexpr uint32_t kGroups = kUnitsPerFrag / kClsWaves;  // workgroups a fragment
+  const uint32_t f = blockIdx.x / kGroups;
+  const uint32_t unit_in_frag = (blockIdx.x % kGroups) * kClsWaves + wv;
+  const ZhFragDesc fd = a.frags[f];
+  if (unit_in_frag * kUnit >= fd.len) return;
+  const ZhBlockDesc bd = a.blocks[fd.block];
+  const uint8_t* src = d_src + bd.src_off;
+  const uint32_t block_len = (uint32_t)bd.len;
+  const uint32_t nins = block_len > 4u ? block_len - 4u : 0u;  // positions with pos + 4 < block end
+  const uint32_t unit = (f - bd.first_frag) * kUnitsPerFrag + unit_in_frag;  // of the block
+  uint32_t* cls = cls_scratch + (size_t)fd.block * kClsStride + (size_t)unit * kClasses;
+  uint32_t* list = lists + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  if (lane < kClasses) s_c[wv][lane] = kScatter ? cls[lane] : 0u;
+  zh_wave_sync();
+  for (uint32_t r = 0; r < kUnit / 64u; r++) {
+    const uint32_t P = unit * kUnit + r * 64u + lane;
+    if (P < nins) {
+      const uint32_t c = zh_chain_hash(load32u(src + P)) & (kClasses - 1u);
+      // (the lanes of one LDS atomic are served in ascending order: places in position order)
+      const uint32_t dest = atomicAdd(&s_c[wv][c], 1u);
+      if (kScatter) list[dest] = P;
+    }
+    zh_wave_sync();
+  }
+  if (!kScatter && lane < kClasses) cls[lane] = s_c[wv][lane];
+}
+// counts -> places: class c's positions start at the classes' sizes before it, unit u's at its class's start
+// plus the counts of the units before it.  One workgroup a block, a wave takes kClasses / 8 classes.
+__global__ __launch_bounds__(512) void zh_chain_class_scan_kernel(ZhCompressArgs a, uint32_t* __restrict__ cls_scratch) {
+  __shared__ uint32_t s_tot[kClasses];
+  const unsigned lane = zh_lane();
+  const uint32_t wv = threadIdx.x >> 6;
+  const ZhBlockDesc bd = a.blocks[blockIdx.x];
+  const uint32_t block_len = (uint32_t)bd.len;
+  const uint32_t nins = block_len > 4u ? block_len - 4u : 0u;
+  const uint32_t units = (nins + kUnit - 1u) / kUnit;
+  uint32_t* cls = cls_scratch + (size_t)blockIdx.x * kClsStride;
+  for (uint32_t c = wv; c < kClasses; c += 8u) {
+    uint32_t tot = 0;
+    for (uint32_t u0 = 0; u0 < units; u0 += 64u) {
+      const uint32_t u = u0 + lane;
+      tot += u < units ? cls[(size_t)u * kClasses + c] : 0u;
+    }
+    tot = zh_wave_sum(tot);
+    if (lane == 0) s_tot[c] = tot;
+  }
+  __syncthreads();
+  for (uint32_t c = wv; c < kClasses; c += 8u) {
+    uint32_t start = 0;
+    for (uint32_t k = 0; k < c; k++) start += s_tot[k];
+    if (lane == 0) {
+      cls[kClsInfo + c] = start;
+      cls[kClsInfo + kClasses + c] = s_tot[c];
+    }
+    uint32_t run = start;
+    for (uint32_t u0 = 0; u0 < units; u0 += 64u) {
+      const uint32_t u = u0 + lane;
+      const uint32_t n = u < units ? cls[(size_t)u * kClasses + c] : 0u;
+      const uint32_t incl = zh_wave_scan(n);
+      if (u < units) cls[(size_t)u * kClasses + c] = run + incl - n;
+      run += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+    }
+  }
+}
+// a class of a block, in order: 64 of its positions a step.  `head` holds position + 1 (zero: empty), and a step
+// is ONE LDS atomic: positions grow along the list and the lanes of an LDS atomic are served in ascending order,
+// so atomicMax hands every lane what the slot held just before it -- the previous position of equal hash, be
+// it an earlier lane of the step or an earlier step -- and leaves the step's last one there.
+__global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
+                                                                  const uint32_t* __restrict__ cls_scratch,
+                                                                  const uint32_t* __restrict__ lists,
+                                                                  uint64_t* __restrict__ prevw, uint32_t ngroups) {
+  constexpr uint32_t kAhead = 4;                 // steps whose positions and bytes are on their way
+  constexpr uint32_t kSlots = 1u << (kHashBits - kClassBits);
+  __shared__ uint32_t s_head[kSlots];            // lz77.nim:5-6 `head`, this class's slots
+  const unsigned lane = zh_lane();
+  // (the classes of a block on ONE XCD: their stores fill the same lines of prevw)
+  const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (bid >= ngroups) return;
+  const uint32_t b = bid >> kClassBits, c = bid & (kClasses - 1u);
+  const ZhBlockDesc bd = a.blocks[b];
+  const uint8_t* src = d_src + bd.src_off;
+  const uint32_t block_len = (uint32_t)bd.len;
+  const uint32_t* cls = cls_scratch + (size_t)b * kClsStride;
+  const uint32_t n = cls[kClsInfo + kClasses + c];
+  if (!n) return;
+  const uint32_t* list = lists + (size_t)bd.first_frag * ZH_FRAG_SIZE + cls[kClsInfo + c];
+  uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  for (uint32_t i = lane; i < kSlots; i += 64) s_head[i] = 0;
+  zh_wave_sync();
+  // the eight bytes at a listed position (zeros behind the block's end); every load is unconditional
+  auto pos_at = [&](uint32_t i) -> uint32_t { return list[i < n ? i : n - 1u]; };
+  auto bytes_at = [&](uint32_t P) -> uint64_t {
+    if (block_len < 8u) {
+      uint64_t v = 0;
+      for (uint32_t j = 0; j < 8u && P + j < block_len; j++) v |= (uint64_t)src[P + j] << (8u * j);
+      return v;
+    }
+    const uint32_t at = P + 8u <= block_len ? P : block_len - 8u;
+    return load64u(src + at) >> (8u * (P - at));
+  };
+  // a step's positions are asked for two rounds of kAhead steps ahead, its bytes (whose address they are) one
+  uint32_t pq[kAhead], pn[kAhead];
+  uint64_t wq[kAhead];
+#pragma unroll
+  for (uint32_t k = 0; k < kAhead; k++) {
+    pq[k] = pos_at(64u * k + lane);
+    pn[k] = pos_at(64u * (kAhead + k) + lane);
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < kAhead; k++) wq[k] = bytes_at(pq[k]);
+  for (uint32_t base0 = 0; base0 < n; base0 += 64u * kAhead) {
+    uint32_t P[kAhead], old[kAhead];
+    uint64_t w8[kAhead];
+#pragma unroll
+    for (uint32_t k = 0; k < kAhead; k++) {  // (the steps' atomics in order, one behind the other)
+      const uint32_t i = base0 + 64u * k + lane;
+      P[k] = pq[k];
+      w8[k] = wq[k];
+      pq[k] = pn[k];
+      wq[k] = bytes_at(pq[k]);
+      pn[k] = pos_at(i + 2u * 64u * kAhead);
+      const uint32_t h = zh_chain_hash((uint32_t)w8[k]) >> kClassBits;  // the slot inside the class
+      old[k] = i < n ? atomicMax(&s_head[h], P[k] + 1u) : 0u;
+      zh_wave_sync();
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kAhead; k++) {
+      const uint32_t i = base0 + 64u * k + lane;
+      const uint32_t link = old[k] ? (old[k] - 1u) & 32767u : 0u;
+      if (i < n) pw[P[k]] = (uint64_t)link | ((w8[k] & 0xffffffffffffull) << 16);
+    }
+  }
+}
+
 // ---- 2. best match of a position (lz77.nim:83-112) ----
 // `pos` is block-relative, `pw` the block's links (kernel 1).  Returns length | offset << 16, or 0
 // when the longest match is not longer than 4 (lz77.nim:114).
@@ -705,11 +871,31 @@ __global__ __launch_bounds__(64) void zh_frag_stats_kernel(const uint8_t* __rest
 // Up to this many blocks the exchanging kernel with its 512 KiB tables, beyond it the load / store
 // kernel with 256 KiB ones (the plan's scratch is sized for either).
 extern "C" uint32_t zh_chain_prev_slice(void) { return 1024u; }
+// ZH_CHAIN_PREV=serial: the in-order kernels 1 / 1b (a wave a block) instead of 1c: cross-check and measurement
+static bool chain_prev_serial() {
+  static const bool on = [] {
+    const char* e = getenv("ZH_CHAIN_PREV");
+    return e && strcmp(e, "serial") == 0;
+  }();
+  return on;
+}
+// `lists`: 4 bytes a position of scratch (the plan lends best[], which the walks clear before they use it)
 extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
-                                     uint32_t* head_scratch, uint64_t* prevw) {
+                                     uint32_t* head_scratch, uint64_t* prevw, uint32_t* lists) {
+  if (!a.nblocks) return;
+  if (!chain_prev_serial()) {
+    // (head_scratch holds at least 256 KiB a block: kClsStride words)
+    const uint32_t ngrid = a.nfrags * (kUnitsPerFrag / kClsWaves);
+    hipLaunchKernelGGL(zh_chain_class_kernel<false>, dim3(ngrid), dim3(64 * kClsWaves), 0, stream, d_src, a, head_scratch, lists);
+    hipLaunchKernelGGL(zh_chain_class_scan_kernel, dim3(a.nblocks), dim3(512), 0, stream, a, head_scratch);
+    hipLaunchKernelGGL(zh_chain_class_kernel<true>, dim3(ngrid), dim3(64 * kClsWaves), 0, stream, d_src, a, head_scratch, lists);
+    const uint32_t ng = a.nblocks * kClasses;
+    hipLaunchKernelGGL(zh_chain_class_links_kernel, dim3((ng + 7u) & ~7u), dim3(64), 0, stream, d_src, a, head_scratch, lists,
+                       prevw, ng);
+    return;
+  }
   const uint32_t slice = zh_chain_prev_slice();
   if (a.nblocks <= slice) {
-    if (!a.nblocks) return;
     (void)hipMemsetAsync(head_scratch, 0, (size_t)a.nblocks * ZH_CHAIN_HEAD_WORDS * 4u, stream);
     hipLaunchKernelGGL(zh_chain_prev_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a, head_scratch, prevw, 0u);
     return;
