@@ -33,6 +33,9 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   __shared__ uint32_t s_start[kChunk / 32];  // bit p - c0: a match starts at p
   __shared__ uint32_t s_cover[kChunk / 32];  // bit p - c0: p is inside a match (not its start)
   __shared__ uint32_t s_stage[kStageWords + 4];
+  // the pass's matches, coded once each by the first lanes (a pass of 256 positions starts at most 86)
+  __shared__ uint64_t s_mval[88];
+  __shared__ uint32_t s_mbits[88];
 
   const unsigned lane = zh_lane();
   KPROF_DECL(8);  // 0 flush + loop, 1 chunk bitmaps, 2 bitmaps/source/scan/match fields, 3 codes, 4 scan + LDS ORs, 5 last flush, 6 waves
@@ -98,13 +101,21 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
       if (mnext) cover(m_pos[mnext - 1] + 1u, (uint32_t)m_pos[mnext - 1] + m_len[mnext - 1], c0, c1);
       else cover(0, spill, c0, c1);
     }
+    // (the next 64 matches' fields are asked for before these are filed: unconditional loads at clamped
+    // indices; what was asked for in vain when the chunk ends is asked for again by the next chunk)
+    const uint32_t mlast = nmatch ? nmatch - 1u : 0u;
+    auto at = [&](uint32_t m) { return m < nmatch ? m : mlast; };
+    uint32_t sq = m_pos[at(mnext + lane)], lq = m_len[at(mnext + lane)];
     for (;;) {
       const uint32_t m = mnext + lane;
-      const uint32_t s = m < nmatch ? m_pos[m] : 0xffffffffu;
+      const uint32_t s = m < nmatch ? sq : 0xffffffffu;
+      const uint32_t l = lq;
+      sq = m_pos[at(m + 64u)];
+      lq = m_len[at(m + 64u)];
       const bool here = s < c1;
       if (here) {
         atomicOr(&s_start[(s - c0) >> 5], 1u << ((s - c0) & 31u));
-        cover(s + 1u, s + m_len[m], c0, c1);  // (chain levels: a match may run past the fragment)
+        cover(s + 1u, s + l, c0, c1);  // (chain levels: a match may run past the fragment)
       }
       const uint32_t cnt = (uint32_t)__popcll(__ballot(here));
       mnext += cnt;
@@ -127,6 +138,14 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   const uint32_t last_dw = (n + mis - 1u) >> 2;  // n >= 1 here
   auto dw = [&](uint32_t i) -> uint32_t { return asrc[i < last_dw ? i : last_dw]; };
 
+  // a pass ahead: the lane's source bytes and the next 64 matches' fields (clamped, unconditional loads)
+  const uint32_t mlast = nmatch ? nmatch - 1u : 0u;
+  auto word_at = [&](uint32_t p0) -> uint32_t {
+    const uint32_t q = p0 + mis;
+    return __builtin_amdgcn_alignbyte(dw((q >> 2) + 1u), dw(q >> 2), q);
+  };
+  uint32_t w_next = word_at(4u * lane);
+  uint32_t pl = m_len[lane < nmatch ? lane : mlast], po = m_off[lane < nmatch ? lane : mlast];
   for (uint32_t base = 0; base < n; base += 256) {
     KPROF_MARK(0);
     if ((base & (kChunk - 1u)) == 0) build_chunk(base);
@@ -137,28 +156,38 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
     const uint32_t st4 = in ? (s_start[bw] >> bs) & 15u : 0u;
     uint32_t skip4 = in ? (s_cover[bw] >> bs) & 15u : 15u;
     if (in && n - p0 < 4u) skip4 |= 15u << (n - p0);  // positions past the fragment
-    const uint32_t q = p0 + mis;
-    const uint32_t w = in ? __builtin_amdgcn_alignbyte(dw((q >> 2) + 1u), dw(q >> 2), q) : 0u;
-    // match index of this lane's first start
+    const uint32_t w = in ? w_next : 0u;
+    w_next = word_at(p0 + 256u);  // (dw() clamps behind the fragment's last byte)
+    // index (in the pass) of this lane's first match start
     const uint32_t nst = (uint32_t)__popc(st4);
     const uint32_t incl_st = zh_wave_scan(nst);
-    uint32_t m = mbase + incl_st - nst;
-    mbase += (uint32_t)__builtin_amdgcn_readlane(incl_st, 63);
-    // the match fields first (independent loads), then the codes
-    uint32_t ml[4], mo[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
-      ml[k] = 0;
-      mo[k] = 0;
-      if ((st4 >> k) & 1u) {
-        ml[k] = m_len[m];
-        mo[k] = m_off[m];
-        m++;
-      }
+    uint32_t mj = incl_st - nst;
+    const uint32_t npass = (uint32_t)__builtin_amdgcn_readlane(incl_st, 63);
+    // ---- the pass's matches: length code + extra + distance code + extra (deflate.nim:417-433), one
+    // match a lane (their fields are neighbours in the match list), parked for the lanes that own the
+    // positions ----
+    for (uint32_t j = lane; j < npass; j += 64) {
+      const uint32_t length = j < 64u ? pl : m_len[mbase + j], offset = j < 64u ? po : m_off[mbase + j];
+      const uint32_t li = zh_len_code(length), di = zh_dist_code(offset);
+      const uint32_t lc = s_lit[257 + li], dc = s_dist[di];
+      uint64_t v = lc & 0xffffu;
+      uint32_t nbits = lc >> 16;
+      v |= (uint64_t)(length - zh_len_base(li)) << nbits;
+      nbits += zh_len_extra_bits(li);
+      v |= (uint64_t)(dc & 0xffffu) << nbits;
+      nbits += dc >> 16;
+      v |= (uint64_t)(offset - zh_dist_base(di)) << nbits;
+      nbits += zh_dist_extra_bits(di);
+      s_mval[j] = v;
+      s_mbits[j] = nbits;
     }
-#ifdef ZH_KPROF
-    asm volatile("" ::"v"(ml[0]), "v"(mo[0]), "v"(ml[3]), "v"(w));
-#endif
+    mbase += npass;
+    {
+      const uint32_t mi = mbase + lane < nmatch ? mbase + lane : mlast;
+      pl = m_len[mi];
+      po = m_off[mi];
+    }
+    zh_wave_sync();
     KPROF_MARK(2);
     uint64_t val[4];
     uint32_t nb[4], lane_bits = 0;
@@ -167,18 +196,9 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
       uint64_t v = 0;
       uint32_t nbits = 0;
       if ((st4 >> k) & 1u) {
-        const uint32_t length = ml[k], offset = mo[k];
-        const uint32_t li = zh_len_code(length), di = zh_dist_code(offset);
-        const uint32_t lc = s_lit[257 + li], dc = s_dist[di];
-        // deflate.nim:417-433
-        v = lc & 0xffffu;
-        nbits = lc >> 16;
-        v |= (uint64_t)(length - zh_len_base(li)) << nbits;
-        nbits += zh_len_extra_bits(li);
-        v |= (uint64_t)(dc & 0xffffu) << nbits;
-        nbits += dc >> 16;
-        v |= (uint64_t)(offset - zh_dist_base(di)) << nbits;
-        nbits += zh_dist_extra_bits(di);
+        v = s_mval[mj];
+        nbits = s_mbits[mj];
+        mj++;
       } else if (!((skip4 >> k) & 1u)) {
         const uint32_t lc = s_lit[(w >> (8u * k)) & 255u];
         v = lc & 0xffffu;
