@@ -46,6 +46,38 @@ def test_emu_tokens(eng):
     pc.check_tokens(eng, synth.corpus_file("html")[:20000], -2)
 
 
+def _chain_inputs():
+    # more than a fragment, more than a window, more than one unit of the links' class sort; a second
+    # input of two deflate blocks (> 4 MiB: runs and zeros keep the emulator fast)
+    mixed = (synth.corpus_file("alice29.txt") + synth.corpus_file("html")[:60000] +
+             synth.gen_batch("rand", 1, 20000)[0].tobytes() + synth.corpus_file("alice29.txt")[:50000])
+    return mixed, b"\x00" * 2500000 + synth.gen_batch("runs", 1, 1800000)[0].tobytes()
+
+
+def test_emu_chain_levels_across_windows(eng):
+    mixed, two_blocks = _chain_inputs()
+    pc.check_compress_identical(eng, [mixed], levels=(-1, 5), formats=(oracle.dfDeflate,))
+    pc.check_tokens(eng, mixed, -1)
+    pc.check_compress_identical(eng, [two_blocks], levels=(-1,), formats=(oracle.dfGzip,))
+
+
+def test_emu_chain_cross_check_kernels():
+    """The in-order link kernels and the every-position search (ZH_CHAIN_PREV=serial, ZH_CHAIN_SEARCH=dense:
+    switches read once a process) give the oracle's bytes, too."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import emu, oracle, parity_cases as pc\n"
+            "from test_emu_parity import _chain_inputs\n"
+            "pc.check_compress_identical(emu.engine(), [_chain_inputs()[0]], levels=(-1,), formats=(oracle.dfDeflate,))\n"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    for env in ({"ZH_CHAIN_PREV": "serial"}, {"ZH_CHAIN_SEARCH": "dense"}, {"ZH_CHAIN_SELECT": "serial"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, (env, r.stderr[-2000:])
+
+
 def test_emu_multi_block_buffer(eng):
     # > 4 MiB: two deflate blocks in one buffer (deflate.nim:228-237); runs/zeros keep it fast
     src = (b"\x00" * 3000000 + synth.gen_batch("runs", 1, 1300000)[0].tobytes())
