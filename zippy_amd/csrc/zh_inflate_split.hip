@@ -261,23 +261,19 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
         r.term = 1u;
         break;
       }
+      // A second literal out of the same bits, if it starts before `limit` and ends inside the input: the
+      // decisions the loop would take on its next turn, so every pass over these bits finds the same tokens.
+      // (Two tokens in three of the bench data are literals: 15.4 -> 11.6 ms.  Up to one / two / three more out
+      // of a 64-bit window: 12.6 / 12.8 / 14.0 ms.)  The two share ONE record: length 2, the second byte on top.
+      if (tb2 && p < limit && p + tb2 <= end_rel) {
+        p += tb2;
+        rec = 2u | (1u << 9) | (rec & 0xff0000u) | ((rec2 & 0xff0000u) << 8);
+      }
       if (out) {
         out[r.n] = rec;
         if (kSeg) r.bytes += rec & 0x1ffu;
       }
       r.n++;
-      // A second literal out of the same bits, if it starts before `limit` and ends inside the input: the
-      // decisions the loop would take on its next turn, so every pass over these bits finds the same tokens.
-      // (Two tokens in three of the bench data are literals: 15.4 -> 11.6 ms.  Up to one / two / three more out
-      // of a 64-bit window: 12.6 / 12.8 / 14.0 ms.)
-      if (tb2 && p < limit && p + tb2 <= end_rel) {
-        p += tb2;
-        if (out) {
-          out[r.n] = rec2;
-          if (kSeg) r.bytes += 1u;
-        }
-        r.n++;
-      }
     }
     r.end = p;
     return r;
@@ -965,12 +961,14 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
       if (fit[k]) s_map[o[k]] = (uint16_t)(i0 + k + 1u);
     __syncthreads();
     uint32_t t[kB];
+    uint32_t starts = 0;  // bit j: a record starts at this thread's byte j
     {
       uint32_t m = 0;
 #pragma unroll
       for (uint32_t j = 0; j < kB / 2u; j++) {
         const uint32_t w = s_map32[(kB / 2u) * tid + j];
         s_map32[(kB / 2u) * tid + j] = 0;
+        starts |= ((w & 0xffffu) ? 1u : 0u) << (2u * j) | ((w >> 16) ? 2u : 0u) << (2u * j);
         m = max(m, w & 0xffffu);
         t[2u * j] = m;
         m = max(m, w >> 16);
@@ -994,7 +992,8 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
       const uint32_t tk = max(carry, t[j]);  // its record + 1 (>= 1 for every live byte)
       const uint32_t rec = s_tok[(uint32_t)(ti + tk - 1u) & (kWrRing - 1u)];
       par[j] = pb;
-      val[j] = (rec >> 16) & 0xffu;
+      // a literal record holds one byte or two: its first at bit 16, the one behind it at bit 24
+      val[j] = (rec >> ((starts >> j) & 1u ? 16u : 24u)) & 0xffu;
       if (pb < total && !((rec >> 9) & 1u)) {
         const uint32_t dist = rec >> 16;
         if (dist <= pb) {
