@@ -264,7 +264,8 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
       // A second literal out of the same bits, if it starts before `limit` and ends inside the input: the
       // decisions the loop would take on its next turn, so every pass over these bits finds the same tokens.
       // (Two tokens in three of the bench data are literals: 15.4 -> 11.6 ms.  Up to one / two / three more out
-      // of a 64-bit window: 12.6 / 12.8 / 14.0 ms.)  The two share ONE record: length 2, the second byte on top.
+      // of a 64-bit window: 12.6 / 12.8 / 14.0 ms; a literal behind a COPY out of the copy's 64 bits as well: 12.3
+      // against 11.4.)  The two share ONE record: length 2, the second byte on top.
       if (tb2 && p < limit && p + tb2 <= end_rel) {
         p += tb2;
         rec = 2u | (1u << 9) | (rec & 0xff0000u) | ((rec2 & 0xff0000u) << 8);
