@@ -986,6 +986,8 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
       if (w < wv) carry = max(carry, s_w[4][w]);
     // ---- every byte: literal, copy from before the round (far), or from inside it (near) ----
     uint32_t par[kB], val[kB];
+    int64_t far_at[kB];  // where a byte copied from before the round comes from
+    uint32_t far_mask = 0;
     bool any_near = false;
 #pragma unroll
     for (uint32_t j = 0; j < kB; j++) {
@@ -995,15 +997,31 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
       par[j] = pb;
       // a literal record holds one byte or two: its first at bit 16, the one behind it at bit 24
       val[j] = (rec >> ((starts >> j) & 1u ? 16u : 24u)) & 0xffu;
+      far_at[j] = (int64_t)op;  // (a byte of this stream's slot that is read in vain)
       if (pb < total && !((rec >> 9) & 1u)) {
         const uint32_t dist = rec >> 16;
         if (dist <= pb) {
           par[j] = pb - dist;
           any_near = true;
         } else {
-          val[j] = ld_out((int64_t)(op + pb) - dist);  // (written before this round: visible since its start)
+          far_mask |= 1u << j;
+          far_at[j] = (int64_t)(op + pb) - dist;  // (written before this round: visible since its start)
         }
       }
+    }
+    // the far bytes of a thread are read TOGETHER: unconditional loads (a lane without one reads the round's
+    // first byte in vain) that are all in flight at once -- under their bytes' conditions the compiler waited
+    // for each of the eight before it issued the next, eight trips to L2 a round
+    {
+      uint32_t got[kB];
+#pragma unroll
+      for (uint32_t j = 0; j < kB; j++)
+        got[j] = __hip_atomic_load(dst + (kSeg && far_at[j] < 0 ? (int64_t)op : far_at[j]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (uint32_t j = 0; j < kB; j++)
+        if ((far_mask >> j) & 1u)
+          val[j] = kSeg && far_at[j] < 0 ? 0x8000u | (uint32_t)(32768 + far_at[j]) : got[j];  // (ld_out's rule)
     }
     if (any_near) s_flag[2u + (round & 1u)] = 1;
 #pragma unroll
