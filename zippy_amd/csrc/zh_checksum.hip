@@ -99,8 +99,11 @@ __global__ __launch_bounds__(64) void zh_checksum_pieces_kernel(
         sum_ib += (uint64_t)i * b;
       }
     }
+    // (a row ahead: the next row's sixteen bytes are asked for before this row's go through the tables)
+    uint4 vn = rows ? *reinterpret_cast<const uint4*>(bp + lane * 16u) : make_uint4(0, 0, 0, 0);
     for (uint32_t r = 0; r < rows; r++) {
-      const uint4 v = *reinterpret_cast<const uint4*>(bp + ((size_t)r << 10) + lane * 16u);
+      const uint4 v = vn;
+      vn = *reinterpret_cast<const uint4*>(bp + ((size_t)(r + 1u < rows ? r + 1u : r) << 10) + lane * 16u);
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
       if (want_crc) {
         if (r) {  // skip the other 63 lanes' bytes of the previous row boundary
