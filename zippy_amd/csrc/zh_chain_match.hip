@@ -5,18 +5,22 @@
 // `head`/`chain` (also for the bytes a match skips, lz77.nim:121-126), so the chain state
 // a position sees does NOT depend on the parse: it is "every earlier position of the
 // block, newest first, linked by equal 17-bit hash".  Hence
-//   1. zh_chain_prev_kernel   (one wave per <= 4 MiB block, 64 positions per turn, in
-//      order): prevw[P] = the value the reference's `chain[windowPos]` receives when P is
+//   1. the links: prevw[P] = the value the reference's `chain[windowPos]` receives when P is
 //      inserted = window position of the latest earlier position with the same hash, 0
 //      when there is none (the reference's "empty" sentinel, lz77.nim:88) -- stale
-//      entries older than the window included, exactly like its never-cleared `head`;
-//   2. zh_chain_search_kernel (one THREAD per position): the reference's bounded chain
+//      entries older than the window included, exactly like its never-cleared `head`.
+//      zh_chain_class_* (1c, the default): a block's positions sorted into 32 hash classes,
+//      each class linked in order by a wave of its own; zh_chain_prev_kernel / _ldst_kernel
+//      (1 / 1b, ZH_CHAIN_PREV=serial): one wave per <= 4 MiB block, 64 positions per turn;
+//   2. zh_chain_walk_kernel (a thread per 32-position chunk, only the positions a greedy walk
+//      visits; zh_chain_search_kernel, one THREAD per position, is the cross-check): the reference's bounded chain
 //      walk (good / nice / chain of internal.nim:177-189, the decreasing-offset wrap test,
 //      the self-loop test, determineMatchLength) with `chain[w]` read as prevw[] of the
 //      position that owns window slot w at that time -> best (length, offset) per position;
-//   3. zh_chain_select_kernel (one wave per block): the greedy parse itself
+//   3. zh_chain_select_par_kernel (a workgroup per block, chunk walkers handing their ends on;
+//      zh_chain_select_kernel, one wave per block, is the cross-check): the greedy parse itself
 //      (lz77.nim:73-130): accept matches longer than 4, hop over them, literals otherwise;
-//      64 positions per turn through v_readlane hops.
+//      what no walk of step 2 came by it works out itself.
 // The match list / fragment bookkeeping handed to the Huffman and emission kernels is
 // the same as the BestSpeed matcher's; output is byte-identical to the serial walk.
 //
