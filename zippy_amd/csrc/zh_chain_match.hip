@@ -734,10 +734,25 @@ __global__ __launch_bounds__(256) void zh_chain_select_par_kernel(const uint8_t*
     const uint32_t base = frag * ZH_FRAG_SIZE;
     const uint32_t npos = nmain > base ? (nmain - base < ZH_FRAG_SIZE ? nmain - base : ZH_FRAG_SIZE) : 0u;
     __syncthreads();  // (the previous fragment's walks are done with s_len)
-    for (uint32_t i = tid; i < ZH_FRAG_SIZE; i += kT) {
-      const uint32_t v = i < npos ? bst[base + i] : kBestKnown;
-      const uint32_t len = v & 0xffffu;
-      s_len[i] = (uint8_t)(v & kBestKnown ? (len ? len - 4u : 0u) : 255u);  // 255: nobody came by here yet
+    for (uint32_t i = tid * 4u; i < ZH_FRAG_SIZE; i += kT * 4u) {  // four entries a load, four bytes a store
+      uint32_t v[4] = {kBestKnown, kBestKnown, kBestKnown, kBestKnown};
+      if (i + 4u <= npos) {
+        const uint4 q = *reinterpret_cast<const uint4*>(bst + base + i);
+        v[0] = q.x;
+        v[1] = q.y;
+        v[2] = q.z;
+        v[3] = q.w;
+      } else {
+        for (uint32_t k = 0; k < 4u; k++)
+          if (i + k < npos) v[k] = bst[base + i + k];
+      }
+      uint32_t packed = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t len = v[k] & 0xffffu;
+        packed |= (v[k] & kBestKnown ? (len ? len - 4u : 0u) : 255u) << (8u * k);  // 255: nobody came by here yet
+      }
+      *reinterpret_cast<uint32_t*>(&s_len[i]) = packed;
     }
     if (tid == 0) s_first_dirty[0] = s_first_dirty[1] = kT;
     __syncthreads();
