@@ -567,6 +567,9 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   chk(hipMemsetAsync(base + o_fhist, 0, nf * ZH_HIST_STRIDE * 2, s));
   chk(hipMemsetAsync(base + o_fnl, 0, nf * 4, s));
   chk(hipMemsetAsync(base + o_fex, 0, nf * 4, s));
+  // best[] starts out all "not worked out" -- once: every run leaves it that way again (the links kernel
+  // clears the sorted positions it has borrowed the array for, zh_chain_class_links_kernel)
+  if (chain && nf) chk(hipMemsetAsync(base + o_cbest, 0, nf * (size_t)ZH_FRAG_SIZE * 4, s));
   chk(hipStreamSynchronize(s));  // host vectors go out of scope
   if (up != hipSuccess) {
     ctx->last_error = std::string("plan upload: ") + hipGetErrorString(up);

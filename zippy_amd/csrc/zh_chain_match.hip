@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512) void zh_chain_class_scan_kernel(ZhCompressArgs
 // it an earlier lane of the step or an earlier step -- and leaves the step's last one there.
 __global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
                                                                   const uint32_t* __restrict__ cls_scratch,
-                                                                  const uint32_t* __restrict__ lists,
+                                                                  uint32_t* __restrict__ lists,
                                                                   uint64_t* __restrict__ prevw, uint32_t ngroups) {
   constexpr uint32_t kAhead = 4;                 // steps whose positions and bytes are on their way
   constexpr uint32_t kSlots = 1u << (kHashBits - kClassBits);
@@ -322,7 +322,8 @@ __global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t*
   const uint32_t* cls = cls_scratch + (size_t)b * kClsStride;
   const uint32_t n = cls[kClsInfo + kClasses + c];
   if (!n) return;
-  const uint32_t* list = lists + (size_t)bd.first_frag * ZH_FRAG_SIZE + cls[kClsInfo + c];
+  uint32_t* list_rw = lists + (size_t)bd.first_frag * ZH_FRAG_SIZE + cls[kClsInfo + c];
+  const uint32_t* list = list_rw;
   uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
   for (uint32_t i = lane; i < kSlots; i += 64) s_head[i] = 0;
   zh_wave_sync();
@@ -366,7 +367,10 @@ __global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t*
     for (uint32_t k = 0; k < kAhead; k++) {
       const uint32_t i = base0 + 64u * k + lane;
       const uint32_t link = old[k] ? (old[k] - 1u) & 32767u : 0u;
-      if (i < n) pw[P[k]] = (uint64_t)link | ((w8[k] & 0xffffffffffffull) << 16);
+      if (i < n) {
+        pw[P[k]] = (uint64_t)link | ((w8[k] & 0xffffffffffffull) << 16);
+        list_rw[i] = 0;  // best[] goes back the way the walks expect it: nothing worked out
+      }
     }
   }
 }
@@ -905,11 +909,21 @@ __global__ __launch_bounds__(64) void zh_frag_stats_kernel(const uint8_t* __rest
   }
   zh_wave_sync();
   uint32_t nlit = 0;
-  for (uint32_t base = 0; base < n; base += 64) {
-    const uint32_t p = base + lane;
-    if (p < n && !((s_cover[p >> 5] >> (p & 31u)) & 1u)) {
-      atomicAdd(&s_hist[src[p]], 1u);
-      nlit++;
+  for (uint32_t base = 0; base < n; base += 256) {  // four positions a lane: one load, one word of the bitmap
+    const uint32_t p0 = base + 4u * lane;
+    if (p0 < n) {
+      uint32_t w = 0, live = 15u;
+      if (p0 + 4u <= n) {
+        w = load32u(src + p0);
+      } else {
+        live = (1u << (n - p0)) - 1u;
+        for (uint32_t k = 0; k < n - p0; k++) w |= (uint32_t)src[p0 + k] << (8u * k);
+      }
+      live &= ~(s_cover[p0 >> 5] >> (p0 & 31u));
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; k++)
+        if ((live >> k) & 1u) atomicAdd(&s_hist[(w >> (8u * k)) & 255u], 1u);
+      nlit += (uint32_t)__popc(live);
     }
   }
   extra_bits = zh_wave_sum(extra_bits);
@@ -988,8 +1002,9 @@ extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src,
       hipLaunchKernelGGL(zh_chain_search_kernel, dim3(nf * (ZH_FRAG_SIZE / 256u)), dim3(256), 0, stream,
                          d_src, a, good, nice, max_chain, prevw, best, f0);
     } else {
-      // (nothing is worked out yet: the walks of one launch may look at the next launch's entries)
-      if (f0 == 0) (void)hipMemsetAsync(best, 0, (size_t)a.nfrags * ZH_FRAG_SIZE * 4u, stream);
+      // (nothing is worked out yet -- the walks of one launch may look at the next launch's entries --: the
+      // class-sorted links have left best[] cleared; after the in-order kernels it still holds the last run's)
+      if (f0 == 0 && chain_prev_serial()) (void)hipMemsetAsync(best, 0, (size_t)a.nfrags * ZH_FRAG_SIZE * 4u, stream);
       constexpr uint32_t kChunk = 32;
       const uint32_t ng = nf * (ZH_FRAG_SIZE / kChunk / kWalkThreads);
       hipLaunchKernelGGL(zh_chain_walk_kernel<kChunk>, dim3((ng + 7u) & ~7u), dim3(kWalkThreads), 0, stream, d_src, a, good,
