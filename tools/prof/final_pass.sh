@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_bench.json (BASELINE metric + configs 2-5 + the parallel-parse leg + cpu_baseline),
 #    _c4.json / _c4share.json (DefaultCompression, whole batch on one GPU / 512 x 1 MiB), _share512.json (one GPU's share of eight),
 #    _kernel_stats.csv (rocprofv3 --kernel-trace --stats of the bench command), _pytest_gpu.log,
-#    _host_api*.json, _single_call.json, _one_stream.json, hbm_traffic.json (two --pmc passes)
+#    _host_api*.json, _single_call.json, _one_stream.json, _fuzz*.log, hbm_traffic.json (two --pmc passes)
 R=$(pwd); T=${1:-r03}
 O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
@@ -21,6 +21,8 @@ timeout 600 python tools/bench_one_stream.py 2>/dev/null | tail -1 > $O/${T}_one
 ZH_L1_PARSE=parallel timeout 300 python tools/bench_single_call.py 2>/dev/null | tail -1 > $O/${T}_single_call_parallel_parse.json
 ZH_L1_PARSE=parallel timeout 300 python bench.py --buffers 512 --steps 10 --warmup 2 --no-cpu-baseline --no-configs --no-parallel-parse 2>/dev/null | tail -1 > $O/${T}_share512_parallel_parse.json
 timeout 900 python tools/gpu_fuzz.py 1000 120 2>&1 | tail -4 > $O/${T}_fuzz.log
+timeout 900 python tools/gpu_fuzz_chain.py 600 20 2>&1 | tail -2 > $O/${T}_fuzz_chain.log
+(timeout 900 python tools/gpu_fuzz.py --mutations 10000 2>&1 | tail -3; timeout 900 python tools/gpu_fuzz.py --seg-mutations 4000 2>&1 | tail -2) > $O/${T}_fuzz_damaged.log 2>&1
 timeout 300 python tools/kprof.py --l1-parse 1 --buffers 1024 2>&1 | head -13 > $O/${T}_kprof_l1p.txt
 cd /tmp
 rm -rf /tmp/kt /tmp/pf /tmp/pw
