@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--kind", default="mix")
     ap.add_argument("--inflate", type=int, default=-1)
     ap.add_argument("--l1-parse", type=int, default=-1, help="1: the parallel BestSpeed parse (zh_l1p_match_kernel)")
+    ap.add_argument("--foreign", type=int, default=None, help="uncompress gzip members made by system zlib at this level instead")
     args = ap.parse_args()
     import torch
     import synth
@@ -73,15 +74,32 @@ def main():
     uplan.set_src_lens_device(cplan.device_lens())
     cplan.set_profiling(True)
     uplan.set_profiling(True)
+    if args.foreign is not None:
+        import zlib
+        from concurrent.futures import ThreadPoolExecutor
+        import numpy as np
+
+        def gz(i):
+            c = zlib.compressobj(args.foreign, zlib.DEFLATED, 31)
+            return c.compress(host[i].tobytes()) + c.flush()
+        with ThreadPoolExecutor(32) as ex:
+            blobs = list(ex.map(gz, range(n)))
+        stage = np.zeros((n, slot), dtype=np.uint8)
+        for i, b in enumerate(blobs):
+            stage[i, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+        d_comp.copy_(torch.from_numpy(stage.reshape(-1)))
+        uplan = eng.plan_uncompress(comp_off, [len(b) for b in blobs], src_off, [size] * n, api.dfGzip)
+        uplan.set_profiling(True)
     for it in range(2):
         eng.lib.zh_kprof_read(None, 1)
-        cplan.run(d_src.data_ptr(), d_comp.data_ptr())
+        if args.foreign is None:
+            cplan.run(d_src.data_ptr(), d_comp.data_ptr())
         uplan.run(d_comp.data_ptr(), d_back.data_ptr())
         torch.cuda.synchronize()
     assert torch.equal(d_back, d_src)
     slots = (ctypes.c_ulonglong * 64)()
     eng.lib.zh_kprof_read(slots, 0)
-    print("kernel ms:", {k: round(v, 3) for k, v in cplan.kernel_times() + uplan.kernel_times()})
+    print("kernel ms:", {k: round(v, 3) for k, v in (cplan.kernel_times() if args.foreign is None else []) + uplan.kernel_times()})
     if args.l1_parse == 1:
         show("zh_l1p_match_kernel (thread 0 of each workgroup, per fragment)", L1P, list(slots[0:8]))
     else:
