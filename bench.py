@@ -337,6 +337,7 @@ def pp_fields(pp, N, comp_rank_exact, roof):
             "compress_GiBps": round(total / GIB / (pp["tc"] * 1e-3), 3),
             "uncompress_GiBps": round(total / GIB / (pp["tu"] * 1e-3), 3),
             "size_vs_exact_parse": round(pp["comp_rank"] / comp_rank_exact, 5),
+            "parity_sample": pp.get("parity_sample"),
             "kernels_ms": {k: round(v, 4) for k, v in sorted(pk.items(), key=lambda kv: -kv[1]) if k != "end"},
             "roofline_matcher": roof(N, pk["zh_l1p_match_kernel"], "zh_l1p_match_kernel"),
         },
@@ -381,6 +382,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true",
                     help="skip BASELINE configs 2-5 (run after the headline at N=1 with the default workload)")
     ap.add_argument("--no-transfer", action="store_true", help="skip the RCCL scatter/gather leg (N > 1)")
+    ap.add_argument("--no-parity-sample", action="store_true",
+                    help="skip the comparison of 64 of the streams with the oracle's (outside the timed region)")
     args = ap.parse_args()
     if args.foreign is not None:
         args.uncompress_only = True
@@ -484,6 +487,19 @@ def main():
     assert all(s == 0 for s in usts), "uncompress statuses (CRC-32 / ISIZE verified on device)"
     assert ulens == [size] * n
     assert torch.equal(d_back, d_src), "round trip mismatch"
+    # ---- the headline carries its own parity evidence: a sample of the streams about to be timed against the
+    # oracle's compress(), byte for byte (the checker, outside the timed region; rank 0's shard) ----
+    parity_sample = None
+    if args.foreign is None and rank == 0 and not args.no_parity_sample:
+        import oracle
+        pick = list(range(0, n, max(1, n // 64)))[:64]
+        same = 0
+        for i in pick:
+            z = d_comp[i * slot:i * slot + clens[i]].cpu().numpy().tobytes()
+            same += z == oracle.compress(host[i].tobytes(), args.level, oracle.dfGzip, fname_len=0)
+        parity_sample = {"n": len(pick), "identical": same == len(pick), "against": "oracle.compress(level %d, gzip)" % args.level,
+                         "buffers": "every %d-th of this rank's %d" % (max(1, n // 64), n)}
+        assert parity_sample["identical"], "device streams differ from the oracle's (%d of %d equal)" % (same, len(pick))
 
     # ---- timed region ----
     kernel_ms = {}
@@ -542,6 +558,17 @@ def main():
             for i in range(0, n, max(1, n // 8)):  # a sample through system zlib as well
                 z = d_comp[i * slot:i * slot + plens[i]].cpu().numpy().tobytes()
                 assert zlib.decompress(z, 31) == host[i].tobytes(), "parallel parse: zlib disagrees"
+            if rank == 0 and not args.no_parity_sample:
+                # ... and 64 through the oracle's uncompress() (the reference's decoder restated): the contract
+                # this parse is held to is "zippy's own uncompress() gives the input back", not byte identity
+                import oracle
+                pick = list(range(0, n, max(1, n // 64)))[:64]
+                okc = 0
+                for i in pick:
+                    z = d_comp[i * slot:i * slot + plens[i]].cpu().numpy().tobytes()
+                    okc += oracle.uncompress(z, oracle.dfGzip) == host[i].tobytes()
+                pstate["parity_sample"] = {"n": len(pick), "round_trips_through_oracle_uncompress": okc == len(pick)}
+                assert okc == len(pick), "parallel parse: the oracle's uncompress() disagrees"
             pstate["C"] = sum(plens)
         time_plans(torch, stream, cplan, uplan, (d_src, d_comp, d_back), 0, max(args.warmup, 1), verify_pp)
         if use_dist:
@@ -563,7 +590,8 @@ def main():
             dist.all_reduce(c)
             p_comp = int(c.item())
         pp = {"elapsed": p_elapsed, "tc": ptc, "tu": ptu, "kernels": pk, "comp_all": p_comp,
-              "comp_rank": pstate["C"], "total": total_uncompressed, "steps": args.steps}
+              "comp_rank": pstate["C"], "total": total_uncompressed, "steps": args.steps,
+              "parity_sample": pstate.get("parity_sample")}
 
     # ---- N > 1: the batch lives on rank 0 and comes home to rank 0 (RCCL over xGMI) ----
     transfer = None
@@ -622,6 +650,7 @@ def main():
             "roofline_passes": {},
             "roofline_kernels": {k: roof(b, avg[k], k) for k, b in own.items() if k in avg},
             "source_sha": source_sha(),
+            "parity_sample": parity_sample,
         }
         if do_c:
             out["roofline_passes"]["compress"] = roof(N + C, t_comp / args.steps)
@@ -642,10 +671,17 @@ def main():
             torch.cuda.empty_cache()
             out["configs"] = side_configs(torch, eng, api, synth, stream, host, max(2, min(args.steps, 5)))
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            cores = min(os.cpu_count() or 1, 32)
-            per_core = max(1, min(64, (16 << 20) // size))  # ~0.1 s a repetition: ten of them are not noise
+            # every host core this process may run on (no cap); a repetition is >= 2 core-seconds of
+            # work a core pair, i.e. ~ 32 MiB a thread, so that thread start-up and a straggler are
+            # a few percent of it: ~ 20 s in all
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            per_core = max(1, (32 << 20) // size)
             sample = [host[i].tobytes() for i in range(min(n, cores * per_core))]
             out["cpu_baseline"] = cpu_baseline(sample, args.level, cores)
+            out["cpu_baseline"]["nproc"] = os.cpu_count()
         out["host_gen_s"] = round(t_gen, 1)
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -84,6 +84,14 @@ typedef struct zh_ctx zh_ctx;
 /* device < 0: current device.  stream: a hipStream_t to enqueue on, or NULL to
  * let the context create its own. */
 int zh_create(int device, void *stream, zh_ctx **out);
+/* The chain levels' (-1, 2..9) link kernels take the ORDER of their results from a property of the LDS
+ * unit -- the lanes of one returning atomic are served in ascending lane order -- which the ISA manual does
+ * not promise (lz77.nim:69-71's `chain[windowPos] = head[hash]; head[hash] = windowPos`, 64 positions a
+ * step).  zh_create asks the device itself, once per device and process (a known-answer launch on the
+ * context's stream, which it waits for); a device that answers otherwise gets the in-order link kernels
+ * -- same bytes, slower -- and zh_last_error says so.  -> 1: the device passed, 0: the in-order kernels run
+ * (also under ZH_CHAIN_PREV=serial). */
+int zh_chain_links_parallel(zh_ctx *ctx);
 void zh_destroy(zh_ctx *ctx);
 const char *zh_strerror(int status);
 const char *zh_last_error(zh_ctx *ctx); /* detail of the last ZH_ERR_DEVICE */

@@ -92,6 +92,17 @@ int main(void) {
     if (rc != ZH_OK || st[3] != ZH_ERR_DST_TOO_SMALL || cd[3] != NULL || clen[3] != comp_len[3])
       return fail("compress_into with a small buffer", rc ? rc : st[3]);
     if (st[4] != ZH_OK) return fail("neighbour of a small buffer", st[4]);
+    /* ... and so does uncompress: the status a binding grows its buffer and retries on, not a checksum error */
+    for (i = 0; i < N; i++) {
+      cd[i] = comp[i];
+      ud[i] = ubuf[i];
+      ucap[i] = lens[i];
+    }
+    ucap[3] = lens[3] - 1;
+    rc = zh_uncompress_batch_into(ctx, (const void *const *)cd, comp_len, N, ZH_DF_GZIP, ud, ucap, ulen, st);
+    if (rc != ZH_OK || st[3] != ZH_ERR_DST_TOO_SMALL || ud[3] != NULL || ulen[3] != lens[3])
+      return fail("uncompress_into with a small buffer", rc ? rc : st[3]);
+    if (st[4] != ZH_OK || ulen[4] != lens[4]) return fail("neighbour of a small buffer (uncompress)", st[4]);
   }
 
   /* a damaged member fails its own slot with the reference's error, the others still decode */

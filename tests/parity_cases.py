@@ -546,34 +546,43 @@ def check_ragged_staging(eng, scale):
 
 def check_batch_into(eng):
     """zh_compress_batch_into / zh_uncompress_batch_into: the results of the ordinary calls, in
-    buffers of the caller's; one that is too small only fails its own slot and learns its size."""
+    buffers of the caller's; one that is too small only fails its own slot -- with ZH_ERR_DST_TOO_SMALL,
+    which is what a binding grows and retries on (include/zippy_hip.h) -- and learns its size.  Once as
+    one plan, once as pipelined groups."""
     import synth
+    TOO_SMALL = 21  # ZH_ERR_DST_TOO_SMALL
     eng.set_gzip_fname_len(0)
     bufs = [b.tobytes() for b in synth.gen_batch("mix", 5, 70001)] + [b"", b"x" * 300, synth.corpus_file("html")]
     want, sts = eng.compress_batch(bufs, 1, oracle.dfGzip)
-    outs = [bytearray(eng.compress_bound(len(b))) for b in bufs]
-    outs[2] = bytearray(100)  # too small
-    lens, sts2, filled = eng.compress_batch_into(bufs, outs, 1, oracle.dfGzip)
-    for i, b in enumerate(bufs):
-        assert lens[i] == len(want[i]), i
-        if i == 2:
-            assert sts2[i] != 0 and not filled[i]
-        else:
-            assert sts2[i] == 0 and bytes(outs[i][:lens[i]]) == want[i], i
-    for fmt in (oracle.dfGzip, oracle.dfDeflate):
-        blobs, _ = eng.compress_batch(bufs, 1, fmt)
-        back = [bytearray(len(b)) for b in bufs]
-        back[4] = bytearray(len(bufs[4]) - 1)  # one byte short
-        blobs = list(blobs)
-        blobs[1] = blobs[1][:len(blobs[1]) // 2]  # and a damaged stream
-        lens, sts3, filled = eng.uncompress_batch_into(blobs, back, fmt)
-        for i, b in enumerate(bufs):
-            if i == 1:
-                assert sts3[i] != 0
-            elif i == 4:
-                assert sts3[i] != 0 and lens[i] == len(b), (fmt, sts3[i], lens[i])
-            else:
-                assert sts3[i] == 0 and lens[i] == len(b) and bytes(back[i]) == b, (fmt, i)
+    for pipe in ((1 << 60, 0), (1, 150000)):
+        try:
+            eng.set_host_pipeline(*pipe)
+            outs = [bytearray(eng.compress_bound(len(b))) for b in bufs]
+            outs[2] = bytearray(100)  # too small
+            lens, sts2, filled = eng.compress_batch_into(bufs, outs, 1, oracle.dfGzip)
+            for i, b in enumerate(bufs):
+                assert lens[i] == len(want[i]), (pipe, i)
+                if i == 2:
+                    assert sts2[i] == TOO_SMALL and not filled[i], (pipe, sts2[i])
+                else:
+                    assert sts2[i] == 0 and filled[i] and bytes(outs[i][:lens[i]]) == want[i], (pipe, i)
+            for fmt in (oracle.dfGzip, oracle.dfZlib, oracle.dfDeflate):
+                blobs, _ = eng.compress_batch(bufs, 1, fmt)
+                back = [bytearray(len(b)) for b in bufs]
+                back[4] = bytearray(len(bufs[4]) - 1)  # one byte short
+                back[7] = bytearray(5)                 # far too short (a sized stream takes the sizing pass)
+                blobs = list(blobs)
+                blobs[1] = blobs[1][:len(blobs[1]) // 2]  # and a damaged stream
+                lens, sts3, filled = eng.uncompress_batch_into(blobs, back, fmt)
+                for i, b in enumerate(bufs):
+                    if i == 1:
+                        assert sts3[i] not in (0, TOO_SMALL), (pipe, fmt, sts3[i])
+                    elif i in (4, 7):
+                        assert sts3[i] == TOO_SMALL and lens[i] == len(b) and not filled[i], (pipe, fmt, i, sts3[i], lens[i])
+                    else:
+                        assert sts3[i] == 0 and filled[i] and lens[i] == len(b) and bytes(back[i]) == b, (pipe, fmt, i)
+        finally:
+            eng.set_host_pipeline(0, 0)
 
 
 def check_unsized_streams(eng):

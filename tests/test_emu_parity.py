@@ -78,6 +78,26 @@ def test_emu_chain_cross_check_kernels():
         assert r.returncode == 0, (env, r.stderr[-2000:])
 
 
+def test_emu_lds_order_probe(eng):
+    """zh_create asks the device whether the lanes of an LDS atomic are served in ascending order (what the
+    class-sorted chain links take their order from): the emulator passes; a device that fails the probe
+    (ZH_LDS_ORDER_PROBE=fail pretends one) gets the in-order kernels, says so, and still gives the oracle's bytes."""
+    import os
+    import subprocess
+    import sys
+    assert eng.chain_links_parallel()
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import emu, oracle, parity_cases as pc, synth\n"
+            "eng = emu.engine()\n"
+            "assert not eng.chain_links_parallel()\n"
+            "assert b'in-order' in eng.lib.zh_last_error(eng._h)\n"
+            "pc.check_compress_identical(eng, [synth.corpus_file('alice29.txt')[:60000]], levels=(-1, 1), formats=(oracle.dfDeflate,))\n"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZH_LDS_ORDER_PROBE="fail"), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_emu_multi_block_buffer(eng):
     # > 4 MiB: two deflate blocks in one buffer (deflate.nim:228-237); runs/zeros keep it fast
     src = (b"\x00" * 3000000 + synth.gen_batch("runs", 1, 1300000)[0].tobytes())

@@ -32,6 +32,13 @@ def inflate_mode(request, eng):
     eng.set_inflate_mode(-1)
 
 
+def test_gpu_lds_order_probe(eng):
+    """zh_create's known-answer launch: this MI355X serves the lanes of a returning LDS atomic in ascending
+    order, so the chain levels' links come from the class-sorted kernels (byte identity of those levels is what
+    the compress tests below check; a device that failed here would run the in-order kernels instead)."""
+    assert eng.chain_links_parallel(), eng.lib.zh_last_error(eng._h)
+
+
 def test_gpu_fixtures_decode(eng, inflate_mode):
     pc.check_fixtures(eng)
 

@@ -19,6 +19,7 @@ _SIGS = {
     "zh_stream": (_c.c_void_p, [_c.c_void_p]),
     "zh_set_gzip_fname_len": (None, [_c.c_void_p, _c.c_int]),
     "zh_set_host_pipeline": (None, [_c.c_void_p, _c.c_size_t, _c.c_size_t]),
+    "zh_chain_links_parallel": (_c.c_int, [_c.c_void_p]),
     "zh_set_inflate_mode": (None, [_c.c_void_p, _c.c_int]),
     "zh_set_l1_parse": (None, [_c.c_void_p, _c.c_int]),
     "zh_compress_bound": (_c.c_size_t, [_c.c_size_t, _c.c_int]),
@@ -335,6 +336,11 @@ class Engine:
         """BestSpeed match finder: 0 the reference's parse (byte-identical streams, default),
         1 the parallel parse (valid streams of about the same size), -1: default / ZH_L1_PARSE."""
         self.lib.zh_set_l1_parse(self._h, mode)
+
+    def chain_links_parallel(self):
+        """True: the device passed zh_create's probe and the chain levels' links are built by the class-sorted
+        kernels; False: by the in-order ones (a failed probe, or ZH_CHAIN_PREV=serial)."""
+        return bool(self.lib.zh_chain_links_parallel(self._h))
 
     def set_host_pipeline(self, min_batch_bytes=0, group_bytes=0):
         self.lib.zh_set_host_pipeline(self._h, min_batch_bytes, group_bytes)

@@ -54,6 +54,8 @@ uint32_t zh_l1p_slots(void);
 void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint32_t* head_scratch,
                           uint64_t* prevw, uint32_t* lists);
 uint32_t zh_chain_prev_slice(void);
+int zh_chain_lds_order_ok(int device, hipStream_t stream);
+int zh_chain_prev_is_serial(void);
 void zh_launch_chain_search(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
                             int max_chain, const uint64_t* prevw, uint32_t* best);
 void zh_launch_chain_select(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
@@ -265,8 +267,17 @@ extern "C" int zh_create(int device, void* stream, zh_ctx** out) {
     delete c;
     return ZH_ERR_DEVICE;
   }
+  // the chain levels' parallel link kernels rest on the order in which the LDS unit serves the lanes of an
+  // atomic: the device is asked once (zh_chain_match.hip); one that answers otherwise runs the in-order kernels
+  if (!zh_chain_lds_order_ok(device, c->stream))
+    c->last_error = "this device does not serve the lanes of an LDS atomic in ascending order (or could not be asked): "
+                    "levels -1, 2..9 build their chain links with the in-order kernels (ZH_CHAIN_PREV=serial)";
   *out = c;
   return ZH_OK;
+}
+extern "C" int zh_chain_links_parallel(zh_ctx* ctx) {
+  if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return 0;
+  return zh_chain_prev_is_serial() ? 0 : 1;
 }
 
 extern "C" void zh_destroy(zh_ctx* ctx) {
@@ -342,6 +353,10 @@ struct zh_plan {
   uint32_t* l1_counter = nullptr; // ... and the counter its waves draw fragments from
   uint64_t* chain_prev = nullptr;
   uint32_t* chain_best = nullptr;
+  // best[] is cleared when the plan is made and handed back cleared by every run's link kernels; a run that
+  // did not get as far (a launch that failed between the scatter and the links) leaves it dirty, and the next
+  // run clears it before anything reads it
+  bool chain_best_dirty = false;
   uint64_t dst_lo = 0, dst_hi = 0;  // byte range of d_dst covered by the slots
   bool dst_dense = true;            // the slots tile [dst_lo, dst_hi) without gaps
   uint64_t dst_max_cap = 0;
@@ -1124,12 +1139,18 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       zh_launch_l1_match(s, d_src, a, p->level == -2, p->l1_tables, p->l1_counter);
     } else if (p->level != 0) {
       const int* cfg = kChainConfig[p->level == -1 ? 6 : p->level];
+      if (p->chain_best_dirty)
+        ZH_HIP(ctx, hipMemsetAsync(p->chain_best, 0, (size_t)a.nfrags * ZH_FRAG_SIZE * 4u, s));
+      p->chain_best_dirty = true;
       prof_mark(p, "zh_chain_prev_kernel");
       zh_launch_chain_prev(s, d_src, a, p->head_scratch, p->chain_prev, p->chain_best);
+      ZH_HIP(ctx, hipGetLastError());
       prof_mark(p, "zh_chain_walk_kernel");
       zh_launch_chain_search(s, d_src, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
       prof_mark(p, "zh_chain_select_kernel");
       zh_launch_chain_select(s, d_src, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+      ZH_HIP(ctx, hipGetLastError());
+      p->chain_best_dirty = false;  // (every launch was accepted: the links kernel hands best[] back cleared)
       prof_mark(p, "zh_frag_stats_kernel");
       zh_launch_frag_stats(s, d_src, a);
     }
@@ -1984,9 +2005,12 @@ static int uncompress_batch_pipelined(zh_ctx* ctx, const void* const* srcs, cons
   return ZH_OK;
 }
 
+// hints_are_caps: the hints are capacities of buffers of the caller's (zh_uncompress_batch_into), not promised
+// sizes: a stream that outgrows its hint takes the sizing pass (its size is all that is reported then) instead of
+// a second decode at the 1032 x expansion bound.
 static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const size_t* lens, size_t n,
                                  int data_format, const uint64_t* size_hints, void** dsts,
-                                 size_t* dst_lens, int32_t* statuses, uint32_t* crcs) {
+                                 size_t* dst_lens, int32_t* statuses, uint32_t* crcs, bool hints_are_caps = false) {
   if (!ctx || (n && (!srcs || !lens || !dsts || !dst_lens || !statuses))) return ZH_ERR_ARGUMENT;
   for (size_t i = 0; i < n; i++) {
     dsts[i] = nullptr;
@@ -2008,7 +2032,7 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
   // verified afterwards); zlib / raw streams carry nothing: they get a guess (4x their size,
   // enough for most data) and, if they outgrow it, a sizing pass (count only) and a second decode.
   std::vector<uint64_t> cap(n, 0);
-  std::vector<char> guessed(n, 0), active(n, 1);
+  std::vector<char> guessed(n, 0), active(n, 1), hinted(n, 0);
   for (size_t i = 0; i < n; i++) {
     const uint8_t* s8 = (const uint8_t*)srcs[i];
     const int f = host_detect(s8, lens[i], data_format);
@@ -2020,6 +2044,7 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
     } else if (f == ZH_DF_ZLIB || f == ZH_DF_DEFLATE) {
       if (size_hints) {
         cap[i] = std::min<uint64_t>(size_hints[i], max_out);
+        hinted[i] = 1;
       } else {
         guessed[i] = 1;
         cap[i] = std::min<uint64_t>((uint64_t)lens[i] * 4 + 65536, max_out);
@@ -2085,6 +2110,7 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
       if (!active[i]) continue;
       statuses[i] = ost[i];
       if (ost[i] == ZH_ERR_DST_TOO_SMALL && pass == 1) {
+        if (hints_are_caps && hinted[i]) guessed[i] = 1;  // (only its size is wanted: count, then decode into as much)
         if (guessed[i])
           size_first = true;
         else
@@ -2093,6 +2119,10 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
         continue;
       }
       active[i] = 0;
+      // the decoder ran out of room at the expansion bound (or at the size its own sizing pass counted): the
+      // stream is not what it claims to be.  (A result that does not fit a buffer of the CALLER's is
+      // download_pack's DST_TOO_SMALL below and stays that.)
+      if (ost[i] == ZH_ERR_DST_TOO_SMALL) statuses[i] = ZH_ERR_CHECKSUM;
       if (ost[i] != ZH_OK) continue;
       take[i] = 1;
       if (crcs) crcs[i] = ocrc[i];
@@ -2102,8 +2132,6 @@ static int uncompress_batch_impl(zh_ctx* ctx, const void* const* srcs, const siz
     if (!again || pass == 2) break;
     pass = size_first ? 0 : 2;
   }
-  for (size_t i = 0; i < n; i++)
-    if (statuses[i] == ZH_ERR_DST_TOO_SMALL) statuses[i] = ZH_ERR_CHECKSUM;
   return ZH_OK;
 }
 
@@ -2119,7 +2147,7 @@ extern "C" int zh_uncompress_batch_into(zh_ctx* ctx, const void* const* srcs, co
   IntoScope scope(ctx, dsts, caps, n);
   // (the capacities double as size hints: a stream without a size field is decoded into as much)
   std::vector<uint64_t> hints(caps, caps + n);
-  return uncompress_batch_impl(ctx, srcs, lens, n, data_format, hints.data(), dsts, dst_lens, statuses, nullptr);
+  return uncompress_batch_impl(ctx, srcs, lens, n, data_format, hints.data(), dsts, dst_lens, statuses, nullptr, true);
 }
 extern "C" int zh_uncompress_batch_sized(zh_ctx* ctx, const void* const* srcs, const size_t* lens,
                                          size_t n, int data_format, const uint64_t* size_hints,

@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <atomic>
 #include "zh_common.h"
 #include "zh_tables.h"
 
@@ -940,14 +941,85 @@ __global__ __launch_bounds__(64) void zh_frag_stats_kernel(const uint8_t* __rest
 // Up to this many blocks the exchanging kernel with its 512 KiB tables, beyond it the load / store
 // kernel with 256 KiB ones (the plan's scratch is sized for either).
 extern "C" uint32_t zh_chain_prev_slice(void) { return 1024u; }
-// ZH_CHAIN_PREV=serial: the in-order kernels 1 / 1b (a wave a block) instead of 1c: cross-check and measurement
+// ---- the hardware property kernels 1c take their ORDER from, asked of the device itself ----
+// "The lanes of one returning LDS atomic are served in ascending lane order" is what makes an atomicAdd a
+// stable rank and an atomicMax "the previous occupant of my slot, in position order" (zh_chain_class_kernel,
+// zh_chain_class_links_kernel).  The ISA manual does not promise it; a device that did otherwise would still
+// produce valid deflate (candidates are compared byte by byte), only not the reference's bytes.  So every
+// device answers a known-answer probe once, when the first context on it is made (zh_create): 64 rounds of
+// both atomics on few and many slots, with all and with some lanes active, each lane's answer compared with
+// the one the order implies.  A device that fails it gets the in-order kernels (ZH_CHAIN_PREV=serial's).
+__global__ __launch_bounds__(64) void zh_lds_order_probe_kernel(uint32_t* __restrict__ out) {
+  __shared__ uint32_t s_cnt[64], s_max[64];
+  const unsigned lane = zh_lane();
+  uint32_t bad = 0;
+  for (uint32_t round = 0; round < 64u; round++) {
+    s_cnt[lane] = 0;
+    if (round == 0) s_max[lane] = 0;
+    zh_wave_sync();
+    const uint32_t nslots = 1u + ((round * 11u) & 63u);                       // 1 .. 64 slots in use
+    const uint32_t h = ((lane * 2654435761u + round * 40503u) >> 7) % nslots;  // this lane's slot
+    const bool active = (round & 3u) != 3u || ((lane * 7u + round) & 3u) != 0u;  // every fourth round: three lanes in four
+    // what the order implies: the active lower lanes of my slot -- how many, and the highest
+    uint32_t below = 0, last = 64;
+    for (uint32_t j = 0; j < 64u; j++) {
+      const uint32_t hj = (uint32_t)__shfl((int)h, (int)j, 64);
+      const bool aj = __shfl((int)active, (int)j, 64) != 0;
+      if (aj && hj == h && j < lane) {
+        below++;
+        last = j;
+      }
+    }
+    const uint32_t before = s_max[h];  // (what earlier rounds left in my slot)
+    zh_wave_sync();
+    if (active) {
+      const uint32_t rank = atomicAdd(&s_cnt[h], 1u);
+      const uint32_t prev = atomicMax(&s_max[h], round * 64u + lane + 1u);
+      bad |= rank != below;
+      bad |= prev != (last < 64u ? round * 64u + last + 1u : before);
+    }
+    zh_wave_sync();
+  }
+  const uint64_t anybad = __ballot(bad != 0);
+  if (lane == 0) out[0] = anybad ? 2u : 1u;
+}
+static std::atomic<int> g_lds_order[64];  // per device: 0 not asked, 1 in lane order, 2 not
+// -> 1: this device serves the lanes of an LDS atomic in ascending order (kernels 1c are exact), 0: it does not
+// (or could not be asked): the in-order kernels run.  Synchronises `stream` the first time a device is asked.
+extern "C" int zh_chain_lds_order_ok(int device, hipStream_t stream) {
+  if (device < 0 || device >= 64) return 0;
+  int v = g_lds_order[device].load();
+  if (v == 0) {
+    uint32_t* d = nullptr;
+    uint32_t h = 0;
+    if (hipMalloc(&d, 4) == hipSuccess) {
+      if (hipMemsetAsync(d, 0, 4, stream) == hipSuccess) {
+        hipLaunchKernelGGL(zh_lds_order_probe_kernel, dim3(1), dim3(64), 0, stream, d);
+        if (hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+          h = 0;
+      }
+      (void)hipFree(d);
+    }
+    v = h == 1u ? 1 : 2;
+    const char* e = getenv("ZH_LDS_ORDER_PROBE");  // test aid: "fail" pretends the device answered otherwise
+    if (e && strcmp(e, "fail") == 0) v = 2;
+    g_lds_order[device].store(v);
+  }
+  return v == 1;
+}
+// ZH_CHAIN_PREV=serial: the in-order kernels 1 / 1b (a wave a block) instead of 1c: cross-check and measurement;
+// also what a device gets that failed the probe above
 static bool chain_prev_serial() {
   static const bool on = [] {
     const char* e = getenv("ZH_CHAIN_PREV");
     return e && strcmp(e, "serial") == 0;
   }();
-  return on;
+  if (on) return true;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  return g_lds_order[dev].load() != 1;  // (never asked: no context was made on this device -- be safe)
 }
+extern "C" int zh_chain_prev_is_serial(void) { return chain_prev_serial() ? 1 : 0; }
 // `lists`: 4 bytes a position of scratch (the plan lends best[], which the walks clear before they use it)
 extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
                                      uint32_t* head_scratch, uint64_t* prevw, uint32_t* lists) {
