@@ -1515,6 +1515,9 @@ const char *zo_strerror(int status) {
 #define _GNU_SOURCE
 #endif
 #include <pthread.h>
+#ifdef __GLIBC__
+#include <malloc.h>
+#endif
 #include <sched.h>
 #include <time.h>
 
@@ -1564,6 +1567,21 @@ static void *zo_mt_worker(void *arg) {
 int zo_batch_mt(const uint8_t *const *srcs, const size_t *lens, size_t n, int dir, int level, int fmt,
                 int threads, zo_buf *outs, double *seconds) {
   if (threads < 1) threads = 1;
+#ifdef __GLIBC__
+  {
+    /* The codec grows its result with realloc(); glibc serves blocks of a MiB by mmap()/munmap(), every one of
+     * them a trip through the process's address-space lock and a page fault a page -- with a few hundred threads
+     * that lock, not the codec, is what gets timed.  Keep such blocks in the (per-thread) arenas instead: after
+     * the warm-up repetition a thread's buffers are recycled memory. */
+    static int tuned = 0;
+    if (!tuned) {
+      tuned = 1;
+      mallopt(M_MMAP_THRESHOLD, 1 << 30);
+      mallopt(M_TRIM_THRESHOLD, 1 << 30);
+      mallopt(M_TOP_PAD, 64 << 20);
+    }
+  }
+#endif
   pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof *tid);
   zo_mt_job *jobs = (zo_mt_job *)calloc((size_t)threads, sizeof *jobs);
   pthread_barrier_t bar;
