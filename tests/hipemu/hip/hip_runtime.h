@@ -25,6 +25,7 @@
 #define __shared__ static
 #define __constant__ static
 #define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 

@@ -698,6 +698,34 @@ def split_inflate_edge_streams():
     return out
 
 
+def damaged_header_streams(step=1):
+    """Raw deflate streams (no checksum behind them: only the byte comparison catches a wrong byte) whose
+    dynamic header is hit bit by bit: every bit of the first 90 bytes flipped, one at a time -- HLIT / HDIST /
+    HCLEN, the code-length code's lengths, the run-length coded lengths with their repeat counts.  One input
+    has a skewed alphabet (code lengths up to 15: second-level tables), one is text, one uses few symbols
+    (long zero runs in the header).  zh_inflate_split.hip reads clean headers with a whole wave and builds the
+    tables with the workgroup; anything else goes to the serial reader: both have to agree with the oracle."""
+    rnd = random.Random(4242)
+    skew = bytes(min(255, int(rnd.expovariate(0.035))) for _ in range(6000))
+    few = bytes(rnd.choice(b"ab\x00\xff") for _ in range(2500)) + b"abab" * 50
+    text = synth.corpus_file("alice29.txt")[:4000]
+    out = []
+    for data, strategy in ((skew, zlib.Z_HUFFMAN_ONLY), (text, zlib.Z_DEFAULT_STRATEGY), (few, zlib.Z_DEFAULT_STRATEGY)):
+        c = zlib.compressobj(9, zlib.DEFLATED, -15, 9, strategy)
+        blob = c.compress(data) + c.flush()
+        assert (blob[0] >> 1) & 3 == 2, "expected a dynamic block"
+        out.append(blob)
+        for bit in range(0, min(len(blob), 90) * 8, step):
+            m = bytearray(blob)
+            m[bit >> 3] ^= 1 << (bit & 7)
+            out.append(bytes(m))
+    return out
+
+
+def check_damaged_headers(eng, step=1):
+    check_errors_match_oracle(eng, damaged_header_streams(step), oracle.dfDeflate)
+
+
 def check_split_inflate_edges(eng):
     """Both inflate paths return the input for every stream above, and the same statuses when the
     output slot is one byte short (device plan API is exercised by check_plan_slots_with_gaps)."""

@@ -154,6 +154,10 @@ def test_emu_damaged_streams(eng, inflate_mode):
     pc.check_error_statuses(eng)
 
 
+def test_emu_damaged_headers(eng, inflate_mode):
+    pc.check_damaged_headers(eng, step=3)
+
+
 def test_emu_zlib_and_raw_need_sizing_pass(eng, inflate_mode):
     import zlib
     src = synth.corpus_file("alice29.txt")[:60000]

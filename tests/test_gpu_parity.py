@@ -39,6 +39,12 @@ def test_gpu_lds_order_probe(eng):
     assert eng.chain_links_parallel(), eng.lib.zh_last_error(eng._h)
 
 
+def test_gpu_damaged_headers(eng, inflate_mode):
+    """Every bit of three dynamic headers flipped in turn (2 160 raw deflate streams): the wave-parallel header
+    reader, its fall-back to the serial one and the workgroup-built tables against the oracle."""
+    pc.check_damaged_headers(eng)
+
+
 def test_gpu_fixtures_decode(eng, inflate_mode):
     pc.check_fixtures(eng)
 

@@ -43,6 +43,9 @@
 #ifndef ZH_SUBBITS
 #define ZH_SUBBITS 512
 #endif
+#ifndef ZH_SERIAL_HEADER
+#define ZH_SERIAL_HEADER 0  // 1: the code lengths of every dynamic header by the serial reader (cross-check, measurement)
+#endif
 
 #include "zh_common.h"
 #include "zh_kprof.h"
@@ -51,6 +54,7 @@
 
 namespace {
 
+constexpr bool kSerialHeader = ZH_SERIAL_HEADER != 0;
 constexpr uint32_t kSubBits = ZH_SUBBITS;                            // one thread's share of a superchunk
 constexpr uint32_t kSubWords = kSubBits / 32u;                 // 16
 // The staged superchunk gives every subchunk 19 dwords: its own 16 and a copy of the next three
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
   // comes out, in bits behind the subchunk's end (or kMapTerm)
   __shared__ uint8_t s_map[kMapGroup][kStartSpan];
   // block / superchunk control words written by one thread, read by all
-  __shared__ uint32_t s_c_btype, s_c_final, s_c_st, s_c_stored_len, s_c_term, s_c_endrel;
+  __shared__ uint32_t s_c_btype, s_c_final, s_c_st, s_c_stored_len, s_c_term, s_c_endrel, s_c_hlit, s_c_hdist;
   __shared__ uint64_t s_c_pos;
 
   const uint32_t tid = threadIdx.x;
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
 
   // the block header at `pos`: staged, then read by wave 0 like the serial kernel does; leaves the
   // tables in LDS and the s_c_* words
+  uint32_t hdr_st = 0;  // the header's status (the same in every thread)
   auto parse_header = [&]() {
     // ---- block header: staged, then read by wave 0 like the serial kernel does ----
     const uint64_t hbase = pos >> 5;  // dword of the header's first bit
@@ -349,7 +354,20 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
           hdist = take(5) + 1;
           const uint32_t hclen = take(4) + 4;
           if (hlit > 286 || hdist > 30) hst = ZH_ERR_INVALID_BUFFER;
-          if (hst == ZH_OK) {
+          // the code lengths by the whole wave (zh_inflate_tables.h); anything but a clean header comes back as 0
+          // and is read again by the serial reader below, which raises the reference's error for it
+          uint32_t fast_q = 0;
+          if (hst == ZH_OK && !kSerialHeader)
+            fast_q = code_lengths_wave(s_in, (uint32_t)bp, hlit, hdist, hclen, end * 8 > hbase * 32 ? end * 8 - hbase * 32 : 0,
+                                       s_lens, reinterpret_cast<uint8_t*>(s_dst));
+#ifdef ZH_EMU
+          if (lane == 0 && hst == ZH_OK && getenv("ZH_DBG_HDR")) fprintf(stderr, "dynamic header: %s\n", fast_q ? "wave" : "serial reader");
+#endif
+          if (fast_q) {
+            bp = fast_q;
+            hc = 0;
+          }
+          if (hst == ZH_OK && !fast_q) {
             zh_wave_sync();
             if (lane < 20) s_lens[lane] = 0;
             zh_wave_sync();
@@ -360,7 +378,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
             }
             hst = build_table(s_lens, 19, s_dst, 7, 2, &s_tab_cl, s_val_cl, s_cnt);
           }
-          if (hst == ZH_OK) {
+          if (hst == ZH_OK && !fast_q) {
             uint32_t i = 0;
             const uint32_t total = hlit + hdist;
             uint32_t prev = 0;
@@ -400,11 +418,9 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
             }
           }
         }
-        if (hst == ZH_OK) {
-          const uint32_t dist_at = btype == 1 ? 288u : hlit;
-          hst = build_table(s_lens, hlit, s_lit, kLitBits, 0, &s_tab_lit, s_val_lit, s_cnt, kLitSub);
-          if (hst == ZH_OK)
-            hst = build_table(s_lens + dist_at, hdist, s_dst, kDistBits, 1, &s_tab_dist, s_val_dist, s_cnt, kDistSub);
+        if (lane == 0) {
+          s_c_hlit = hlit;
+          s_c_hdist = hdist;
         }
       }
       if (lane == 0) {
@@ -416,6 +432,16 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
       }
     }
     __syncthreads();
+    hdr_st = s_c_st;
+    if (hdr_st == (uint32_t)ZH_OK && s_c_btype != 0u) {
+      // the decode tables, by everybody (the staged header is done with: its bytes behind the first 320 words are scratch)
+      const uint32_t hlit = s_c_hlit, hdist = s_c_hdist, dist_at = s_c_btype == 1u ? 288u : hlit;
+      int t = build_table_wg<kSplitThreads, kLitBits, kLitSub, 0>(s_lens, hlit, s_lit, &s_tab_lit, s_val_lit, s_cnt, s_in + 320);
+      if (t == ZH_OK)
+        t = build_table_wg<kSplitThreads, kDistBits, kDistSub, 1>(s_lens + dist_at, hdist, s_dst, &s_tab_dist, s_val_dist, s_cnt,
+                                                                  s_in + 320);
+      hdr_st = (uint32_t)t;
+    }
     KPROF_MARK(0);
   };
   // the superchunk that starts at the dword of `base_bit`, into s_in
@@ -473,7 +499,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
       pos = (uint64_t)mis * 8 + hdr;
       parse_header();
       const uint64_t payload = s_c_pos;
-      if (s_c_st == (uint32_t)ZH_OK && s_c_btype != 0u && payload < target) {
+      if (hdr_st == (uint32_t)ZH_OK && s_c_btype != 0u && payload < target) {
         constexpr uint64_t kBefore = 4096;  // bits of run-up
         const bool exact = payload + kBefore >= target;  // (the block starts that close: no guessing)
         const uint64_t s0 = exact ? payload : target - kBefore;
@@ -520,7 +546,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
     if (tid == 0 && getenv("ZH_DBG_BLOCKS"))
       fprintf(stderr, "block at bit %llu type %u (region %u)\n", (unsigned long long)(hdr_at - mis * 8), btype, sid);
 #endif
-    st = (int)s_c_st;
+    st = (int)hdr_st;
     if (s_c_final) final_block = true;
     pos = s_c_pos;
     if (st != ZH_OK) break;

@@ -164,5 +164,288 @@ __device__ int build_table(const uint8_t* lens, uint32_t n, uint32_t* lut, uint3
   return ZH_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// The same tables built by a whole WORKGROUP (zh_inflate_split.hip: a foreign stream of short blocks --
+// system zlib's are ~ 40 KiB of input each -- spent 38 % of the tokens kernel in block headers, one wave
+// at work and the others waiting at a barrier).  Not the same stores in the same order as build_table(),
+// but the same function of the code lengths: a root entry per R-bit prefix -- the code of at most R bits
+// that the prefix starts with, or a link to the second-level table of the longer codes below it, or 0
+// ("decode alone on the canonical path", which also finds the errors) -- second-level tables in prefix
+// order as long as they fit, the canonical arrays for the slow path, and ZH_ERR_INVALID_BUFFER for an
+// over-subscribed code (inflate.nim:32-51).  Every root entry is written (no clearing pass), every thread
+// resolves its own prefixes with the counts in registers (no serial walk over the symbols).
+// ---------------------------------------------------------------------------
+// entry encoders without the constant tables (a per-lane lookup there is a trip to memory)
+__device__ __forceinline__ uint32_t litlen_entry_a(uint32_t sym, uint32_t len) {
+  if (sym < 256) return len | (kKindLit << 8) | 0x8000u | (sym << 16);
+  if (sym == 256) return len | (kKindEob << 8);
+  if (sym < 286) {
+    const uint32_t li = sym - 257;
+    return len | (zh_len_extra_bits(li) << 4) | (kKindBase << 8) | (zh_len_base(li) << 16);
+  }
+  return len | (kKindBad << 8);
+}
+__device__ __forceinline__ uint32_t dist_entry_a(uint32_t sym, uint32_t len) {
+  if (sym < 30) return len | (zh_dist_extra_bits(sym) << 4) | (kKindBase << 8) | (zh_dist_base(sym) << 16);
+  return len | (kKindBad << 8);
+}
+
+constexpr uint32_t kWgScratchWords = 128u + 256u;  // build_table_wg's scratch (dwords)
+
+// T threads (256 or 1024), all of them; R-bit root table, SUBCAP second-level entries behind it; KIND 0 litlen,
+// 1 distance.  lens[0..n) in LDS, n <= 320.  `scratch`: kWgScratchWords dwords of LDS nobody else uses meanwhile.
+// Ends with a barrier (the tables are ready for every thread); the returned status is the same in every thread.
+template <uint32_t T, uint32_t R, uint32_t SUBCAP, int KIND>
+__device__ __noinline__ int build_table_wg(const uint8_t* lens, uint32_t n, uint32_t* lut, HuffTab* tab, uint16_t* values,
+                              uint32_t* s_cnt, uint32_t* scratch) {
+  static_assert(T % 64u == 0 && R <= 10u, "");
+  constexpr uint32_t kGroups = 5;                       // symbols in groups of 64: 320 slots
+  constexpr uint32_t kSlots = (kGroups * 64u + T - 1u) / T;  // symbol slots a thread
+  constexpr uint32_t kPP = ((1u << R) + T - 1u) / T;   // prefixes a thread
+  const uint32_t tid = threadIdx.x, wv = tid >> 6;
+  const unsigned lane = zh_lane();
+  uint32_t* const s_g = scratch;            // [kGroups][16] symbols of a length in a group
+  uint32_t* const s_bad = scratch + 80;
+  uint32_t* const s_ws = scratch + 96;      // [T / 64] wave sums of the second-level sizes
+  uint8_t* const s_sz = reinterpret_cast<uint8_t*>(scratch + 128);  // (unused: sizes stay in registers)
+  (void)s_sz;
+  // ---- 1. every symbol's rank among the symbols of its length in its group ----
+  uint32_t sl[kSlots], srank[kSlots];
+#pragma unroll
+  for (uint32_t j = 0; j < kSlots; j++) {
+    const uint32_t s = tid + j * T;
+    sl[j] = 0;
+    srank[j] = 0;
+    if (s < kGroups * 64u) {  // (wave-uniform)
+      const uint32_t l = s < n ? lens[s] : 0u;
+      sl[j] = l;
+#pragma unroll
+      for (uint32_t L = 1; L < 16; L++) {
+        const uint64_t m = __ballot(l == L);
+        if (l == L) srank[j] = (uint32_t)__popcll(m & zh_lanemask_lt());
+        if (lane == 0) s_g[(s >> 6) * 16u + L] = (uint32_t)__popcll(m);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 2. inflate.nim:32-51: counts, first codes, first canonical indices (wave 0, every lane alike) ----
+  if (tid < 64) {
+    uint32_t code = 0, k = 0;
+    int bad = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < 16; i++) {
+      uint32_t h = 0;
+#pragma unroll
+      for (uint32_t g = 0; g < kGroups; g++) h += s_g[g * 16u + i];
+      if (h > (1u << i)) bad = 1;
+      if (lane == 0) {
+        s_cnt[i] = h;
+        tab->first_code[i] = (uint16_t)code;
+        tab->first_symbol[i] = (uint16_t)k;
+      }
+      code += h;
+      if (h > 0 && code - 1 >= (1u << i)) bad = 1;
+      if (lane == 0) tab->max_codes[i] = code << (16 - i);
+      code <<= 1;
+      k += h;
+    }
+    if (lane == 0) {
+      tab->max_codes[16] = 1u << 16;
+      s_cnt[0] = 0;
+      *s_bad = (uint32_t)bad;
+    }
+  }
+  __syncthreads();
+  if (*s_bad) {
+    __syncthreads();  // (everybody has read the flag before the scratch is used again)
+    return ZH_ERR_INVALID_BUFFER;
+  }
+  // the code's shape in registers: first code and count of a length in one word, first canonical index
+  uint32_t fcn[16], fs[16];
+#pragma unroll
+  for (uint32_t i = 1; i < 16; i++) {
+    fcn[i] = (uint32_t)tab->first_code[i] | (s_cnt[i] << 16);
+    fs[i] = tab->first_symbol[i];
+  }
+  // ---- 3. symbols in canonical order ----
+#pragma unroll
+  for (uint32_t j = 0; j < kSlots; j++) {
+    const uint32_t s = tid + j * T;
+    if (s < kGroups * 64u && sl[j]) {
+      uint32_t before = 0;
+      for (uint32_t g = 0; g < (s >> 6); g++) before += s_g[g * 16u + sl[j]];
+      uint32_t first = 0;
+#pragma unroll
+      for (uint32_t i = 1; i < 16; i++)
+        if (sl[j] == i) first = fs[i];
+      values[first + before + srank[j]] = (uint16_t)s;
+    }
+  }
+  __syncthreads();
+  // ---- 4. a root entry per prefix (prefix p = the first R bits of the stream as a number, first bit on top) ----
+  uint32_t hit_l[kPP], hit_t[kPP], sub_l[kPP], size_sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kPP; k++) {
+    const uint32_t p = tid * kPP + k;
+    hit_l[k] = 0;
+    hit_t[k] = 0;
+    sub_l[k] = 0;
+    if (p < (1u << R)) {
+#pragma unroll
+      for (uint32_t l = 1; l <= R; l++) {  // the code of l bits the prefix starts with, if any (a prefix code: one at most)
+        const uint32_t d = (p >> (R - l)) - (fcn[l] & 0xffffu);
+        if (d < (fcn[l] >> 16)) {
+          hit_l[k] = l;
+          hit_t[k] = fs[l] + d;
+        }
+      }
+      if (!hit_l[k]) {
+#pragma unroll
+        for (uint32_t L = R + 1u; L < 16; L++) {  // the longest code below the prefix
+          const uint32_t lo = p << (L - R), hi = lo + (1u << (L - R));
+          const uint32_t a = fcn[L] & 0xffffu, b = a + (fcn[L] >> 16);
+          if (a < b && lo < b && a < hi) sub_l[k] = L;
+        }
+        if (sub_l[k]) size_sum += 1u << (sub_l[k] - R);
+      }
+    }
+  }
+  // second-level tables in prefix order (= canonical order), as long as they fit
+  const uint32_t incl = zh_wave_scan(size_sum);
+  if (lane == 63) s_ws[wv] = incl;
+  __syncthreads();
+  uint32_t at = incl - size_sum;
+  for (uint32_t w = 0; w < wv; w++) at += s_ws[w];
+#pragma unroll
+  for (uint32_t k = 0; k < kPP; k++) {
+    const uint32_t p = tid * kPP + k;
+    if (p < (1u << R)) {
+      const uint32_t x = __brev(p) >> (32u - R);  // where the decoder looks: the stream carries codes first bit first
+      uint32_t e = 0;
+      if (hit_l[k]) {
+        const uint32_t sym = values[hit_t[k]];
+        e = KIND == 0 ? litlen_entry_a(sym, hit_l[k]) : dist_entry_a(sym, hit_l[k]);
+      } else if (sub_l[k]) {
+        const uint32_t sb = sub_l[k] - R, size = 1u << sb;
+        if (at + size <= SUBCAP) {  // (the sums grow: behind the first table that does not fit none does)
+          const uint32_t base = (1u << R) + at;
+          e = sb | 0x400u | (base << 16);
+          for (uint32_t q = 0; q < size; q++) {
+            uint32_t se = 0;
+            const uint32_t rq = __brev(q);
+#pragma unroll
+            for (uint32_t L = R + 1u; L < 16; L++) {
+              if (L <= sub_l[k]) {
+                const uint32_t code = (p << (L - R)) | (rq >> (32u - (L - R)));
+                const uint32_t d = code - (fcn[L] & 0xffffu);
+                if (d < (fcn[L] >> 16)) {
+                  const uint32_t sym = values[fs[L] + d];
+                  se = KIND == 0 ? litlen_entry_a(sym, L) : dist_entry_a(sym, L);
+                }
+              }
+            }
+            lut[base + q] = se;
+          }
+        }
+        at += size;
+      }
+      lut[x] = e;
+    }
+  }
+  __syncthreads();
+  return ZH_OK;
+}
+
+// The code lengths of a dynamic header (inflate.nim:115-171) by ONE WAVE instead of one lane's scalar chain:
+// the 64 lanes decode the code-length symbols that start at 64 consecutive bit positions, a wave-uniform walk
+// (one v_readlane a symbol) picks the ones really in the sequence, repeat counts become places by a prefix sum.
+// `hdr`: the header staged in LDS (dwords), bit 0 of hdr[0] = bit 0 of the staged range; `q`: the first bit
+// behind HCLEN; `end_bits`: the input's end in the same bit coordinates.  Fills lens[0 .. hlit + hdist) and
+// returns the bit behind the last symbol -- or 0 where the header is anything but clean (a code-length code
+// that is over-subscribed or does not cover what it is asked, a repeat with nothing before it or past the
+// end, input that ends inside): the caller then runs the serial reader, which knows the reference's status
+// for every such case.  `lut8`: 128 bytes of LDS.
+__device__ __noinline__ uint32_t code_lengths_wave(const uint32_t* hdr, uint32_t q, uint32_t hlit, uint32_t hdist, uint32_t hclen,
+                                      uint64_t end_bits, uint8_t* lens, uint8_t* lut8) {
+  const unsigned lane = zh_lane();
+  auto peek = [&](uint32_t at) -> uint32_t { return zh_alignbit(hdr[(at >> 5) + 1u], hdr[at >> 5], at); };
+  // lane s < 19: the length of code-length symbol s; its place in the header is the inverse of c_clcl_order
+  // {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2}, five bits a symbol in two constants
+  constexpr uint64_t kPlaceLo = 3ull | 17ull << 5 | 15ull << 10 | 13ull << 15 | 11ull << 20 | 9ull << 25 | 7ull << 30 |
+                                5ull << 35 | 4ull << 40 | 6ull << 45 | 8ull << 50 | 10ull << 55;
+  constexpr uint64_t kPlaceHi = 12ull | 14ull << 5 | 16ull << 10 | 18ull << 15 | 0ull << 20 | 1ull << 25 | 2ull << 30;
+  const uint32_t place = lane < 12u ? (uint32_t)(kPlaceLo >> (5u * lane)) & 31u
+                                    : lane < 19u ? (uint32_t)(kPlaceHi >> (5u * (lane - 12u))) & 31u : 99u;
+  const uint32_t l = place < hclen ? peek(q + 3u * place) & 7u : 0u;
+  q += 3u * hclen;
+  // canonical codes (inflate.nim:29-65): symbols of one length in symbol order; Kraft sum in 1/128ths
+  uint32_t code = 0, next = 0;
+#pragma unroll
+  for (uint32_t k = 1; k <= 7; k++) {
+    const uint64_t m = __ballot(l == k);
+    if (l == k) code = next + (uint32_t)__popcll(m & zh_lanemask_lt());
+    next = (next + (uint32_t)__popcll(m)) << 1;
+  }
+  if (zh_wave_sum(l ? 128u >> l : 0u) > 128u) return 0;  // over-subscribed
+  zh_wave_sync();
+  if (lane < 32u) reinterpret_cast<uint32_t*>(lut8)[lane] = 0;
+  for (uint32_t i = lane; i < (320u + 16u) / 4u; i += 64u) reinterpret_cast<uint32_t*>(lens)[i] = 0;
+  zh_wave_sync();
+  if (l) {
+    const uint32_t rev = __brev(code) >> (32u - l);
+    for (uint32_t e = rev; e < 128u; e += 1u << l) lut8[e] = (uint8_t)(lane | (l << 5));
+  }
+  zh_wave_sync();
+  const uint32_t total = hlit + hdist;
+  uint32_t i = 0, prev = 0;
+  while (i < total) {
+    const uint32_t w = peek(q + lane);  // the symbol that starts at bit q + lane
+    const uint32_t e = lut8[w & 127u], sym = e & 31u, cl = e >> 5;
+    const uint32_t x = w >> cl;
+    uint32_t rep = 1, val = sym, nb = cl;
+    if (sym == 16u) {
+      rep = (x & 3u) + 3u;
+      nb += 2u;
+    } else if (sym == 17u) {
+      rep = (x & 7u) + 3u;
+      nb += 3u;
+      val = 0;
+    } else if (sym == 18u) {
+      rep = (x & 127u) + 11u;
+      nb += 7u;
+      val = 0;
+    }
+    if (cl == 0u) nb = 64u;  // no code here: a walk that comes by ends the fast path
+    uint64_t on = 0;
+    uint32_t pos = 0;
+    while (pos < 64u) {
+      on |= 1ull << pos;
+      pos += (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)pos);
+    }
+    bool mine = (on >> lane) & 1ull;
+    const uint32_t incl = zh_wave_scan(mine ? rep : 0u);
+    const uint32_t at = i + incl - (mine ? rep : 0u);  // index of my first entry
+    if (mine && at >= total) mine = false;             // behind the last length: not part of the header
+    const uint64_t ON = __ballot(mine);                // (bit 0 is set: at = i < total)
+    if (__ballot(mine && (cl == 0u || at + rep > total))) return 0;
+    if (i == 0 && (uint32_t)__builtin_amdgcn_readlane((int)sym, 0) == 16u) return 0;  // nothing to repeat
+    // "previous length" for symbol 16: the nearest symbol before that is not a 16 (17 / 18 leave zero)
+    const uint64_t plain = __ballot(mine && sym != 16u) & zh_lanemask_lt();
+    const uint32_t from = plain ? 63u - (uint32_t)__clzll((long long)plain) : 0u;
+    const uint32_t pv = (uint32_t)__shfl((int)val, (int)from, 64);
+    if (sym == 16u) val = plain ? pv : prev;
+    if (mine && val)  // (zeros are there already; what is left repeats six times at most)
+      for (uint32_t j = 0; j < rep; j++) lens[at + j] = (uint8_t)val;
+    const uint32_t lastl = 63u - (uint32_t)__clzll((long long)ON);
+    i = (uint32_t)__builtin_amdgcn_readlane((int)(at + rep), (int)lastl);
+    prev = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)lastl);
+    q += lastl + (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)lastl);
+  }
+  zh_wave_sync();
+  if ((uint64_t)q > end_bits) return 0;
+  return q;
+}
+
 }  // namespace
 
