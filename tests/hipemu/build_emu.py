@@ -16,6 +16,13 @@ def build(force=False):
     import sys
     sys.path.insert(0, ROOT)
     from zippy_amd.build import SOURCES, HEADERS
+    # ZH_EMU_VARIANT=name ZH_EMU_DEFINES="-DZH_X=1 ...": a build of its own with other compile-time switches
+    global LIB, OBJ
+    var = os.environ.get("ZH_EMU_VARIANT")
+    defines = os.environ.get("ZH_EMU_DEFINES", "").split()
+    if var:
+        LIB = os.path.join(HERE, "libzippy_hip_emu_%s.so" % var)
+        OBJ = os.path.join(HERE, "build_" + var)
     os.makedirs(OBJ, exist_ok=True)
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(HERE, "hip", "hip_runtime.h")]
     objs = []
@@ -28,7 +35,7 @@ def build(force=False):
                 os.path.getmtime(p) for p in [s] + deps):
             cmd = ["g++", "-O1", "-g", "-std=c++17", "-x", "c++", "-fPIC", "-I", HERE,
                    "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unknown-pragmas",
-                   "-Wno-attributes", "-c", s, "-o", o]
+                   "-Wno-attributes"] + defines + ["-c", s, "-o", o]
             procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
     for cmd, p in procs:
         _, err = p.communicate()

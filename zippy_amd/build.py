@@ -29,12 +29,15 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, kprof=False):
+def build(force=False, verbose=False, kprof=False, variant=None, defines=()):
     """kprof=True builds the tuning variant libzippy_hip_kprof.so (-DZH_KPROF: in-kernel
-    phase timers, csrc/zh_kprof.h); the product library never carries them."""
-    objdir = OBJDIR + ("_kprof" if kprof else "")
-    lib = LIB.replace(".so", "_kprof.so") if kprof else LIB
-    flags = FLAGS + (["-DZH_KPROF", "-fgpu-rdc"] if kprof else [])
+    phase timers, csrc/zh_kprof.h); the product library never carries them.
+    variant="name", defines=["-DZH_X=1", ...]: a measurement build libzippy_hip_<name>.so of the same sources
+    with other compile-time switches (A/B runs on the GPU box: ZIPPY_HIP_LIB=<that file> python bench.py ...)."""
+    tag = ("_kprof" if kprof else "") + ("_" + variant if variant else "")
+    objdir = OBJDIR + tag
+    lib = LIB.replace(".so", tag + ".so")
+    flags = FLAGS + (["-DZH_KPROF", "-fgpu-rdc"] if kprof else []) + list(defines)
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
@@ -64,4 +67,7 @@ def build(force=False, verbose=False, kprof=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, kprof="--kprof" in sys.argv))
+    # python -m zippy_amd.build [--force] [--kprof] [--variant NAME -DZH_X=1 ...]
+    var = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    print(build(force="--force" in sys.argv, verbose="--quiet" not in sys.argv, kprof="--kprof" in sys.argv, variant=var,
+                defines=[a for a in sys.argv[1:] if a.startswith("-D")]))
