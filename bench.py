@@ -142,17 +142,18 @@ def cpu_baseline(bufs, level, cores, reps=8):
     }
 
 
-def hbm_traffic(n, size):
+def hbm_traffic(workload="headline"):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
-    (tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs of this same command, units and
-    gfx950 corrections as the MI355X guide prescribes).  Quoted only when the file was taken with
-    THESE kernel sources and this workload; otherwise {} (-> "traffic": null)."""
+    (tools/prof/pmc_passes.sh -> tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs of the command
+    behind every workload -- the headline step and BASELINE configs 2-5 --, units and gfx950 corrections as the
+    MI355X guide prescribes).  Quoted only when the file was taken with THESE kernel sources; otherwise {}
+    (-> "traffic": null)."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as fh:
             t = json.load(fh)
-        if t.get("buffers") == n and t.get("buffer_bytes") == size and t.get("source_sha") == source_sha():
-            return {k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()}
+        if t.get("source_sha") == source_sha():
+            return {k: v["hbm_bytes_per_launch"] for k, v in t["workloads"][workload]["kernels"].items()}
     except (OSError, KeyError, ValueError):
         pass
     return {}
@@ -213,14 +214,17 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
     from concurrent.futures import ThreadPoolExecutor
     out = {}
 
-    def entry(workload, nbytes, comp_bytes, tc, tu, kms):
+    def entry(workload, nbytes, comp_bytes, tc, tu, kms, pmc_key=None):
         ms = (tc if tc else 0.0) + (tu if tu else 0.0)
         own = own_bytes(nbytes, comp_bytes)
         dom = max((k for k in kms if k.startswith("zh_")), key=lambda k: kms[k])
         e = {"workload": workload, "value": round(nbytes / GIB / (ms * 1e-3), 3), "unit": "GiB/s",
              "ms_per_step": round(ms, 3), "ratio": round(nbytes / comp_bytes, 4),
              "dominant_kernel": dom, "dominant_kernel_ms": round(kms[dom], 4),
+             "algorithmic_bytes": own.get(dom, nbytes + comp_bytes),
              "frac": round(own.get(dom, nbytes + comp_bytes) / (kms[dom] * 1e-3) / HBM_PEAK, 6),
+             # measured HBM bytes a launch of that kernel (profiles/hbm_traffic.json, this workload's own PMC passes)
+             "traffic": hbm_traffic(pmc_key).get(dom) if pmc_key and full_size else None,
              "kernels_ms": {k: round(v, 4) for k, v in sorted(kms.items(), key=lambda kv: -kv[1]) if k != "end"}}
         if tc and tu:
             e["compress_GiBps"] = round(nbytes / GIB / (tc * 1e-3), 3)
@@ -285,7 +289,8 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
         time_plans(torch, stream, cplan, uplan, (d_src, d_comp, d_back), 0, 1, verify)
         tc, tu, kms = time_plans(torch, stream, cplan if do_c else None, uplan if do_u else None,
                                  (d_src, d_comp, d_back), nsteps, 0)
-        out[tag] = entry(workload, n * size, state["C"], tc if do_c else None, tu if do_u else None, kms)
+        out[tag] = entry(workload, n * size, state["C"], tc if do_c else None, tu if do_u else None, kms,
+                         "headline" if tag == "c3_own" else tag)
         for pl in (cplan, uplan):
             if pl is not None:
                 pl.close()
@@ -294,6 +299,7 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
         eng.set_l1_parse(-1)
 
     nb = host.shape[0]
+    full_size = nb == 4096  # (the PMC passes were taken on BASELINE's sizes)
     batch("c2", "config 2: 1024 x 64 KiB, compress BestSpeed gzip", min(1024, nb * 16), 65536, 1, True, False)
     batch("c2_parallel_parse", "config 2 with the opt-in parallel BestSpeed parse (valid streams, not the "
           "reference's bytes)", min(1024, nb * 16), 65536, 1, True, False, l1_parse=1)
@@ -325,7 +331,7 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
         assert ust == 0 and ulen == size and torch.equal(d_back, d_src), "config 5"
     tc, tu, kms = time_plans(torch, stream, cplan, uplan, (d_src, d_comp, d_back), steps, 1, verify5)
     out["c5"] = entry("config 5: 1 x %d MiB as independent 32 KiB deflate blocks, compress BestSpeed gzip + "
-                      "indexed uncompress" % mib, size, clen, tc, tu, kms)
+                      "indexed uncompress" % mib, size, clen, tc, tu, kms, "c5")
     cplan.close()
     uplan.close()
     return out
@@ -616,7 +622,7 @@ def main():
         # matcher N (reads the source), emit N + C, inflate C + N, checksum N.
         N, C = n * size, comp_total
         own = own_bytes(N, C)
-        traffic = hbm_traffic(n, size)
+        traffic = hbm_traffic("headline") if (n, size, args.level) == (4096, 1 << 20, 1) and args.foreign is None else {}
 
         def roof(nbytes, ms, name=None):
             a = nbytes / (ms * 1e-3)

@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
-"""HBM traffic per kernel launch from two rocprofv3 PMC passes of `python bench.py ...`
-(one with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE: they do not fit one pass on gfx950).
+"""HBM traffic per kernel launch from two rocprofv3 PMC passes of one command (one with
+--pmc FETCH_SIZE, one with --pmc WRITE_SIZE: they do not fit one pass on gfx950), merged into
+profiles/hbm_traffic.json under a workload key -- the headline step and BASELINE configs 2-5 each
+have their own pair of passes (tools/prof/pmc_passes.sh):
 
-    python tools/pmc_traffic.py fetch_results.db write_results.db --buffers 4096 --size 1048576 \
-        > profiles/hbm_traffic.json
+    python tools/pmc_traffic.py fetch_results.db write_results.db --workload headline \
+        --known-bytes 4294967296 --merge-into gpurun_out/hbm_traffic.json
 
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md "HBM" prescribes:
 FETCH_SIZE / WRITE_SIZE count KiB at the L2's memory side; on gfx950 FETCH_SIZE reports
-half the bytes of a wide (16 B/lane) coalesced read stream.  The factor is calibrated here
-on zh_checksum_pieces_kernel, which reads every input byte exactly once with dwordx4 loads
-(known byte count = buffers x size); narrower patterns are reported with the same factor
-and flagged as uncalibrated.
+half the bytes of a wide (16 B/lane) coalesced read stream.  The factor is calibrated on
+zh_checksum_pieces_kernel, which reads every input byte exactly once with dwordx4 loads
+(--known-bytes = what one launch of it reads in this command); narrower patterns are reported
+with the same factor and flagged as uncalibrated.  A workload whose command gives no clean
+calibration (--known-bytes 0) takes the factor the file already holds for "headline".
 """
 import argparse
 import json
@@ -38,21 +41,35 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("fetch_db")
     ap.add_argument("write_db")
-    ap.add_argument("--buffers", type=int, required=True)
-    ap.add_argument("--size", type=int, required=True)
+    ap.add_argument("--workload", required=True, help="key in the file: headline, c2, c3_zlib6, c4_share, c5, ...")
+    ap.add_argument("--known-bytes", type=int, default=0,
+                    help="bytes ONE launch of zh_checksum_pieces_kernel reads in this command (0: no calibration here)")
+    ap.add_argument("--command", default="", help="the profiled command, for the record")
+    ap.add_argument("--merge-into", required=True)
     a = ap.parse_args()
+    from bench import source_sha
     fetch = per_kernel(a.fetch_db, "FETCH_SIZE")
     write = per_kernel(a.write_db, "WRITE_SIZE")
-    known = a.buffers * a.size
+    try:
+        with open(a.merge_into) as fh:
+            doc = json.load(fh)
+        if doc.get("source_sha") != source_sha() or "workloads" not in doc:
+            doc = None  # other sources (or the old single-workload layout): start over
+    except (OSError, ValueError):
+        doc = None
+    if doc is None:
+        doc = {"source_sha": source_sha(),  # bench.py quotes these numbers only while the kernel sources are the ones measured
+               "calibration": "zh_checksum_pieces_kernel reads a known number of bytes once (dwordx4, coalesced)",
+               "note": "FETCH corrected by the dwordx4-stream factor (an upper bound for narrow gathers, whose requests are "
+                       "64 B and counted as such); WRITE_SIZE as reported (uncalibrated)",
+               "workloads": {}}
     calls, kib = fetch.get("zh_checksum_pieces_kernel", (0, 0))
-    factor = known / (kib * 1024.0 / calls) if calls and kib else 2.0
-    from bench import source_sha
-    out = {"buffers": a.buffers, "buffer_bytes": a.size,
-           # bench.py quotes these numbers only while the kernel sources are the ones measured
-           "source_sha": source_sha(),
-           "fetch_correction_factor": round(factor, 4),
-           "calibration": "zh_checksum_pieces_kernel reads buffers x size bytes once (dwordx4, coalesced)",
-           "kernels": {}}
+    if a.known_bytes and calls and kib:
+        factor, calibrated = a.known_bytes / (kib * 1024.0 / calls), True
+    else:
+        factor = doc["workloads"].get("headline", {}).get("fetch_correction_factor", 2.0)
+        calibrated = False
+    w = {"command": a.command, "fetch_correction_factor": round(factor, 4), "calibrated_here": calibrated, "kernels": {}}
     for name in sorted(set(fetch) | set(write)):
         if not name.startswith("zh_"):
             continue
@@ -60,15 +77,19 @@ def main():
         wc, wk = write.get(name, (0, 0))
         fb = fk * 1024.0 / fc * factor if fc else 0.0
         wb = wk * 1024.0 / wc if wc else 0.0
-        out["kernels"][name] = {
+        w["kernels"][name] = {
+            "launches": fc or wc,
             "fetch_kib_raw_per_launch": round(fk / fc, 1) if fc else 0,
             "write_kib_raw_per_launch": round(wk / wc, 1) if wc else 0,
             "hbm_bytes_per_launch": int(fb + wb),
             "hbm_bytes_per_launch_uncorrected": int((fk * 1024.0 / fc if fc else 0.0) + wb),
-            "note": "FETCH corrected by the dwordx4-stream factor (an upper bound for narrow gathers, whose "
-                    "requests are 64 B and counted as such); WRITE_SIZE as reported (uncalibrated)",
         }
-    print(json.dumps(out, indent=1))
+    doc["workloads"][a.workload] = w
+    with open(a.merge_into, "w") as fh:
+        json.dump(doc, fh, indent=1)
+    dom = sorted(w["kernels"].items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:4]
+    print(a.workload, "factor %.3f%s" % (factor, "" if calibrated else " (headline's)"),
+          {k: round(v["hbm_bytes_per_launch"] / 1e9, 3) for k, v in dom})
 
 
 if __name__ == "__main__":

@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_bench.json (BASELINE metric + configs 2-5 + the parallel-parse leg + cpu_baseline),
 #    _c4.json / _c4share.json (DefaultCompression, whole batch on one GPU / 512 x 1 MiB), _share512.json (one GPU's share of eight),
 #    _kernel_stats.csv (rocprofv3 --kernel-trace --stats of the bench command), _pytest_gpu.log,
-#    _host_api*.json, _single_call.json, _one_stream.json, _fuzz*.log, hbm_traffic.json (two --pmc passes)
+#    _host_api*.json, _single_call.json, _one_stream.json, _fuzz*.log, hbm_traffic.json (tools/prof/pmc_passes.sh: two --pmc passes a workload)
 R=$(pwd); T=${1:-r03}
 O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
@@ -25,11 +25,9 @@ timeout 900 python tools/gpu_fuzz_chain.py 600 20 2>&1 | tail -2 > $O/${T}_fuzz_
 (timeout 900 python tools/gpu_fuzz.py --mutations 10000 2>&1 | tail -3; timeout 900 python tools/gpu_fuzz.py --seg-mutations 4000 2>&1 | tail -2) > $O/${T}_fuzz_damaged.log 2>&1
 timeout 300 python tools/kprof.py --l1-parse 1 --buffers 1024 2>&1 | head -13 > $O/${T}_kprof_l1p.txt
 cd /tmp
-rm -rf /tmp/kt /tmp/pf /tmp/pw
+rm -rf /tmp/kt
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $O/${T}_rocprof_bench.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o pf -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-configs > /dev/null 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o pw -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-configs > /dev/null 2>&1
 cd $R
 python tools/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) > $O/${T}_kernel_stats.csv 2>$O/${T}_summary.err
-python tools/pmc_traffic.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) --buffers 4096 --size 1048576 > $O/hbm_traffic.json 2>>$O/${T}_summary.err
+bash tools/prof/pmc_passes.sh > $O/${T}_pmc.log 2>&1   # -> gpurun_out/hbm_traffic.json: the headline and configs 2-5, a pair of PMC passes each
 tail -2 $O/${T}_pytest_gpu.log; for f in bench c4 share512; do echo "== $f"; cut -c1-600 $O/${T}_$f.json; done; head -14 $O/${T}_kernel_stats.csv

@@ -49,6 +49,11 @@
 
 #include "zh_common.h"
 #include "zh_kprof.h"
+#ifdef ZH_KPROF_HDR
+#define KPROF_HDR_MARK(i) KPROF_MARK(i)
+#else
+#define KPROF_HDR_MARK(i) ((void)0)
+#endif
 #include "zh_tables.h"
 #include "zh_inflate_tables.h"
 
@@ -294,6 +299,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
     __syncthreads();
     for (uint32_t i = tid; i < kHeaderWords; i += kSplitThreads) s_in[i] = load_dword((hbase + i) * 4);
     __syncthreads();
+    KPROF_HDR_MARK(1);  // (-DZH_KPROF_HDR: the header's phases in slots 1 / 3 / 0 -- staged, lengths read, tables built)
     if (tid < 64) {
       uint64_t bp = pos & 31u;  // relative to hbase * 32
       uint64_t hb = 0;
@@ -432,6 +438,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
       }
     }
     __syncthreads();
+    KPROF_HDR_MARK(3);
     hdr_st = s_c_st;
     if (hdr_st == (uint32_t)ZH_OK && s_c_btype != 0u) {
       // the decode tables, by everybody (the staged header is done with: its bytes behind the first 320 words are scratch)
@@ -613,7 +620,11 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
                                    ? (uint32_t)(end_bit - base_bit < 0xfffffff0ull ? end_bit - base_bit : 0xfffffff0ull)
                                    : 0u;
       __syncthreads();
+#ifdef ZH_KPROF_HDR
+      KPROF_MARK(2);
+#else
       KPROF_MARK(1);
+#endif
       KPROF_COUNT(5, 1);
       const uint32_t limit = kSeg && tid == cut_t ? cut_rel : (tid + 1u) * kSubBits;
       uint32_t my_start = tid == 0 ? rel0 : (kSeg && tid > cut_t ? kNoStart : tid * kSubBits);
@@ -747,7 +758,11 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
         st = ZH_ERR_DST_TOO_SMALL;
         break;
       }
+#ifdef ZH_KPROF_HDR
+      KPROF_MARK(2);
+#else
       KPROF_MARK(3);
+#endif
       // (parking every run's records in HBM and copying them into place here was tried: the
       // scattered 4-byte stores of the speculative turns cost more than this second decode)
       uint32_t made = 0;
