@@ -380,6 +380,13 @@ const void *zh_tar_data(const zh_tar_reader *reader, size_t *len);
  * library-allocated (zh_free). */
 int zh_debug_tokens(zh_ctx *ctx, const void *src, size_t len, int level, uint16_t **tokens,
                     size_t *num_tokens);
+/* Debug hook: ONE prefix code from a histogram of num_freq <= 288 symbols (deflate.nim:13-151 huffmanCodes:
+ * min_codes as the reference's minCodes, limit <= 15 bits).  contract 0: the replay of the reference (its heap
+ * order, its length limiting) -- the tests hold it against the oracle symbol for symbol; 1: contract mode's
+ * builder (zh_set_l1_parse(ctx, 1)) -- an optimal code with other tie-breaks.  codes (bit-reversed, as they
+ * go into the stream) and lens hold num_freq + 2 entries; *num_codes is the reference's numCodes. */
+int zh_debug_huffman(zh_ctx *ctx, const uint32_t *freq, int num_freq, int min_codes, int limit, int contract,
+                     uint16_t *codes, uint8_t *lens, int *num_codes);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,83 @@ def check_parallel_parse(eng, inputs, formats=(oracle.dfGzip,), margin=1.02):
     return dev, ref
 
 
+def huffman_histograms():
+    """Histograms for the code builders: random and skewed ones, Fibonacci frequencies (a tree deeper than any
+    limit), one / two / no symbols used, equal frequencies (ties everywhere), the three alphabets' sizes."""
+    rnd = random.Random(31)
+    out = []
+    fib = [1, 1]
+    while len(fib) < 40:
+        fib.append(fib[-1] + fib[-2])
+    for n, minc, limit in ((286, 257, 15), (30, 2, 15), (19, 19, 7)):
+        out.append((np.zeros(n, np.uint32), minc, limit))
+        for k in (0, 3, n - 1):
+            f = np.zeros(n, np.uint32)
+            f[k] = 5
+            out.append((f, minc, limit))
+        f = np.zeros(n, np.uint32)
+        f[1] = f[n - 2] = 7
+        out.append((f, minc, limit))
+        out.append((np.full(n, 3, np.uint32), minc, limit))
+        out.append((np.arange(1, n + 1, dtype=np.uint32), minc, limit))
+        m = min(n, 34)
+        f = np.zeros(n, np.uint32)
+        order = list(range(n))
+        rnd.shuffle(order)
+        for i in range(m):
+            f[order[i]] = fib[i]
+        out.append((f, minc, limit))
+        for _ in range(12):
+            used = rnd.randrange(2, n + 1)
+            f = np.zeros(n, np.uint32)
+            for i in rnd.sample(range(n), used):
+                f[i] = max(1, int(rnd.expovariate(1.0 / rnd.choice((2, 50, 5000, 400000)))))
+            out.append((f, minc, limit))
+    return out
+
+
+def check_huffman_builders(eng):
+    """zh_debug_huffman: the byte-identical builder gives the oracle's huffmanCodes symbol for symbol (codes and
+    lengths); contract mode's gives a complete prefix code within the limit whose payload is the optimum's where
+    no length had to be cut (= the oracle's cost there) and within 1 % + 16 bits of the oracle's where some had."""
+    for f, minc, limit in huffman_histograms():
+        want_codes, want_lens = oracle.huffman_codes(f, minc, limit)
+        codes, lens = eng.debug_huffman(f, minc, limit, contract=False)
+        assert list(lens) == list(want_lens) and list(codes) == list(want_codes), (len(f), limit, "exact builder")
+        codes, lens = eng.debug_huffman(f, minc, limit, contract=True)
+        assert len(lens) == len(want_lens), (len(f), limit)
+        used = [i for i in range(len(f)) if f[i]]
+        if len(used) >= 2:
+            assert all(1 <= lens[i] <= limit for i in used) and all(lens[i] == 0 for i in range(len(lens)) if i >= len(f) or not f[i])
+            assert sum(2.0 ** -int(lens[i]) for i in used) == 1.0, "not a complete prefix code"
+            seen = set()
+            for i in used:  # canonical, bit-reversed: no code is another's prefix (read first bit first)
+                bits = format(int(codes[i]), "0%db" % lens[i])[::-1]
+                assert all(bits[:k] not in seen for k in range(1, len(bits) + 1)), "prefix clash"
+                seen.add(bits)
+            cost = sum(int(f[i]) * int(lens[i]) for i in used)
+            ref = sum(int(f[i]) * int(want_lens[i]) for i in used)
+            unlimited = _huffman_cost(f)
+            if max(int(lens[i]) for i in used) < limit and max(int(want_lens[i]) for i in used) < limit:
+                assert cost == unlimited == ref, (cost, unlimited, ref)
+            else:
+                assert unlimited <= cost <= ref * 1.01 + 16, (cost, ref, unlimited)
+        else:
+            assert list(lens) == list(want_lens), "special cases as deflate.nim:34-45"
+
+
+def _huffman_cost(f):
+    import heapq
+    h = [int(x) for x in f if x]
+    heapq.heapify(h)
+    cost = 0
+    while len(h) > 1:
+        a, b = heapq.heappop(h), heapq.heappop(h)
+        cost += a + b
+        heapq.heappush(h, a + b)
+    return cost
+
+
 def wide_length_count_input():
     """deflate.nim:136-139 counts the symbols of a code length in a uint8, which
     wraps when 256 or more share one length.  3000 bytes at level -2 (Huffman only, no stored

@@ -184,6 +184,10 @@ def test_emu_parallel_parse_contract(eng):
     pc.check_parallel_parse(eng, inputs, formats=(oracle.dfGzip, oracle.dfDeflate))
 
 
+def test_emu_huffman_builders(eng):
+    pc.check_huffman_builders(eng)
+
+
 def test_emu_wide_code_length_counts(eng):
     pc.check_wide_code_length_counts(eng)
 

@@ -138,6 +138,10 @@ def test_gpu_parallel_parse_contract(eng, golds):
         print("parallel parse, %s: %d B against the oracle's %d B (%.4f)" % (kind, dev, ref, dev / ref))
 
 
+def test_gpu_huffman_builders(eng):
+    pc.check_huffman_builders(eng)
+
+
 def test_gpu_wide_code_length_counts(eng):
     """256 symbols of one code length (deflate.nim:136-139 would wrap its uint8 count)."""
     pc.check_wide_code_length_counts(eng)

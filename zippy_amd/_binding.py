@@ -116,6 +116,8 @@ _SIGS = {
     "zh_tar_data": (_c.c_void_p, [_c.c_void_p, _c.POINTER(_c.c_size_t)]),
     "zh_debug_tokens": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int,
                                    _c.POINTER(_c.POINTER(_c.c_uint16)), _c.POINTER(_c.c_size_t)]),
+    "zh_debug_huffman": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                    _c.POINTER(_c.c_uint16), _c.POINTER(_c.c_uint8), _c.POINTER(_c.c_int)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)  # every entry point include/zippy_hip.h declares
@@ -413,6 +415,18 @@ class Engine:
     def uncompress(self, src, data_format=dfDetect):
         outs, sts = self.uncompress_batch([src], data_format)
         return self._raise_first(outs, sts)[0]
+
+    def debug_huffman(self, freq, min_codes, limit, contract=False):
+        """One prefix code from a histogram, by the byte-identical builder or by contract mode's
+        (zh_debug_huffman) -> (codes, lens) as numpy arrays of numCodes entries."""
+        import numpy as np
+        f = np.ascontiguousarray(freq, dtype=np.uint32)
+        codes = (_c.c_uint16 * (len(f) + 2))()
+        lens = (_c.c_uint8 * (len(f) + 2))()
+        n = _c.c_int()
+        self._check(self.lib.zh_debug_huffman(self._h, f.ctypes.data_as(_c.POINTER(_c.c_uint32)), len(f), min_codes, limit,
+                                              1 if contract else 0, codes, lens, _c.byref(n)))
+        return np.array(codes[:n.value], dtype=np.uint16), np.array(lens[:n.value], dtype=np.uint8)
 
     # ---- ZIP archives (ziparchives.nim) ----
     def open_zip(self, image):

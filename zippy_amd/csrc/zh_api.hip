@@ -61,7 +61,9 @@ void zh_launch_chain_search(hipStream_t, const uint8_t* d_src, ZhCompressArgs a,
 void zh_launch_chain_select(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
                             int max_chain, const uint64_t* prevw, uint32_t* best);
 void zh_launch_frag_stats(hipStream_t, const uint8_t* d_src, ZhCompressArgs a);
-void zh_launch_huffman(hipStream_t, ZhCompressArgs a);
+void zh_launch_huffman(hipStream_t, ZhCompressArgs a, int contract);
+void zh_launch_huffman_probe(hipStream_t, const uint32_t* freq, int num_freq, int min_codes, int limit, int contract,
+                             uint16_t* codes, uint8_t* lens, int* n_out);
 void zh_launch_layout(hipStream_t, uint8_t* d_dst, ZhCompressArgs a, const uint32_t* buf_crc,
                       const uint32_t* buf_adler);
 void zh_launch_emit(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhCompressArgs a);
@@ -1163,7 +1165,9 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
                                  p->piece_len, want_crc, want_adler, p->buf_crc, p->buf_adler);
     }
     prof_mark(p, "zh_huffman_kernel");
-    zh_launch_huffman(s, a);
+    // (contract mode -- zh_set_l1_parse(ctx, 1), BestSpeed only -- also builds the block's codes without the
+    // replay of the reference's heap: optimal codes, other tie-breaks)
+    zh_launch_huffman(s, a, p->level == 1 && l1_parallel(ctx) ? 1 : 0);
     prof_mark(p, "zh_layout_kernel");
     zh_launch_layout(s, d_dst, a, p->buf_crc, p->buf_adler);
     prof_mark(p, "zh_emit_kernel");
@@ -2390,6 +2394,33 @@ extern "C" int zh_adler32(zh_ctx* ctx, const void* src, size_t len, uint32_t* ou
 // ---------------------------------------------------------------------------
 // parity introspection: device parse -> reference token stream
 // ---------------------------------------------------------------------------
+// Debug hook: one prefix code from a histogram -- contract 0: the replay of deflate.nim:13-151 huffmanCodes
+// (byte-identical mode), 1: the wave-parallel optimal builder of contract mode.  codes / lens: num_freq + 2 entries.
+extern "C" int zh_debug_huffman(zh_ctx* ctx, const uint32_t* freq, int num_freq, int min_codes, int limit, int contract,
+                                uint16_t* codes, uint8_t* lens, int* num_codes) {
+  if (!ctx || !freq || !codes || !lens || !num_codes || num_freq < 1 || num_freq > 288 || min_codes < 1 || min_codes > 287 ||
+      limit < 1 || limit > 15)
+    return ZH_ERR_ARGUMENT;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf d;
+  const size_t o_codes = 2048, o_lens = 4096, o_n = 5120;
+  if (dev_alloc(ctx, d, 8192) != hipSuccess) return ZH_ERR_NOMEM;
+  hipStream_t s = ctx->stream;
+  ZH_HIP(ctx, hipMemcpyAsync(d.p, freq, (size_t)num_freq * 4, hipMemcpyHostToDevice, s));
+  zh_launch_huffman_probe(s, reinterpret_cast<const uint32_t*>(d.p), num_freq, min_codes, limit, contract,
+                          reinterpret_cast<uint16_t*>(d.p + o_codes), d.p + o_lens, reinterpret_cast<int*>(d.p + o_n));
+  ZH_HIP(ctx, hipGetLastError());
+  int n = 0;
+  ZH_HIP(ctx, hipMemcpyAsync(&n, d.p + o_n, 4, hipMemcpyDeviceToHost, s));
+  ZH_HIP(ctx, hipStreamSynchronize(s));
+  if (n < 0 || n > 288) return ZH_ERR_COMPRESS_INTERNAL;
+  ZH_HIP(ctx, hipMemcpyAsync(codes, d.p + o_codes, (size_t)n * 2, hipMemcpyDeviceToHost, s));
+  ZH_HIP(ctx, hipMemcpyAsync(lens, d.p + o_lens, (size_t)n, hipMemcpyDeviceToHost, s));
+  ZH_HIP(ctx, hipStreamSynchronize(s));
+  *num_codes = n;
+  return ZH_OK;
+}
+
 extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int level,
                                uint16_t** tokens, size_t* num_tokens) {
   if (!ctx || !tokens || !num_tokens || (len && !src)) return ZH_ERR_ARGUMENT;

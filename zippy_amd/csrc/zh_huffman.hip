@@ -226,6 +226,207 @@ __device__ int huffman_codes(const uint32_t* freq, int num_freq, int min_codes, 
   return num_codes;
 }
 
+
+// ---------------------------------------------------------------------------
+// Contract mode (zh_set_l1_parse(ctx, 1): valid streams of about the reference's size, not its bytes): an
+// optimal length-limited prefix code WITHOUT the replay of Nim's heapqueue (above: ~ 70 dependent LDS trips a
+// symbol for the sake of its tie-breaks, 1.2 ms a block on one lane).  Any optimal code costs the same payload
+// bits, so: the used symbols are ranked by (frequency, symbol) by the whole wave, one lane merges them with the
+// two-queue method (leaves and internal nodes both come in ascending order: no heap), depths come from pointer
+// doubling over the parent links, codes deeper than the limit are repaired on the histogram of lengths the way
+// miniz / zlib do (take a code from the deepest level, split the deepest shorter one) and the lengths are
+// handed out by rank -- the longest to the rarest --, canonical codes by ballots.  RFC 1951 3.2.2.
+// Same special cases as deflate.nim:34-45 (no symbol / one symbol used), same `numCodes` rule (:24-32).
+// ---------------------------------------------------------------------------
+struct FastWork {  // overlays HuffWork (5.8 KiB)
+  uint32_t lf[kMaxSyms];       // leaf frequencies, ascending
+  uint32_t nf[kMaxSyms];       // internal nodes' frequencies, in creation (= ascending) order
+  uint16_t sym_of[kMaxSyms];   // rank -> symbol
+  uint16_t rank_of[kMaxSyms];  // symbol -> rank (used symbols)
+  uint16_t par[2 * kMaxSyms];  // node -> parent (leaves 0 .. n-1 by rank, internal nodes n .. 2n-2)
+  uint16_t dep[2 * kMaxSyms];  // node -> depth
+};
+static_assert(sizeof(FastWork) <= sizeof(HuffWork) + 0, "FastWork lives in HuffWork's bytes");
+
+// every lane of the wave; freq / codes / lens in LDS.  Returns the number of codes.
+__device__ int huffman_codes_fast(const uint32_t* freq, int num_freq, int min_codes, int limit, uint16_t* codes,
+                                  uint8_t* lens, FastWork& w, uint32_t* s_num) {
+  const unsigned lane = zh_lane();
+  constexpr int kPer = (kMaxSyms + 63) / 64;  // symbols a lane: lane, lane + 64, ...
+  // ---- used symbols, the highest of them ----
+  uint32_t f[kPer];
+  int highest = 0, used = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int sidx = (int)lane + 64 * k;
+    f[k] = sidx < num_freq ? freq[sidx] : 0u;
+    const uint64_t m = __ballot(f[k] != 0u);
+    used += __popcll(m);
+    if (m) highest = 64 * k + 63 - __clzll((long long)m);
+  }
+  const int num_codes = (highest > min_codes ? highest : min_codes) + 1;
+  for (int i = (int)lane; i < num_codes; i += 64) {
+    codes[i] = 0;
+    lens[i] = 0;
+  }
+  zh_wave_sync();
+  if (used <= 1) {  // deflate.nim:34-45
+    if (lane == 0) {
+      if (used == 0) {
+        lens[0] = 1;
+        lens[1] = 1;
+      } else {
+        lens[highest] = 1;
+        lens[highest == 0 ? 1 : 0] = 1;
+      }
+    }
+  } else {
+    const int n = used;
+    // ---- rank by (frequency, symbol): how many used symbols come before mine ----
+    uint32_t rk[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; k++) rk[k] = 0;
+    for (int j = 0; j < num_freq; j++) {
+      const uint32_t fj = freq[j];  // (one address for the wave: a broadcast)
+      if (fj == 0u) continue;
+#pragma unroll
+      for (int k = 0; k < kPer; k++) {
+        const int sidx = (int)lane + 64 * k;
+        rk[k] += (fj < f[k] || (fj == f[k] && j < sidx)) ? 1u : 0u;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int sidx = (int)lane + 64 * k;
+      if (f[k]) {
+        w.lf[rk[k]] = f[k];
+        w.sym_of[rk[k]] = (uint16_t)sidx;
+        w.rank_of[sidx] = (uint16_t)rk[k];
+      }
+    }
+    zh_wave_sync();
+    // ---- two-queue merge (one lane): the two smallest of {next leaves, next internal nodes}, n - 1 times ----
+    if (lane == 0) {
+      int i = 0, j = 0;  // next leaf, next internal node
+      for (int m = 0; m < n - 1; m++) {
+        uint32_t sum = 0;
+        for (int t = 0; t < 2; t++) {
+          const bool leaf = i < n && (j >= m || w.lf[i] <= w.nf[j]);
+          if (leaf) {
+            sum += w.lf[i];
+            w.par[i] = (uint16_t)(n + m);
+            i++;
+          } else {
+            sum += w.nf[j];
+            w.par[n + j] = (uint16_t)(n + m);
+            j++;
+          }
+        }
+        w.nf[m] = sum;
+      }
+      w.par[2 * n - 2] = (uint16_t)(2 * n - 2);  // the root
+    }
+    zh_wave_sync();
+    // ---- depths: dep += dep[par], par = par[par] until every node hangs on the root ----
+    const int nodes = 2 * n - 1;
+    for (int v = (int)lane; v < nodes; v += 64) w.dep[v] = v == nodes - 1 ? 0 : 1;
+    zh_wave_sync();
+    constexpr int kNodesPer = (2 * kMaxSyms + 63) / 64;
+    for (;;) {
+      uint32_t p1[kNodesPer], d1[kNodesPer], p2[kNodesPer], d2[kNodesPer];
+      bool moved = false;
+#pragma unroll
+      for (int k = 0; k < kNodesPer; k++) {
+        const int v = (int)lane + 64 * k;
+        if (v < nodes) {
+          p1[k] = w.par[v];
+          d1[k] = w.dep[v];
+          p2[k] = w.par[p1[k]];
+          d2[k] = w.dep[p1[k]];
+        }
+      }
+      zh_wave_sync();  // (every lane has read before any lane writes)
+#pragma unroll
+      for (int k = 0; k < kNodesPer; k++) {
+        const int v = (int)lane + 64 * k;
+        if (v < nodes && p1[k] != (uint32_t)(nodes - 1) && p1[k] != (uint32_t)v) {
+          w.dep[v] = (uint16_t)(d1[k] + d2[k]);
+          w.par[v] = (uint16_t)p2[k];
+          moved = true;
+        }
+      }
+      zh_wave_sync();
+      if (!__ballot(moved)) break;
+    }
+    // ---- histogram of the leaves' depths, everything deeper than the limit counted at the limit ----
+    if (lane < 32) s_num[lane] = 0;
+    zh_wave_sync();
+    for (int v = (int)lane; v < n; v += 64) {
+      const uint32_t d = w.dep[v];
+      atomicAdd(&s_num[d < (uint32_t)limit ? d : (uint32_t)limit], 1u);
+    }
+    zh_wave_sync();
+    // lane L holds num[L]; Kraft sum in units of 2^-limit
+    uint32_t num = lane >= 1 && (int)lane <= limit ? s_num[lane] : 0u;
+    uint32_t total = zh_wave_sum(lane >= 1 && (int)lane <= limit ? num << (limit - (int)lane) : 0u);
+    while (total > (1u << limit)) {  // over-subscribed: a code leaves the deepest level, the deepest shorter code splits
+      const uint64_t have = __ballot(num != 0u) & ((1ull << limit) - 2ull);  // levels 1 .. limit - 1 in use
+      const int i = 63 - __clzll((long long)have);                           // (there is one: total > 2^limit)
+      if ((int)lane == limit) num -= 1u;
+      if ((int)lane == i) num -= 1u;
+      if ((int)lane == i + 1) num += 2u;
+      total--;
+    }
+    // ---- lengths by rank: the num[1] most frequent symbols get one bit, the next num[2] two, ... ----
+    const uint32_t incl = zh_wave_scan(num);  // lane L: symbols with at most L bits
+    uint32_t le[16];
+#pragma unroll
+    for (int L = 1; L < 16; L++) le[L] = (uint32_t)__builtin_amdgcn_readlane((int)incl, L);
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int sidx = (int)lane + 64 * k;
+      if (f[k]) {
+        const uint32_t desc = (uint32_t)(n - 1) - rk[k];  // 0: the most frequent symbol
+        uint32_t L = 1;
+#pragma unroll
+        for (int q = 1; q < 15; q++) L += desc >= le[q] ? 1u : 0u;
+        lens[sidx] = (uint8_t)L;
+      }
+    }
+  }
+  zh_wave_sync();
+  // ---- canonical codes, bit-reversed (deflate.nim:136-149), symbols of one length in symbol order ----
+  uint32_t l[kPer], hist[16];
+#pragma unroll
+  for (int L = 0; L < 16; L++) hist[L] = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int sidx = (int)lane + 64 * k;
+    l[k] = sidx < num_codes ? lens[sidx] : 0u;
+#pragma unroll
+    for (int L = 1; L < 16; L++) hist[L] += (uint32_t)__popcll(__ballot(l[k] == (uint32_t)L));
+  }
+  uint32_t next_code[16];
+  next_code[0] = 0;
+  hist[0] = 0;
+#pragma unroll
+  for (int L = 1; L < 16; L++) next_code[L] = (next_code[L - 1] + hist[L - 1]) << 1;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int sidx = (int)lane + 64 * k;
+    uint32_t c = 0;
+#pragma unroll
+    for (int L = 1; L < 16; L++) {
+      const uint64_t m = __ballot(l[k] == (uint32_t)L);
+      if (l[k] == (uint32_t)L) c = next_code[L] + (uint32_t)__popcll(m & zh_lanemask_lt());
+      next_code[L] += (uint32_t)__popcll(m);
+    }
+    if (l[k]) codes[sidx] = (uint16_t)(rev16(c & 0xffffu) >> (16 - l[k]));
+  }
+  zh_wave_sync();
+  return num_codes;
+}
+
 struct HdrWriter {
   uint32_t* words;
   uint32_t bits;
@@ -254,7 +455,9 @@ __device__ inline void or_byte(uint8_t* base, uint64_t byte_pos, uint32_t v) {
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
+// `contract`: the block's three codes by huffman_codes_fast (optimal codes, not the reference's tie-breaks:
+// zh_set_l1_parse(ctx, 1)); 0: by the replay of deflate.nim:13-151, byte-identical.
+__global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a, int contract) {
   __shared__ uint32_t s_freq[ZH_HIST_STRIDE];
   __shared__ HuffWork s_work;
   __shared__ uint16_t s_codes[ZH_HIST_STRIDE];  // litlen at 0, distance at 288
@@ -263,12 +466,17 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   __shared__ uint8_t s_rle[704];
   __shared__ uint32_t s_hdr[ZH_HDR_WORDS];
   __shared__ uint32_t s_mode, s_hdr_bits;
+  __shared__ uint32_t s_clfreq[32], s_num[32];  // the code-length alphabet's histogram; the fast builder's length counts
+  __shared__ uint16_t s_clcodes[20];
+  __shared__ uint8_t s_cllens[20];
+  __shared__ int s_n[3];  // litlen codes, distance codes, run-length items
 
   const unsigned lane = zh_lane();
   KPROF_DECL(8);
   const uint32_t b = blockIdx.x;
   const ZhBlockDesc bd = a.blocks[b];
   const int level = a.level;
+  FastWork& fwork = *reinterpret_cast<FastWork*>(&s_work);
 
   // ---- block histogram = sum of the fragment histograms (BlockMetadata) ----
   uint32_t nlit = 0;
@@ -288,6 +496,7 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   zh_wave_sync();
   KPROF_MARK(0);
 
+  HdrWriter h{s_hdr, 0};
   if (lane == 0) {
     uint32_t mode;
     if (level == 0 ||
@@ -299,7 +508,6 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
       mode = ZH_MODE_DYNAMIC;
     }
     s_mode = mode;
-    HdrWriter h{s_hdr, 0};
     if (mode == ZH_MODE_FIXED) {  // internal.nim:151-175
       for (int i = 0; i < 288; i++) s_lens[i] = (uint8_t)(i <= 143 ? 8 : i <= 255 ? 9 : i <= 279 ? 7 : 8);
       for (int i = 0; i < 30; i++) s_lens[288 + i] = 5;
@@ -312,12 +520,29 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
       for (int i = 0; i < 30; i++) s_codes[288 + i] = (uint16_t)(rev16((uint32_t)i) >> 11);
       hdr_add(h, bd.is_final ? 1 : 0, 1);  // deflate.nim:296-298
       hdr_add(h, 1, 2);
-    } else if (mode == ZH_MODE_DYNAMIC) {
-      const int n_litlen = huffman_codes(s_freq, ZH_NUM_LITLEN, 257, 15, s_codes, s_lens, s_work);
+    }
+  }
+  zh_wave_sync();
+  if (s_mode == ZH_MODE_DYNAMIC) {
+    // ---- the literal / length and the distance code ----
+    if (contract) {
+      const int nl = huffman_codes_fast(s_freq, ZH_NUM_LITLEN, 257, 15, s_codes, s_lens, fwork, s_num);
       KPROF_MARK(1);
-      const int n_dist = huffman_codes(s_freq + ZH_NUM_LITLEN, ZH_NUM_DIST, 2, 15, s_codes + 288,
-                                       s_lens + 288, s_work);
+      const int nd = huffman_codes_fast(s_freq + ZH_NUM_LITLEN, ZH_NUM_DIST, 2, 15, s_codes + 288, s_lens + 288, fwork, s_num);
       KPROF_MARK(2);
+      if (lane == 0) {
+        s_n[0] = nl;
+        s_n[1] = nd;
+      }
+    } else if (lane == 0) {
+      s_n[0] = huffman_codes(s_freq, ZH_NUM_LITLEN, 257, 15, s_codes, s_lens, s_work);
+      KPROF_MARK(1);
+      s_n[1] = huffman_codes(s_freq + ZH_NUM_LITLEN, ZH_NUM_DIST, 2, 15, s_codes + 288, s_lens + 288, s_work);
+      KPROF_MARK(2);
+    }
+    zh_wave_sync();
+    const int n_litlen = s_n[0], n_dist = s_n[1];
+    if (lane == 0) {
       const int num_codes = n_litlen + n_dist;
       for (int i = 0; i < n_litlen; i++) s_cl_all[i] = s_lens[i];
       for (int i = 0; i < n_dist; i++) s_cl_all[n_litlen + i] = s_lens[288 + i];
@@ -359,18 +584,34 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
           i++;
         }
       }
+      s_n[2] = rle_len;
       KPROF_MARK(3);
-      uint32_t cl_freq[19];
-      for (int i = 0; i < 19; i++) cl_freq[i] = 0;
+      for (int i = 0; i < 19; i++) s_clfreq[i] = 0;
       for (int i = 0; i < rle_len; i++) {  // deflate.nim:352-360
-        cl_freq[s_rle[i]]++;
+        s_clfreq[s_rle[i]]++;
         if (s_rle[i] >= 16) i++;
       }
+    }
+    zh_wave_sync();
+    // ---- the code of the code lengths (deflate.nim:362) ----
+    if (contract) {
+      huffman_codes_fast(s_clfreq, 19, 19, 7, s_clcodes, s_cllens, fwork, s_num);
+    } else if (lane == 0) {
+      uint32_t cl_freq[19];
+      for (int i = 0; i < 19; i++) cl_freq[i] = s_clfreq[i];
       uint16_t cl_codes[20];
       uint8_t cl_lens[20];
-      huffman_codes(cl_freq, 19, 19, 7, cl_codes, cl_lens, s_work);  // deflate.nim:362
+      huffman_codes(cl_freq, 19, 19, 7, cl_codes, cl_lens, s_work);
+      for (int i = 0; i < 20; i++) {
+        s_clcodes[i] = cl_codes[i];
+        s_cllens[i] = cl_lens[i];
+      }
+    }
+    zh_wave_sync();
+    if (lane == 0) {
+      const int rle_len = s_n[2];
       uint32_t clcl_ordered[19];
-      for (int i = 0; i < 19; i++) clcl_ordered[i] = cl_lens[c_clcl_order[i]];
+      for (int i = 0; i < 19; i++) clcl_ordered[i] = s_cllens[c_clcl_order[i]];
       int hclen = 19;
       while (clcl_ordered[hclen - 1] == 0) hclen--;
       hclen -= 4;
@@ -383,14 +624,14 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
       for (int i = 0; i < hclen + 4; i++) hdr_add(h, clcl_ordered[i], 3);
       for (int i = 0; i < rle_len;) {  // deflate.nim:388-401
         const uint32_t sym = s_rle[i++];
-        hdr_add(h, cl_codes[sym], cl_lens[sym]);
+        hdr_add(h, s_clcodes[sym], s_cllens[sym]);
         if (sym == 16) hdr_add(h, s_rle[i++], 2);
         else if (sym == 17) hdr_add(h, s_rle[i++], 3);
         else if (sym == 18) hdr_add(h, s_rle[i++], 7);
       }
     }
-    s_hdr_bits = h.bits;
   }
+  if (lane == 0) s_hdr_bits = h.bits;
   zh_wave_sync();
   KPROF_MARK(5);
 
@@ -571,9 +812,46 @@ __global__ __launch_bounds__(64) void zh_block_layout_kernel(uint8_t* __restrict
   if (lane == 0) or_bits(out, body_bit0 + cursor, eob & 0xffffu, eob >> 16);  // deflate.nim:471
 }
 
-extern "C" void zh_launch_huffman(hipStream_t stream, ZhCompressArgs a) {
+// zh_debug_huffman: one code from a histogram, by either builder (the tests hold the exact one against the oracle's
+// huffmanCodes symbol for symbol, the fast one against the optimum's cost and the prefix-code conditions)
+__global__ __launch_bounds__(64) void zh_huffman_probe_kernel(const uint32_t* __restrict__ freq, int num_freq, int min_codes,
+                                                              int limit, int contract, uint16_t* __restrict__ codes,
+                                                              uint8_t* __restrict__ lens, int* __restrict__ n_out) {
+  __shared__ uint32_t s_freq[ZH_HIST_STRIDE];
+  __shared__ HuffWork s_work;
+  __shared__ uint16_t s_codes[ZH_HIST_STRIDE];
+  __shared__ uint8_t s_lens[ZH_HIST_STRIDE];
+  __shared__ uint32_t s_num[32];
+  __shared__ int s_n;
+  const unsigned lane = zh_lane();
+  for (int i = (int)lane; i < (int)ZH_HIST_STRIDE; i += 64) {
+    s_freq[i] = i < num_freq ? freq[i] : 0u;
+    s_codes[i] = 0;
+    s_lens[i] = 0;
+  }
+  zh_wave_sync();
+  if (contract) {
+    const int n = huffman_codes_fast(s_freq, num_freq, min_codes, limit, s_codes, s_lens, *reinterpret_cast<FastWork*>(&s_work), s_num);
+    if (lane == 0) s_n = n;
+  } else if (lane == 0) {
+    s_n = huffman_codes(s_freq, num_freq, min_codes, limit, s_codes, s_lens, s_work);
+  }
+  zh_wave_sync();
+  const int n = s_n;
+  for (int i = (int)lane; i < n; i += 64) {
+    codes[i] = s_codes[i];
+    lens[i] = s_lens[i];
+  }
+  if (lane == 0) *n_out = n;
+}
+extern "C" void zh_launch_huffman_probe(hipStream_t stream, const uint32_t* freq, int num_freq, int min_codes, int limit,
+                                        int contract, uint16_t* codes, uint8_t* lens, int* n_out) {
+  hipLaunchKernelGGL(zh_huffman_probe_kernel, dim3(1), dim3(64), 0, stream, freq, num_freq, min_codes, limit, contract, codes,
+                     lens, n_out);
+}
+extern "C" void zh_launch_huffman(hipStream_t stream, ZhCompressArgs a, int contract) {
   if (!a.nblocks) return;
-  hipLaunchKernelGGL(zh_huffman_kernel, dim3(a.nblocks), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(zh_huffman_kernel, dim3(a.nblocks), dim3(64), 0, stream, a, contract);
 }
 extern "C" void zh_launch_layout(hipStream_t stream, uint8_t* d_dst, ZhCompressArgs a,
                                  const uint32_t* buf_crc, const uint32_t* buf_adler) {
