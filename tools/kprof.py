@@ -47,13 +47,14 @@ def main():
     ap.add_argument("--kind", default="mix")
     ap.add_argument("--inflate", type=int, default=-1)
     ap.add_argument("--l1-parse", type=int, default=-1, help="1: the parallel BestSpeed parse (zh_l1p_match_kernel)")
+    ap.add_argument("--lib", default=None, help="another -DZH_KPROF build of the library (python -m zippy_amd.build --kprof --variant ...)")
     ap.add_argument("--foreign", type=int, default=None, help="uncompress gzip members made by system zlib at this level instead")
     args = ap.parse_args()
     import torch
     import synth
     from zippy_amd import api
     from zippy_amd._binding import Engine
-    lib_path = api.LIB_PATH.replace(".so", "_kprof.so")
+    lib_path = args.lib or api.LIB_PATH.replace(".so", "_kprof.so")
     n, size = args.buffers, args.size
     host = synth.gen_batch(args.kind, n, size)
     d_src = torch.from_numpy(host.reshape(-1)).cuda()

@@ -333,30 +333,30 @@ __device__ int huffman_codes_fast(const uint32_t* freq, int num_freq, int min_co
     zh_wave_sync();
     constexpr int kNodesPer = (2 * kMaxSyms + 63) / 64;
     for (;;) {
-      uint32_t p1[kNodesPer], d1[kNodesPer], p2[kNodesPer], d2[kNodesPer];
-      bool moved = false;
+      uint32_t np[kNodesPer], nd[kNodesPer], upd = 0;
 #pragma unroll
       for (int k = 0; k < kNodesPer; k++) {
         const int v = (int)lane + 64 * k;
         if (v < nodes) {
-          p1[k] = w.par[v];
-          d1[k] = w.dep[v];
-          p2[k] = w.par[p1[k]];
-          d2[k] = w.dep[p1[k]];
+          const uint32_t p1 = w.par[v];
+          if (p1 != (uint32_t)(nodes - 1) && p1 != (uint32_t)v) {
+            np[k] = w.par[p1];
+            nd[k] = (uint32_t)w.dep[v] + w.dep[p1];
+            upd |= 1u << k;
+          }
         }
       }
       zh_wave_sync();  // (every lane has read before any lane writes)
 #pragma unroll
       for (int k = 0; k < kNodesPer; k++) {
         const int v = (int)lane + 64 * k;
-        if (v < nodes && p1[k] != (uint32_t)(nodes - 1) && p1[k] != (uint32_t)v) {
-          w.dep[v] = (uint16_t)(d1[k] + d2[k]);
-          w.par[v] = (uint16_t)p2[k];
-          moved = true;
+        if ((upd >> k) & 1u) {
+          w.dep[v] = (uint16_t)nd[k];
+          w.par[v] = (uint16_t)np[k];
         }
       }
       zh_wave_sync();
-      if (!__ballot(moved)) break;
+      if (!__ballot(upd != 0u)) break;
     }
     // ---- histogram of the leaves' depths, everything deeper than the limit counted at the limit ----
     if (lane < 32) s_num[lane] = 0;
@@ -455,21 +455,29 @@ __device__ inline void or_byte(uint8_t* base, uint64_t byte_pos, uint32_t v) {
 
 }  // namespace
 
-// `contract`: the block's three codes by huffman_codes_fast (optimal codes, not the reference's tie-breaks:
-// zh_set_l1_parse(ctx, 1)); 0: by the replay of deflate.nim:13-151, byte-identical.
-__global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a, int contract) {
+// contract = true: the block's three codes by huffman_codes_fast (optimal codes, not the reference's tie-breaks:
+// zh_set_l1_parse(ctx, 1)); false: by the replay of deflate.nim:13-151, byte-identical.  (Two kernels: the fast
+// builder's registers would cost the replay, which needs few, a quarter of its waves.)
+template <bool contract>
+__global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   __shared__ uint32_t s_freq[ZH_HIST_STRIDE];
   __shared__ HuffWork s_work;
   __shared__ uint16_t s_codes[ZH_HIST_STRIDE];  // litlen at 0, distance at 288
   __shared__ uint8_t s_lens[ZH_HIST_STRIDE];
-  __shared__ uint8_t s_cl_all[ZH_HIST_STRIDE];
-  __shared__ uint8_t s_rle[704];
+  __shared__ __attribute__((aligned(16))) uint8_t s_cl_all[ZH_HIST_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint8_t s_rle[704];
   __shared__ uint32_t s_hdr[ZH_HDR_WORDS];
   __shared__ uint32_t s_mode, s_hdr_bits;
-  __shared__ uint32_t s_clfreq[32], s_num[32];  // the code-length alphabet's histogram; the fast builder's length counts
-  __shared__ uint16_t s_clcodes[20];
-  __shared__ uint8_t s_cllens[20];
-  __shared__ int s_n[3];  // litlen codes, distance codes, run-length items
+  // (the kernel's LDS stays under 10 KiB -- sixteen blocks a CU, 4096 blocks one round of the machine --, so the
+  // small arrays of the later stages live in bytes that are dead by then)
+  uint32_t* const s_clfreq = s_freq;        // [32] the code-length alphabet's histogram: the block's own is done with
+  uint16_t* const s_clcodes = reinterpret_cast<uint16_t*>(s_freq + 32);  // [20]
+  uint8_t* const s_cllens = reinterpret_cast<uint8_t*>(s_freq + 48);     // [20]
+  int* const s_n = reinterpret_cast<int*>(s_freq + 64);  // [3] litlen codes, distance codes, run-length items (behind the litlen build)
+  // the fast builder's length counts [32]: in the run-length items' bytes while those are not there yet, in the
+  // collected lengths' once the items are
+  uint32_t* const s_num_a = reinterpret_cast<uint32_t*>(s_rle);
+  uint32_t* const s_num_b = reinterpret_cast<uint32_t*>(s_cl_all);
 
   const unsigned lane = zh_lane();
   KPROF_DECL(8);
@@ -526,9 +534,9 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a, int co
   if (s_mode == ZH_MODE_DYNAMIC) {
     // ---- the literal / length and the distance code ----
     if (contract) {
-      const int nl = huffman_codes_fast(s_freq, ZH_NUM_LITLEN, 257, 15, s_codes, s_lens, fwork, s_num);
+      const int nl = huffman_codes_fast(s_freq, ZH_NUM_LITLEN, 257, 15, s_codes, s_lens, fwork, s_num_a);
       KPROF_MARK(1);
-      const int nd = huffman_codes_fast(s_freq + ZH_NUM_LITLEN, ZH_NUM_DIST, 2, 15, s_codes + 288, s_lens + 288, fwork, s_num);
+      const int nd = huffman_codes_fast(s_freq + ZH_NUM_LITLEN, ZH_NUM_DIST, 2, 15, s_codes + 288, s_lens + 288, fwork, s_num_a);
       KPROF_MARK(2);
       if (lane == 0) {
         s_n[0] = nl;
@@ -595,22 +603,14 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a, int co
     zh_wave_sync();
     // ---- the code of the code lengths (deflate.nim:362) ----
     if (contract) {
-      huffman_codes_fast(s_clfreq, 19, 19, 7, s_clcodes, s_cllens, fwork, s_num);
+      huffman_codes_fast(s_clfreq, 19, 19, 7, s_clcodes, s_cllens, fwork, s_num_b);
     } else if (lane == 0) {
-      uint32_t cl_freq[19];
-      for (int i = 0; i < 19; i++) cl_freq[i] = s_clfreq[i];
-      uint16_t cl_codes[20];
-      uint8_t cl_lens[20];
-      huffman_codes(cl_freq, 19, 19, 7, cl_codes, cl_lens, s_work);
-      for (int i = 0; i < 20; i++) {
-        s_clcodes[i] = cl_codes[i];
-        s_cllens[i] = cl_lens[i];
-      }
+      huffman_codes(s_clfreq, 19, 19, 7, s_clcodes, s_cllens, s_work);
     }
     zh_wave_sync();
     if (lane == 0) {
       const int rle_len = s_n[2];
-      uint32_t clcl_ordered[19];
+      uint32_t* const clcl_ordered = s_freq + 80;  // [19] (dead bytes as well)
       for (int i = 0; i < 19; i++) clcl_ordered[i] = s_cllens[c_clcl_order[i]];
       int hclen = 19;
       while (clcl_ordered[hclen - 1] == 0) hclen--;
@@ -851,7 +851,10 @@ extern "C" void zh_launch_huffman_probe(hipStream_t stream, const uint32_t* freq
 }
 extern "C" void zh_launch_huffman(hipStream_t stream, ZhCompressArgs a, int contract) {
   if (!a.nblocks) return;
-  hipLaunchKernelGGL(zh_huffman_kernel, dim3(a.nblocks), dim3(64), 0, stream, a, contract);
+  if (contract)
+    hipLaunchKernelGGL(zh_huffman_kernel<true>, dim3(a.nblocks), dim3(64), 0, stream, a);
+  else
+    hipLaunchKernelGGL(zh_huffman_kernel<false>, dim3(a.nblocks), dim3(64), 0, stream, a);
 }
 extern "C" void zh_launch_layout(hipStream_t stream, uint8_t* d_dst, ZhCompressArgs a,
                                  const uint32_t* buf_crc, const uint32_t* buf_adler) {
