@@ -307,22 +307,33 @@ __device__ int huffman_codes_fast(const uint32_t* freq, int num_freq, int min_co
     zh_wave_sync();
     // ---- two-queue merge (one lane): the two smallest of {next leaves, next internal nodes}, n - 1 times ----
     if (lane == 0) {
+      // the heads of both queues in registers (what a pick needs is there; what replaces it is asked for a pick or
+      // two before it is compared): a merge is ~ 30 instructions, not a chain of LDS trips
+      constexpr uint32_t kInf = 0xffffffffu;
       int i = 0, j = 0;  // next leaf, next internal node
+      uint32_t la = w.lf[0], lb = w.lf[1], na = kInf, nb = kInf;  // (n >= 2)
       for (int m = 0; m < n - 1; m++) {
         uint32_t sum = 0;
+#pragma unroll
         for (int t = 0; t < 2; t++) {
-          const bool leaf = i < n && (j >= m || w.lf[i] <= w.nf[j]);
-          if (leaf) {
-            sum += w.lf[i];
+          if (la <= na) {  // (ties: the leaf -- the flatter tree)
+            sum += la;
             w.par[i] = (uint16_t)(n + m);
             i++;
+            la = lb;
+            lb = i + 1 < n ? w.lf[i + 1] : kInf;
           } else {
-            sum += w.nf[j];
+            sum += na;
             w.par[n + j] = (uint16_t)(n + m);
             j++;
+            na = nb;
+            nb = j + 1 < m ? w.nf[j + 1] : kInf;  // (node m is not made yet)
           }
         }
         w.nf[m] = sum;
+        // node m joins its queue: as the head, as the one behind it, or further back (then it is read when its turn comes)
+        if (j == m) na = sum;
+        else if (j + 1 == m) nb = sum;
       }
       w.par[2 * n - 2] = (uint16_t)(2 * n - 2);  // the root
     }
@@ -490,7 +501,8 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   uint32_t nlit = 0;
   for (uint32_t i = lane; i < ZH_HIST_STRIDE; i += 64) {
     uint32_t acc = 0;
-    for (uint32_t k = 0; k < bd.nfrag; k++) acc += a.f_hist[(size_t)(bd.first_frag + k) * ZH_HIST_STRIDE + i];
+#pragma unroll 8
+    for (uint32_t k = 0; k < bd.nfrag; k++) acc += a.f_hist[(size_t)(bd.first_frag + k) * ZH_HIST_STRIDE + i];  // (eight loads in flight)
     if (i == 256) acc = 1;  // always one end-of-block symbol (snappy.nim:145, lz77.nim:52)
     s_freq[i] = acc;
   }

@@ -191,25 +191,28 @@ __device__ __forceinline__ uint32_t dist_entry_a(uint32_t sym, uint32_t len) {
   return len | (kKindBad << 8);
 }
 
-constexpr uint32_t kWgScratchWords = 128u + 256u;  // build_table_wg's scratch (dwords)
+constexpr uint32_t kWgScratchWords = 128u;  // build_table_wg's scratch (dwords)
 
-// T threads (256 or 1024), all of them; R-bit root table, SUBCAP second-level entries behind it; KIND 0 litlen,
-// 1 distance.  lens[0..n) in LDS, n <= 320.  `scratch`: kWgScratchWords dwords of LDS nobody else uses meanwhile.
-// Ends with a barrier (the tables are ready for every thread); the returned status is the same in every thread.
+// T threads (256 or 1024), all of them; R-bit root table, SUBCAP second-level entries behind it; KIND 0 litlen
+// (up to 288 symbols), 1 distance (up to 32).  lens[0..n) in LDS.  `scratch`: kWgScratchWords dwords of LDS nobody
+// else uses meanwhile.  Ends with a barrier (the tables are ready for every thread); the returned status is the
+// same in every thread.
+// A canonical code is an ordered partition of the 15-bit values: the codes of l bits, left-justified, are the
+// values [lim[l - 1], lim[l]) with lim[l] = (first code of l bits + their count) << (15 - l).  So the length of the
+// code a bit pattern starts with is a count of comparisons, not a search -- for a root prefix (its first R bits) and
+// for a second-level entry (prefix + its index bits) alike.
 template <uint32_t T, uint32_t R, uint32_t SUBCAP, int KIND>
-__device__ __noinline__ int build_table_wg(const uint8_t* lens, uint32_t n, uint32_t* lut, HuffTab* tab, uint16_t* values,
+__device__ int build_table_wg(const uint8_t* lens, uint32_t n, uint32_t* lut, HuffTab* tab, uint16_t* values,
                               uint32_t* s_cnt, uint32_t* scratch) {
   static_assert(T % 64u == 0 && R <= 10u, "");
-  constexpr uint32_t kGroups = 5;                       // symbols in groups of 64: 320 slots
+  constexpr uint32_t kGroups = KIND == 0 ? 5u : 1u;             // symbols in groups of 64
   constexpr uint32_t kSlots = (kGroups * 64u + T - 1u) / T;  // symbol slots a thread
-  constexpr uint32_t kPP = ((1u << R) + T - 1u) / T;   // prefixes a thread
+  constexpr uint32_t kPP = ((1u << R) + T - 1u) / T;         // prefixes a thread
   const uint32_t tid = threadIdx.x, wv = tid >> 6;
   const unsigned lane = zh_lane();
   uint32_t* const s_g = scratch;            // [kGroups][16] symbols of a length in a group
-  uint32_t* const s_bad = scratch + 80;
+  uint32_t* const s_lim = scratch + 80;     // [16] lim[l]; [0]: over-subscribed
   uint32_t* const s_ws = scratch + 96;      // [T / 64] wave sums of the second-level sizes
-  uint8_t* const s_sz = reinterpret_cast<uint8_t*>(scratch + 128);  // (unused: sizes stay in registers)
-  (void)s_sz;
   // ---- 1. every symbol's rank among the symbols of its length in its group ----
   uint32_t sl[kSlots], srank[kSlots];
 #pragma unroll
@@ -224,90 +227,85 @@ __device__ __noinline__ int build_table_wg(const uint8_t* lens, uint32_t n, uint
       for (uint32_t L = 1; L < 16; L++) {
         const uint64_t m = __ballot(l == L);
         if (l == L) srank[j] = (uint32_t)__popcll(m & zh_lanemask_lt());
-        if (lane == 0) s_g[(s >> 6) * 16u + L] = (uint32_t)__popcll(m);
+        if (lane == L) s_g[(s >> 6) * 16u + L] = (uint32_t)__popcll(m);
       }
     }
   }
   __syncthreads();
-  // ---- 2. inflate.nim:32-51: counts, first codes, first canonical indices (wave 0, every lane alike) ----
+  // ---- 2. inflate.nim:32-51: counts, first codes, first canonical indices: lane l of wave 0 for length l ----
   if (tid < 64) {
-    uint32_t code = 0, k = 0;
-    int bad = 0;
+    uint32_t h = 0;
+    if (lane >= 1 && lane < 16) {
 #pragma unroll
-    for (uint32_t i = 1; i < 16; i++) {
-      uint32_t h = 0;
-#pragma unroll
-      for (uint32_t g = 0; g < kGroups; g++) h += s_g[g * 16u + i];
-      if (h > (1u << i)) bad = 1;
-      if (lane == 0) {
-        s_cnt[i] = h;
-        tab->first_code[i] = (uint16_t)code;
-        tab->first_symbol[i] = (uint16_t)k;
-      }
-      code += h;
-      if (h > 0 && code - 1 >= (1u << i)) bad = 1;
-      if (lane == 0) tab->max_codes[i] = code << (16 - i);
-      code <<= 1;
-      k += h;
+      for (uint32_t g = 0; g < kGroups; g++) h += s_g[g * 16u + lane];
+    }
+    // first code of length l = sum over shorter lengths l' of count[l'] << (l - l'), i.e. lim[l - 1] >> (15 - l);
+    // lim[l] = sum over l' <= l of count[l'] << (15 - l')
+    const uint32_t lim = zh_wave_scan(lane >= 1 && lane < 16 ? h << (15u - lane) : 0u);
+    const uint32_t first_sym = zh_wave_scan(h) - h;
+    const uint32_t first_code = lane >= 1 && lane < 16 ? (lim - (h << (15u - lane))) >> (15u - lane) : 0u;
+    // over-subscribed (inflate.nim:41-46): more codes of a length than that length has, or past its last value
+    const bool bad = lane >= 1 && lane < 16 && (h > (1u << lane) || (h > 0 && first_code + h - 1u >= (1u << lane)));
+    const uint64_t anybad = __ballot(bad);
+    if (lane >= 1 && lane < 16) {
+      s_cnt[lane] = h;
+      tab->first_code[lane] = (uint16_t)first_code;
+      tab->first_symbol[lane] = (uint16_t)first_sym;
+      tab->max_codes[lane] = (first_code + h) << (16u - lane);
+      s_lim[lane] = lim;
     }
     if (lane == 0) {
       tab->max_codes[16] = 1u << 16;
       s_cnt[0] = 0;
-      *s_bad = (uint32_t)bad;
+      s_lim[0] = anybad ? 1u : 0u;
     }
   }
   __syncthreads();
-  if (*s_bad) {
+  if (s_lim[0]) {
     __syncthreads();  // (everybody has read the flag before the scratch is used again)
     return ZH_ERR_INVALID_BUFFER;
   }
-  // the code's shape in registers: first code and count of a length in one word, first canonical index
-  uint32_t fcn[16], fs[16];
+  uint32_t lim[16];
 #pragma unroll
-  for (uint32_t i = 1; i < 16; i++) {
-    fcn[i] = (uint32_t)tab->first_code[i] | (s_cnt[i] << 16);
-    fs[i] = tab->first_symbol[i];
-  }
+  for (uint32_t i = 1; i < 16; i++) lim[i] = s_lim[i];
   // ---- 3. symbols in canonical order ----
 #pragma unroll
   for (uint32_t j = 0; j < kSlots; j++) {
     const uint32_t s = tid + j * T;
     if (s < kGroups * 64u && sl[j]) {
-      uint32_t before = 0;
+      uint32_t before = tab->first_symbol[sl[j]];
       for (uint32_t g = 0; g < (s >> 6); g++) before += s_g[g * 16u + sl[j]];
-      uint32_t first = 0;
-#pragma unroll
-      for (uint32_t i = 1; i < 16; i++)
-        if (sl[j] == i) first = fs[i];
-      values[first + before + srank[j]] = (uint16_t)s;
+      values[before + srank[j]] = (uint16_t)s;
     }
   }
   __syncthreads();
+  // the code that the 15-bit value v starts with: its length (16: none, the code is incomplete there)
+  auto len_of = [&](uint32_t v) -> uint32_t {
+    uint32_t l = 1;
+#pragma unroll
+    for (uint32_t i = 1; i < 16; i++) l += v >= lim[i] ? 1u : 0u;
+    return l;
+  };
+  auto entry_of = [&](uint32_t v, uint32_t l) -> uint32_t {
+    const uint32_t sym = values[(uint32_t)tab->first_symbol[l] + (v >> (15u - l)) - (uint32_t)tab->first_code[l]];
+    return KIND == 0 ? litlen_entry_a(sym, l) : dist_entry_a(sym, l);
+  };
   // ---- 4. a root entry per prefix (prefix p = the first R bits of the stream as a number, first bit on top) ----
-  uint32_t hit_l[kPP], hit_t[kPP], sub_l[kPP], size_sum = 0;
+  uint32_t pl[kPP], size_sum = 0;  // length of the code the prefix starts with, or (R + index bits of its second-level table) | 32
 #pragma unroll
   for (uint32_t k = 0; k < kPP; k++) {
     const uint32_t p = tid * kPP + k;
-    hit_l[k] = 0;
-    hit_t[k] = 0;
-    sub_l[k] = 0;
+    pl[k] = 0;
     if (p < (1u << R)) {
-#pragma unroll
-      for (uint32_t l = 1; l <= R; l++) {  // the code of l bits the prefix starts with, if any (a prefix code: one at most)
-        const uint32_t d = (p >> (R - l)) - (fcn[l] & 0xffffu);
-        if (d < (fcn[l] >> 16)) {
-          hit_l[k] = l;
-          hit_t[k] = fs[l] + d;
-        }
-      }
-      if (!hit_l[k]) {
-#pragma unroll
-        for (uint32_t L = R + 1u; L < 16; L++) {  // the longest code below the prefix
-          const uint32_t lo = p << (L - R), hi = lo + (1u << (L - R));
-          const uint32_t a = fcn[L] & 0xffffu, b = a + (fcn[L] >> 16);
-          if (a < b && lo < b && a < hi) sub_l[k] = L;
-        }
-        if (sub_l[k]) size_sum += 1u << (sub_l[k] - R);
+      const uint32_t v0 = p << (15u - R);
+      const uint32_t l = len_of(v0);
+      if (l <= R) {
+        pl[k] = l;
+      } else if (v0 < lim[15]) {  // codes below the prefix: the longest is the one its last assigned value starts with
+        const uint32_t top = (v0 + (1u << (15u - R)) < lim[15] ? v0 + (1u << (15u - R)) : lim[15]) - 1u;
+        const uint32_t jl = len_of(top);
+        pl[k] = jl | 32u;
+        size_sum += 1u << (jl - R);
       }
     }
   }
@@ -322,33 +320,22 @@ __device__ __noinline__ int build_table_wg(const uint8_t* lens, uint32_t n, uint
     const uint32_t p = tid * kPP + k;
     if (p < (1u << R)) {
       const uint32_t x = __brev(p) >> (32u - R);  // where the decoder looks: the stream carries codes first bit first
+      const uint32_t v0 = p << (15u - R);
       uint32_t e = 0;
-      if (hit_l[k]) {
-        const uint32_t sym = values[hit_t[k]];
-        e = KIND == 0 ? litlen_entry_a(sym, hit_l[k]) : dist_entry_a(sym, hit_l[k]);
-      } else if (sub_l[k]) {
-        const uint32_t sb = sub_l[k] - R, size = 1u << sb;
+      if (pl[k] & 32u) {
+        const uint32_t sb = (pl[k] & 31u) - R, size = 1u << sb;
         if (at + size <= SUBCAP) {  // (the sums grow: behind the first table that does not fit none does)
           const uint32_t base = (1u << R) + at;
           e = sb | 0x400u | (base << 16);
           for (uint32_t q = 0; q < size; q++) {
-            uint32_t se = 0;
-            const uint32_t rq = __brev(q);
-#pragma unroll
-            for (uint32_t L = R + 1u; L < 16; L++) {
-              if (L <= sub_l[k]) {
-                const uint32_t code = (p << (L - R)) | (rq >> (32u - (L - R)));
-                const uint32_t d = code - (fcn[L] & 0xffffu);
-                if (d < (fcn[L] >> 16)) {
-                  const uint32_t sym = values[fs[L] + d];
-                  se = KIND == 0 ? litlen_entry_a(sym, L) : dist_entry_a(sym, L);
-                }
-              }
-            }
-            lut[base + q] = se;
+            const uint32_t v = v0 | ((__brev(q) >> (32u - sb)) << (15u - R - sb));
+            const uint32_t l = len_of(v);
+            lut[base + q] = l <= R + sb && v < lim[15] ? entry_of(v, l) : 0u;
           }
         }
         at += size;
+      } else if (pl[k]) {
+        e = entry_of(v0, pl[k]);
       }
       lut[x] = e;
     }
