@@ -450,6 +450,15 @@ __device__ inline void hdr_add(HdrWriter& h, uint32_t value, uint32_t n) {
   h.bits += n;
 }
 
+// the same into LDS words that other lanes are writing at the same time
+__device__ inline void hdr_add_shared(HdrWriter& h, uint32_t value, uint32_t n) {
+  if (!n) return;
+  const uint32_t w = h.bits >> 5, s = h.bits & 31u;
+  atomicOr(&h.words[w], value << s);
+  if (s + n > 32) atomicOr(&h.words[w + 1], value >> (32 - s));
+  h.bits += n;
+}
+
 // OR `nbits` (<= 32) of value at absolute bit position `bit` of the byte stream at base.
 __device__ inline void or_bits(uint8_t* base, uint64_t bit, uint32_t value, uint32_t nbits) {
   if (!nbits) return;
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   __shared__ uint16_t s_codes[ZH_HIST_STRIDE];  // litlen at 0, distance at 288
   __shared__ uint8_t s_lens[ZH_HIST_STRIDE];
   __shared__ __attribute__((aligned(16))) uint8_t s_cl_all[ZH_HIST_STRIDE];
-  __shared__ __attribute__((aligned(16))) uint8_t s_rle[704];
+  __shared__ uint32_t s_num[32];  // the fast builder's length counts
   __shared__ uint32_t s_hdr[ZH_HDR_WORDS];
   __shared__ uint32_t s_mode, s_hdr_bits;
   // (the kernel's LDS stays under 10 KiB -- sixteen blocks a CU, 4096 blocks one round of the machine --, so the
@@ -485,10 +494,6 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   uint16_t* const s_clcodes = reinterpret_cast<uint16_t*>(s_freq + 32);  // [20]
   uint8_t* const s_cllens = reinterpret_cast<uint8_t*>(s_freq + 48);     // [20]
   int* const s_n = reinterpret_cast<int*>(s_freq + 64);  // [3] litlen codes, distance codes, run-length items (behind the litlen build)
-  // the fast builder's length counts [32]: in the run-length items' bytes while those are not there yet, in the
-  // collected lengths' once the items are
-  uint32_t* const s_num_a = reinterpret_cast<uint32_t*>(s_rle);
-  uint32_t* const s_num_b = reinterpret_cast<uint32_t*>(s_cl_all);
 
   const unsigned lane = zh_lane();
   KPROF_DECL(8);
@@ -546,9 +551,9 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   if (s_mode == ZH_MODE_DYNAMIC) {
     // ---- the literal / length and the distance code ----
     if (contract) {
-      const int nl = huffman_codes_fast(s_freq, ZH_NUM_LITLEN, 257, 15, s_codes, s_lens, fwork, s_num_a);
+      const int nl = huffman_codes_fast(s_freq, ZH_NUM_LITLEN, 257, 15, s_codes, s_lens, fwork, s_num);
       KPROF_MARK(1);
-      const int nd = huffman_codes_fast(s_freq + ZH_NUM_LITLEN, ZH_NUM_DIST, 2, 15, s_codes + 288, s_lens + 288, fwork, s_num_a);
+      const int nd = huffman_codes_fast(s_freq + ZH_NUM_LITLEN, ZH_NUM_DIST, 2, 15, s_codes + 288, s_lens + 288, fwork, s_num);
       KPROF_MARK(2);
       if (lane == 0) {
         s_n[0] = nl;
@@ -562,86 +567,144 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
     }
     zh_wave_sync();
     const int n_litlen = s_n[0], n_dist = s_n[1];
-    if (lane == 0) {
-      const int num_codes = n_litlen + n_dist;
-      for (int i = 0; i < n_litlen; i++) s_cl_all[i] = s_lens[i];
-      for (int i = 0; i < n_dist; i++) s_cl_all[n_litlen + i] = s_lens[288 + i];
-      // deflate.nim:313-350 run-length encoding of the code lengths
-      int rle_len = 0;
-      {
-        int i = 0;
-        while (i < num_codes) {
-          int repeat = 0;
-          while (i + repeat + 1 < num_codes && s_cl_all[i + repeat + 1] == s_cl_all[i]) repeat++;
-          if (s_cl_all[i] == 0 && repeat >= 2) {
-            repeat++;
-            if (repeat <= 10) {
-              s_rle[rle_len++] = 17;
-              s_rle[rle_len++] = (uint8_t)(repeat - 3);
-            } else {
-              if (repeat > 138) repeat = 138;
-              s_rle[rle_len++] = 18;
-              s_rle[rle_len++] = (uint8_t)(repeat - 11);
-            }
-            i += repeat - 1;
-          } else if (repeat >= 3) {
-            const int q = repeat / 6, r = repeat % 6;
-            s_rle[rle_len++] = s_cl_all[i];
-            for (int j = 0; j < q; j++) {
-              s_rle[rle_len++] = 16;
-              s_rle[rle_len++] = 3;
-            }
-            if (r >= 3) {
-              s_rle[rle_len++] = 16;
-              s_rle[rle_len++] = (uint8_t)(r - 3);
-            } else {
-              repeat -= r;
-            }
-            i += repeat;
-          } else {
-            s_rle[rle_len++] = s_cl_all[i];
+    // ---- deflate.nim:313-350: the code lengths, run-length coded -- by the whole wave.  The reference walks the
+    // lengths one by one; what it emits for a maximal run of `run` equal lengths v is a closed form of (v, run):
+    //   zeros, run >= 3:  a symbol 18 (138 zeros) per full 138, then for the rest r: >= 11 one 18, >= 3 one 17, else r zeros
+    //   v != 0, run >= 4: v itself, a symbol 16 (repeat 6) per full six of the run - 1 behind it, then for the rest
+    //                     r: >= 3 one 16, else r times v
+    //   otherwise:        v, run times
+    // so every run's first lane knows its items, their count a symbol (the code-length alphabet's histogram,
+    // deflate.nim:352-360) and, once that alphabet has its code, their bits and where they go. ----
+    const int num_codes = n_litlen + n_dist;
+    constexpr int kG = 5;  // 316 lengths at most
+    for (int i = (int)lane; i < n_litlen; i += 64) s_cl_all[i] = s_lens[i];
+    for (int i = (int)lane; i < n_dist; i += 64) s_cl_all[n_litlen + i] = s_lens[288 + i];
+    if (lane < 19) s_clfreq[lane] = 0;
+    zh_wave_sync();
+    uint32_t rv[kG], rrun[kG];  // a run's first lane: its value and length (0: this lane starts none)
+    {
+      uint64_t H[kG];
+#pragma unroll
+      for (int g = 0; g < kG; g++) {
+        const int pos = 64 * g + (int)lane;
+        rv[g] = pos < num_codes ? s_cl_all[pos] : 0xffu;
+        const bool head = pos < num_codes && (pos == 0 || s_cl_all[pos - 1] != rv[g]);
+        H[g] = __ballot(head);
+      }
+#pragma unroll
+      for (int g = 0; g < kG; g++) {
+        const int pos = 64 * g + (int)lane;
+        rrun[g] = 0;
+        if ((H[g] >> lane) & 1ull) {
+          int next = num_codes;
+          bool found = false;
+          const uint64_t above = lane == 63 ? 0ull : H[g] & ~((2ull << lane) - 1ull);
+          if (above) {
+            next = 64 * g + __ffsll((long long)above) - 1;
+            found = true;
           }
-          i++;
+#pragma unroll
+          for (int g2 = 0; g2 < kG; g2++)
+            if (g2 > g && !found && H[g2]) {
+              next = 64 * g2 + __ffsll((long long)H[g2]) - 1;
+              found = true;
+            }
+          rrun[g] = (uint32_t)(next - pos);
         }
       }
-      s_n[2] = rle_len;
-      KPROF_MARK(3);
-      for (int i = 0; i < 19; i++) s_clfreq[i] = 0;
-      for (int i = 0; i < rle_len; i++) {  // deflate.nim:352-360
-        s_clfreq[s_rle[i]]++;
-        if (s_rle[i] >= 16) i++;
+    }
+#pragma unroll
+    for (int g = 0; g < kG; g++) {
+      const uint32_t v = rv[g], run = rrun[g];
+      if (!run) continue;
+      if (v == 0 && run >= 3) {
+        const uint32_t n18 = run / 138u, r = run % 138u;
+        if (n18 + (r >= 11 ? 1u : 0u)) atomicAdd(&s_clfreq[18], n18 + (r >= 11 ? 1u : 0u));
+        if (r >= 3 && r < 11) atomicAdd(&s_clfreq[17], 1u);
+        if (r < 3 && r) atomicAdd(&s_clfreq[0], r);
+      } else if (run >= 4) {
+        const uint32_t q = (run - 1u) / 6u, r = (run - 1u) % 6u;
+        atomicAdd(&s_clfreq[v], 1u + (r < 3 ? r : 0u));
+        atomicAdd(&s_clfreq[16], q + (r >= 3 ? 1u : 0u));
+      } else {
+        atomicAdd(&s_clfreq[v], run);
       }
     }
     zh_wave_sync();
+    KPROF_MARK(3);
     // ---- the code of the code lengths (deflate.nim:362) ----
     if (contract) {
-      huffman_codes_fast(s_clfreq, 19, 19, 7, s_clcodes, s_cllens, fwork, s_num_b);
+      huffman_codes_fast(s_clfreq, 19, 19, 7, s_clcodes, s_cllens, fwork, s_num);
     } else if (lane == 0) {
       huffman_codes(s_clfreq, 19, 19, 7, s_clcodes, s_cllens, s_work);
     }
     zh_wave_sync();
-    if (lane == 0) {
-      const int rle_len = s_n[2];
-      uint32_t* const clcl_ordered = s_freq + 80;  // [19] (dead bytes as well)
-      for (int i = 0; i < 19; i++) clcl_ordered[i] = s_cllens[c_clcl_order[i]];
-      int hclen = 19;
-      while (clcl_ordered[hclen - 1] == 0) hclen--;
-      hclen -= 4;
+    uint32_t hclen4 = 0;  // HCLEN + 4: the code-length code's lengths that go into the header
+    {
+      const uint32_t ordered = lane < 19 ? s_cllens[c_clcl_order[lane]] : 0u;
+      const uint64_t nz = __ballot(ordered != 0u);
+      hclen4 = nz ? 64u - (uint32_t)__clzll((long long)nz) : 0u;  // (one symbol is always used: the last nonzero is there)
       KPROF_MARK(4);
-      hdr_add(h, bd.is_final ? 1 : 0, 1);  // deflate.nim:376-383
-      hdr_add(h, 2, 2);
-      hdr_add(h, (uint32_t)(n_litlen - 257), 5);
-      hdr_add(h, (uint32_t)(n_dist - 1), 5);
-      hdr_add(h, (uint32_t)hclen, 4);
-      for (int i = 0; i < hclen + 4; i++) hdr_add(h, clcl_ordered[i], 3);
-      for (int i = 0; i < rle_len;) {  // deflate.nim:388-401
-        const uint32_t sym = s_rle[i++];
-        hdr_add(h, s_clcodes[sym], s_cllens[sym]);
-        if (sym == 16) hdr_add(h, s_rle[i++], 2);
-        else if (sym == 17) hdr_add(h, s_rle[i++], 3);
-        else if (sym == 18) hdr_add(h, s_rle[i++], 7);
+      // deflate.nim:376-386: BFINAL, BTYPE, HLIT, HDIST, HCLEN, the 3-bit lengths: 17 + 3 (HCLEN + 4) bits, lane 0 the
+      // fixed fields, lane i the i-th length
+      if (lane == 0) atomicOr(&s_hdr[0], (bd.is_final ? 1u : 0u) | (2u << 1) | ((uint32_t)(n_litlen - 257) << 3) |
+                                             ((uint32_t)(n_dist - 1) << 8) | ((hclen4 - 4u) << 13));
+      if (lane < hclen4) {
+        const uint32_t at = 17u + 3u * lane;
+        atomicOr(&s_hdr[at >> 5], ordered << (at & 31u));
+        if ((at & 31u) > 29u) atomicOr(&s_hdr[(at >> 5) + 1u], ordered >> (32u - (at & 31u)));
       }
     }
+    // ---- deflate.nim:388-401: the items' bits ----
+    auto item_bits = [&](uint32_t sym) -> uint32_t {
+      return (uint32_t)s_cllens[sym] + (sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u);
+    };
+    uint32_t cursor = 17u + 3u * hclen4;
+#pragma unroll
+    for (int g = 0; g < kG; g++) {
+      const uint32_t v = rv[g], run = rrun[g];
+      uint32_t bits = 0;
+      if (run) {
+        if (v == 0 && run >= 3) {
+          const uint32_t n18 = run / 138u, r = run % 138u;
+          bits = n18 * item_bits(18) + (r >= 11 ? item_bits(18) : r >= 3 ? item_bits(17) : r * item_bits(0));
+        } else if (run >= 4) {
+          const uint32_t q = (run - 1u) / 6u, r = (run - 1u) % 6u;
+          bits = item_bits(v) * (1u + (r < 3 ? r : 0u)) + item_bits(16) * (q + (r >= 3 ? 1u : 0u));
+        } else {
+          bits = run * item_bits(v);
+        }
+      }
+      const uint32_t incl = zh_wave_scan(bits);
+      HdrWriter hw{s_hdr, cursor + incl - bits};
+      auto put = [&](uint32_t sym, uint32_t extra) {  // the symbol's code, then its extra bits
+        hdr_add_shared(hw, s_clcodes[sym], s_cllens[sym]);
+        if (sym == 16u) hdr_add_shared(hw, extra, 2);
+        else if (sym == 17u) hdr_add_shared(hw, extra, 3);
+        else if (sym == 18u) hdr_add_shared(hw, extra, 7);
+      };
+      if (run) {
+        if (v == 0 && run >= 3) {
+          const uint32_t n18 = run / 138u, r = run % 138u;
+          for (uint32_t k = 0; k < n18; k++) put(18, 138u - 11u);
+          if (r >= 11) put(18, r - 11u);
+          else if (r >= 3) put(17, r - 3u);
+          else
+            for (uint32_t k = 0; k < r; k++) put(0, 0);
+        } else if (run >= 4) {
+          const uint32_t q = (run - 1u) / 6u, r = (run - 1u) % 6u;
+          put(v, 0);
+          for (uint32_t k = 0; k < q; k++) put(16, 3);
+          if (r >= 3) put(16, r - 3u);
+          else
+            for (uint32_t k = 0; k < r; k++) put(v, 0);
+        } else {
+          for (uint32_t k = 0; k < run; k++) put(v, 0);
+        }
+      }
+      cursor += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    h.bits = cursor;
   }
   if (lane == 0) s_hdr_bits = h.bits;
   zh_wave_sync();
