@@ -555,9 +555,9 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
                                                 : nb * ((size_t)2 << 17);  // (zh_launch_chain_prev)
   const size_t o_head = ar.reserve(p->head_bytes);
   // one 32 KiB hash table per persistent matcher wave (zh_launch_l1_match: min(fragments, slots) waves)
-  // (the parallel parse, zh_launch_l1p_match, keeps 192 KiB of table results and candidate links per workgroup there instead)
+  // (the parallel parse, zh_launch_l1p_match, keeps 128 KiB of table results per workgroup there instead)
   const size_t o_l1tab = ar.reserve(level == 1 ? std::max(std::min<size_t>(nf, zh_l1_table_slots()) * 32768,
-                                                          std::min<size_t>(nf, zh_l1p_slots()) * 196608)
+                                                          std::min<size_t>(nf, zh_l1p_slots()) * 131072)
                                                : 0);
   const size_t o_l1ctr = ar.reserve(256);
   const size_t o_cprev = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 8 : 0);

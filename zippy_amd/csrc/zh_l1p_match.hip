@@ -16,20 +16,19 @@
 //                atomicMax a position: what comes back is the latest earlier position with the
 //                slot's hash -- EVERY position is inserted, not only the ones a serial parse
 //                visits -- and goes to the workgroup's slot of scratch as it is;
-//   P2  lengths  a thread per position: the candidate from the table's answer (or the position
-//                before, in a run), common prefix with it, 0 or 4..258 (internal.nim:251-270
-//                determineMatchLength, limit snappy.nim:110), the fragment's bytes now in LDS
-//                where the table was;
-//   P3  parse    greedy left to right (take the match at p if there is one, else a
-//                literal) -- a static problem once the lengths are known: a thread per 32
-//                positions walks from a guessed entry, exits are handed on and threads whose
-//                entry changed walk again; thread 0's entry is exact, so at the fixed point
-//                every entry is the serial walk's by induction;
+//   P2+P3 parse  greedy left to right (take the match at p if there is one, else a literal), the
+//                fragment's bytes now in LDS where the table was.  A thread per 32 positions walks from
+//                a guessed entry and works out the match length of what it VISITS (the candidate from
+//                the table's answer -- or the position before, in a run --, the common prefix, 0 or
+//                4..258: internal.nim:251-270 determineMatchLength, limit snappy.nim:110); exits are
+//                handed on and threads whose entry changed walk again; thread 0's entry is exact, so
+//                at the fixed point every entry is the serial walk's by induction.  (Round 3 worked out
+//                the length of every position first, a thread a position: 47 % of the kernel for values of
+//                which the parse reads a third.  Same lengths, same parse, same bytes.)
 //   P4  output   match list (same SoA records the exact matcher writes), litlen / distance
 //                histograms, literal count, extra-bit sum.
-// Algorithmic bytes: N read.  The table's answers (128 KiB a fragment) and the candidate links
-// (64 KiB) go through a per-workgroup slot of HBM scratch (persistent workgroups): measured 64 GB a
-// launch of 4096 x 1 MiB against the exact matcher's 394.
+// Algorithmic bytes: N read.  The table's answers (128 KiB a fragment) go through a per-workgroup slot of
+// HBM scratch (persistent workgroups).
 #include <cstdlib>
 #include <cstring>
 
@@ -69,13 +68,11 @@ __global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __re
   uint8_t* const s_mlen = reinterpret_cast<uint8_t*>(s_big + kSrcWords);
 
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  // a workgroup's slot of the pool: what the table returned for every position (a dword each, P1 ->
-  // P2), then the candidates of the positions (a halfword each, P2 -> P4)
-  uint32_t* const raws = reinterpret_cast<uint32_t*>(link_pool + (size_t)blockIdx.x * (3u * ZH_FRAG_SIZE));
-  uint16_t* const links = link_pool + (size_t)blockIdx.x * (3u * ZH_FRAG_SIZE) + 2u * ZH_FRAG_SIZE;
+  // a workgroup's slot of the pool: what the table returned for every position (a dword each, P1 -> P2 / P4)
+  uint32_t* const raws = reinterpret_cast<uint32_t*>(link_pool + (size_t)blockIdx.x * (2u * ZH_FRAG_SIZE));
 
   for (uint32_t f = blockIdx.x; f < a.nfrags;) {
-    KPROF_DECL(8);  // cycles of thread 0: 0 stage-in, 1 links, 2 lengths, 3 parse, 4 output; counts: 5 turns, 6 fragments
+    KPROF_DECL(8);  // cycles of thread 0: 0 stage-in, 1 links, 2 first walks (lengths on demand), 3 turns, 4 output; counts: 5 turns, 6 fragments
     const ZhFragDesc fd = a.frags[f];
     const uint32_t n = fd.len;
     const uint8_t* src = d_src + fd.src_off;
@@ -162,136 +159,77 @@ __global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __re
     auto ld64 = [&](uint32_t p) -> uint64_t { return zh_ld64(s_src, p + mis); };
 
     KPROF_MARK(1);
-    // ---- P2: match length of every position against its candidate (position 512 r + t in turn
-    // r; the links are fetched four turns ahead).  The SIMDs are busy issuing here, so the work is
-    // cut to what the parse can need: a candidate whose hash bits differ is no match; in a stretch
-    // of positions with the same distance to their candidates (a repeat) only the first one -- the
-    // head -- compares, the others' lengths follow from its length; a head compares 16 bytes by
-    // itself, and the few that are longer are finished one after the other by the whole wave, a
-    // lane four bytes ----
-    {
-      // wave-wide: common prefix of positions p and c (wave-uniform) from byte m0 on, at most lim
-      auto finish = [&](uint32_t p, uint32_t c, uint32_t m0, uint32_t lim) -> uint32_t {
-        for (;;) {
-          const uint32_t o = m0 + 4u * lane;
-          const uint32_t x = o < lim ? zh_ld32(s_src, p + o + mis) ^ zh_ld32(s_src, c + o + mis) : 1u;
-          const uint64_t stop = __ballot(x != 0u);
-          if (stop) {
-            const uint32_t fl = (uint32_t)__ffsll((long long)stop) - 1u;
-            const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane((int)x, fl);
-            const uint32_t os = m0 + 4u * fl;
-            const uint32_t m = os < lim ? os + (((uint32_t)__ffs((int)xs) - 1u) >> 3) : lim;
-            return m > lim ? lim : m;
-          }
-          m0 += 256;  // (lim <= 258: one more turn at most)
-        }
-      };
-      uint32_t c0 = raws[t], c1 = raws[kT + t], c2 = raws[2 * kT + t], c3 = raws[3 * kT + t];
-      for (uint32_t r = 0; r < ZH_FRAG_SIZE / kT; r++) {
-        const uint32_t p = r * kT + t;
-        const uint32_t raw = c0;
-        c0 = c1;
-        c1 = c2;
-        c2 = c3;
-        c3 = raws[(r + 4u < ZH_FRAG_SIZE / kT ? r + 4u : r) * kT + t];
-        // the candidate: the latest earlier position with the hash (a candidate lies before its
-        // position) -- or, in a run, the position right before: the nearest candidate there is
-        const uint32_t h = ld32(p) * kHashMul;
-        uint32_t h_prev = (uint32_t)__shfl_up((int)h, 1, 64);
-        if (lane == 0) h_prev = p ? ld32(p - 1u) * kHashMul : ~h;
-        uint32_t c = raw >> 16;
-        bool same = c < p && ((raw ^ (h >> 2)) & 0xffffu) == 0u;  // the candidate's 30 hash bits are the position's
-        if ((h >> 2) == (h_prev >> 2) && p >= 2u) {
-          c = p - 1u;
-          same = true;
-        }
-        if (c >= p) c = 0;
-        links[p] = (uint16_t)c;
-        // no match starts in the last 15 bytes (the reference's ip_limit)
-        const bool cand = p + 16u <= n && same && c != 0u;
-        const uint32_t lim = n - p < 258u ? n - p : 258u;  // snappy.nim:110 (>= 16 for a candidate)
-        const uint32_t off = cand ? p - c : 0u;
-        uint32_t off_prev = (uint32_t)__shfl_up((int)off, 1, 64);
-        if (lane == 0) off_prev = 0;
-        const bool follower = cand && off == off_prev;
-        const bool head = cand && !follower;
-        uint32_t m = 0;
-        bool open = false;  // equal so far and not at the limit: the wave finishes it
-        if (head) {
-          // 16 bytes: both streams as aligned dwords shifted into place
-          const uint32_t ab = p + mis, bb = c + mis, as = ab & 3u, bs = bb & 3u;
-          const uint32_t* ap = s_src + (ab >> 2);
-          const uint32_t* bp = s_src + (bb >> 2);
-          uint32_t x[4];
-#pragma unroll
-          for (uint32_t i = 0; i < 4; i++)
-            x[i] = __builtin_amdgcn_alignbyte(ap[i + 1], ap[i], as) ^ __builtin_amdgcn_alignbyte(bp[i + 1], bp[i], bs);
-          m = 16;
-#pragma unroll
-          for (uint32_t i = 4; i-- > 0;)
-            if (x[i]) m = 4u * i + (((uint32_t)__ffs((int)x[i]) - 1u) >> 3);
-          open = m == 16u && lim > 16u;
-        }
-        uint32_t m0 = 16;
-        auto finish_open = [&]() {  // the open ones, one after the other, by the whole wave
-          for (uint64_t todo = __ballot(open); todo; todo &= todo - 1) {
-            const uint32_t g = (uint32_t)__ffsll((long long)todo) - 1u;
-            const uint32_t mg = finish((uint32_t)__builtin_amdgcn_readlane((int)p, g), (uint32_t)__builtin_amdgcn_readlane((int)c, g),
-                                       (uint32_t)__builtin_amdgcn_readlane((int)m0, g), (uint32_t)__builtin_amdgcn_readlane((int)lim, g));
-            if (lane == g) m = mg;
-          }
-          open = false;
-        };
-        finish_open();
-        if (__ballot(follower)) {
-          // A head that stopped at 258 bytes, not at a difference: its followers reach further (each
-          // to its own 258 bytes) through the same bytes -- how many more of them are equal, once
-          uint32_t ext = 0;
-          for (uint64_t todo = __ballot(head && m == 258u); todo; todo &= todo - 1) {
-            const uint32_t g = (uint32_t)__ffsll((long long)todo) - 1u;
-            const uint32_t pg = (uint32_t)__builtin_amdgcn_readlane((int)p, g);
-            const uint32_t room = n - pg < 322u ? n - pg : 322u;
-            const uint32_t eg = finish(pg, (uint32_t)__builtin_amdgcn_readlane((int)c, g), 258u, room) - 258u;
-            if (lane == g) ext = eg;
-          }
-          // followers: the same bytes against the same bytes, k positions behind the head of the stretch
-          const uint32_t hl = zh_wave_scan_max(head ? lane : 0u);
-          const uint32_t mh = (uint32_t)__shfl((int)m, (int)hl, 64);
-          const uint32_t exth = (uint32_t)__shfl((int)ext, (int)hl, 64);
-          const uint32_t k = lane - hl;
-          if (follower) {
-            if (mh > k) {
-              m = mh - k + exth;
-              if (m > lim) m = lim;
-            } else {  // the head's match ends before this position: nothing is known about it
-              open = true;
-              m0 = 0;
-            }
-          }
-          finish_open();
-        }
-        if (m < 4u) m = 0;
-        s_mlen[p] = (uint8_t)(m ? m - 3u : 0u);
-      }
-    }
-    __syncthreads();
-
-    KPROF_MARK(2);
-    // ---- P3: greedy parse.  step(p) = length of the match at p, or 1 ----
+    // ---- P2 + P3: the greedy parse (take the match at p if there is one, else a literal), and match lengths
+    // only where it comes by.  The parse visits a third of the positions; working out the length of EVERY
+    // position first (round 3: a thread a position, 32 turns) was where the kernel spent its instructions.
+    // A thread walks its 32-position chunk from a guessed entry -- the chunk's first byte -- and works out what
+    // it visits: the candidate from the table's answer (or the position before, in a run), the common prefix,
+    // 0 or 4..258 (internal.nim:251-270 determineMatchLength, limit snappy.nim:110); results stay in s_mlen and
+    // a bit a position in a register says which are there (a thread only ever works inside its own chunk).
+    // Exits are handed on, threads whose entry changed walk again -- what they meet a second time they look up
+    // --; thread 0's entry is exact, so at the fixed point every entry is the serial walk's by induction. ----
     const uint32_t lo = t * kChunk, hi = lo + kChunk < n ? lo + kChunk : n;
+    // the candidate of position p (0: none): the latest earlier position with the hash -- its 30 hash bits must be
+    // the position's -- or, in a run, the position right before: the nearest candidate there is
+    auto candidate = [&](uint32_t p) -> uint32_t {
+      const uint32_t raw = raws[p];
+      const uint64_t w5 = zh_ld64(s_src, p + mis - (p ? 1u : 0u));  // the byte before p and p's four
+      const uint32_t h = (uint32_t)(p ? w5 >> 8 : w5) * kHashMul;
+      const uint32_t h_prev = p ? (uint32_t)w5 * kHashMul : ~h;
+      uint32_t c = raw >> 16;
+      bool same = c < p && ((raw ^ (h >> 2)) & 0xffffu) == 0u;
+      if ((h >> 2) == (h_prev >> 2) && p >= 2u) {
+        c = p - 1u;
+        same = true;
+      }
+      return same && c < p ? c : 0u;
+    };
+    // match length at p: 0 or 4..258; no match starts in the last 15 bytes (the reference's ip_limit)
+    auto eval = [&](uint32_t p) -> uint32_t {
+      if (p + 16u > n) return 0u;
+      const uint32_t c = candidate(p);
+      if (c == 0u) return 0u;
+      const uint32_t lim = n - p < 258u ? n - p : 258u;  // snappy.nim:110 (>= 16 here)
+      uint32_t m = 0;
+      for (;;) {  // 16 bytes a turn: both streams as aligned dwords shifted into place
+        const uint32_t ab = p + m + mis, bb = c + m + mis, as = ab & 3u, bs = bb & 3u;
+        const uint32_t* ap = s_src + (ab >> 2);
+        const uint32_t* bp = s_src + (bb >> 2);
+        uint32_t x[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++)
+          x[i] = __builtin_amdgcn_alignbyte(ap[i + 1], ap[i], as) ^ __builtin_amdgcn_alignbyte(bp[i + 1], bp[i], bs);
+        uint32_t d = 16;
+#pragma unroll
+        for (uint32_t i = 4; i-- > 0;)
+          if (x[i]) d = 4u * i + (((uint32_t)__ffs((int)x[i]) - 1u) >> 3);
+        m += d;
+        if (d < 16u || m >= lim) break;
+      }
+      if (m > lim) m = lim;
+      return m < 4u ? 0u : m;
+    };
+    uint32_t known = 0;  // bit i: the length of position lo + i is in s_mlen
     auto walk = [&](uint32_t p, uint32_t end) -> uint32_t {
       while (p < end) {
-        const uint32_t m = s_mlen[p];
-        p += m ? m + 3u : 1u;
+        const uint32_t bit = 1u << (p - lo);
+        uint32_t m8;
+        if (known & bit) {
+          m8 = s_mlen[p];
+        } else {
+          const uint32_t m = eval(p);
+          m8 = m ? m - 3u : 0u;
+          s_mlen[p] = (uint8_t)m8;
+          known |= bit;
+        }
+        p += m8 ? m8 + 3u : 1u;
       }
       return p;
     };
-    uint32_t entry = 0, ex = 0;
-    if (lo < n) {
-      entry = t ? walk(lo - kChunk, lo) : 0u;  // guessed: as if the chunk before were entered at its first byte
-      ex = walk(entry, hi);
-    }
+    uint32_t entry = lo, ex = 0;
+    if (lo < n) ex = walk(entry, hi);
     s_exit[t] = ex;
+    KPROF_MARK(2);
     for (;;) {
       __syncthreads();
       const uint32_t want = t && lo < n ? s_exit[t - 1] : entry;
@@ -354,12 +292,12 @@ __global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __re
         }
       }
     }
-    __syncthreads();  // (records and links were written by this workgroup: its CU's L1 has them)
-    // distances: a thread per match, so that the scattered reads of the links are all in flight at once
+    __syncthreads();  // (the records were written by this workgroup: its CU's L1 has them)
+    // distances: a thread per match (its candidate once more: the table's answers are all in flight at once)
     uint32_t extra_bits = 0;
     for (uint32_t k = t; k < total_m; k += kT) {
       const uint32_t p = m_pos[k], len = m_len[k];
-      const uint32_t off = p - links[p];
+      const uint32_t off = p - candidate(p);
       m_off[k] = (uint16_t)off;
       const uint32_t di = zh_dist_code(off);
       atomicAdd(&s_hist[ZH_NUM_LITLEN + di], 1u);
