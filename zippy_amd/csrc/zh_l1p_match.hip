@@ -171,8 +171,7 @@ __global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __re
     const uint32_t lo = t * kChunk, hi = lo + kChunk < n ? lo + kChunk : n;
     // the candidate of position p (0: none): the latest earlier position with the hash -- its 30 hash bits must be
     // the position's -- or, in a run, the position right before: the nearest candidate there is
-    auto candidate = [&](uint32_t p) -> uint32_t {
-      const uint32_t raw = raws[p];
+    auto candidate = [&](uint32_t p, uint32_t raw) -> uint32_t {
       const uint64_t w5 = zh_ld64(s_src, p + mis - (p ? 1u : 0u));  // the byte before p and p's four
       const uint32_t h = (uint32_t)(p ? w5 >> 8 : w5) * kHashMul;
       const uint32_t h_prev = p ? (uint32_t)w5 * kHashMul : ~h;
@@ -185,9 +184,9 @@ __global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __re
       return same && c < p ? c : 0u;
     };
     // match length at p: 0 or 4..258; no match starts in the last 15 bytes (the reference's ip_limit)
-    auto eval = [&](uint32_t p) -> uint32_t {
+    auto eval = [&](uint32_t p, uint32_t raw) -> uint32_t {
       if (p + 16u > n) return 0u;
-      const uint32_t c = candidate(p);
+      const uint32_t c = candidate(p, raw);
       if (c == 0u) return 0u;
       const uint32_t lim = n - p < 258u ? n - p : 258u;  // snappy.nim:110 (>= 16 here)
       uint32_t m = 0;
@@ -210,6 +209,10 @@ __global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __re
       return m < 4u ? 0u : m;
     };
     uint32_t known = 0;  // bit i: the length of position lo + i is in s_mlen
+    // the table's answers come four positions a load: two tokens in three are literals, and the position behind
+    // a literal then has its answer in a register already instead of a trip to L2 away
+    uint32_t wbase = 0x80000000u;
+    Bytes16 wr = {0, 0, 0, 0};
     auto walk = [&](uint32_t p, uint32_t end) -> uint32_t {
       while (p < end) {
         const uint32_t bit = 1u << (p - lo);
@@ -217,7 +220,13 @@ __global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __re
         if (known & bit) {
           m8 = s_mlen[p];
         } else {
-          const uint32_t m = eval(p);
+          uint32_t d = p - wbase;
+          if (d >= 4u) {
+            wr = *reinterpret_cast<const Bytes16*>(raws + p);  // (past the fragment's last position: the pool's next bytes, unused)
+            wbase = p;
+            d = 0;
+          }
+          const uint32_t m = eval(p, d == 0u ? wr.x : d == 1u ? wr.y : d == 2u ? wr.z : wr.w);
           m8 = m ? m - 3u : 0u;
           s_mlen[p] = (uint8_t)m8;
           known |= bit;
@@ -228,22 +237,38 @@ __global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __re
     };
     uint32_t entry = lo, ex = 0;
     if (lo < n) ex = walk(entry, hi);
-    s_exit[t] = ex;
+    if (lane == 63) s_exit[t] = ex;
+    __syncthreads();
     KPROF_MARK(2);
+    // Exits are handed on inside a wave first (lane to lane, no barrier: a wave's 64 chunks settle among
+    // themselves), then from wave to wave through s_exit; a round of the outer loop is one such hand-over.
     for (;;) {
-      __syncthreads();
-      const uint32_t want = t && lo < n ? s_exit[t - 1] : entry;
-      if (t == 0) s_misc[1] = 0;
-      __syncthreads();
-      if (want != entry) {
-        entry = want;
-        ex = walk(entry, hi);
-        s_exit[t] = ex;
-        s_misc[1] = 1;
+      uint32_t from_before = entry;  // what the chunk before hands this one: lane 0 gets it from the wave before
+      if (lane == 0 && t && lo < n) from_before = s_exit[t - 1];
+      bool any = false;
+      for (;;) {
+        uint32_t want = (uint32_t)__shfl_up((int)ex, 1, 64);
+        if (lane == 0) want = from_before;
+        if (!(t && lo < n)) want = entry;
+        const bool changed = want != entry;
+        if (changed) {
+          entry = want;
+          ex = walk(entry, hi);
+        }
+        KPROF_COUNT(5, 1);
+        if (!__ballot(changed)) break;
+        any = true;
       }
+      __syncthreads();  // (everybody has read the exits of the round before)
+      if (t == 0) s_misc[1] = 0;
+      if (lane == 63) s_exit[t] = ex;
       __syncthreads();
-      KPROF_COUNT(5, 1);
+      // a wave whose first lane would now be handed something else goes on
+      const bool more = lane == 0 && t && lo < n && s_exit[t - 1] != entry;
+      if (more) s_misc[1] = 1;
+      __syncthreads();
       if (!s_misc[1]) break;
+      (void)any;
     }
     KPROF_MARK(3);
 
@@ -297,7 +322,7 @@ __global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __re
     uint32_t extra_bits = 0;
     for (uint32_t k = t; k < total_m; k += kT) {
       const uint32_t p = m_pos[k], len = m_len[k];
-      const uint32_t off = p - candidate(p);
+      const uint32_t off = p - candidate(p, raws[p]);
       m_off[k] = (uint16_t)off;
       const uint32_t di = zh_dist_code(off);
       atomicAdd(&s_hist[ZH_NUM_LITLEN + di], 1u);
