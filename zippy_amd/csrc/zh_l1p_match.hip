@@ -183,55 +183,66 @@ __global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __re
       }
       return same && c < p ? c : 0u;
     };
-    // match length at p: 0 or 4..258; no match starts in the last 15 bytes (the reference's ip_limit)
-    auto eval = [&](uint32_t p, uint32_t raw) -> uint32_t {
-      if (p + 16u > n) return 0u;
-      const uint32_t c = candidate(p, raw);
-      if (c == 0u) return 0u;
-      const uint32_t lim = n - p < 258u ? n - p : 258u;  // snappy.nim:110 (>= 16 here)
-      uint32_t m = 0;
-      for (;;) {  // 16 bytes a turn: both streams as aligned dwords shifted into place
-        const uint32_t ab = p + m + mis, bb = c + m + mis, as = ab & 3u, bs = bb & 3u;
-        const uint32_t* ap = s_src + (ab >> 2);
-        const uint32_t* bp = s_src + (bb >> 2);
-        uint32_t x[4];
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++)
-          x[i] = __builtin_amdgcn_alignbyte(ap[i + 1], ap[i], as) ^ __builtin_amdgcn_alignbyte(bp[i + 1], bp[i], bs);
-        uint32_t d = 16;
-#pragma unroll
-        for (uint32_t i = 4; i-- > 0;)
-          if (x[i]) d = 4u * i + (((uint32_t)__ffs((int)x[i]) - 1u) >> 3);
-        m += d;
-        if (d < 16u || m >= lim) break;
-      }
-      if (m > lim) m = lim;
-      return m < 4u ? 0u : m;
-    };
     uint32_t known = 0;  // bit i: the length of position lo + i is in s_mlen
     // the table's answers come four positions a load: two tokens in three are literals, and the position behind
     // a literal then has its answer in a register already instead of a trip to L2 away
     uint32_t wbase = 0x80000000u;
     Bytes16 wr = {0, 0, 0, 0};
+    // The walk as ONE loop (a loop per compare inside a loop per position makes a wave wait for its longest
+    // match at every position): a turn takes a lane that stands at a new position through its candidate -- or the
+    // length it already knows -- and a lane that is comparing through 16 more bytes; a lane whose match runs on
+    // compares on while its neighbours walk.  Match length: 0 or 4..258 (internal.nim:251-270, limit
+    // snappy.nim:110); no match starts in the last 15 bytes (the reference's ip_limit).
     auto walk = [&](uint32_t p, uint32_t end) -> uint32_t {
+      uint32_t c = 0, m = 0, lim = 0;  // comparing: candidate, bytes equal so far, limit (c == 0: standing at p)
       while (p < end) {
-        const uint32_t bit = 1u << (p - lo);
-        uint32_t m8;
-        if (known & bit) {
-          m8 = s_mlen[p];
-        } else {
-          uint32_t d = p - wbase;
-          if (d >= 4u) {
-            wr = *reinterpret_cast<const Bytes16*>(raws + p);  // (past the fragment's last position: the pool's next bytes, unused)
-            wbase = p;
-            d = 0;
+        uint32_t m8 = 0;
+        bool done = false;  // the length at p is known this turn
+        if (c == 0u) {
+          const uint32_t bit = 1u << (p - lo);
+          if (known & bit) {
+            m8 = s_mlen[p];
+            done = true;
+          } else {
+            known |= bit;
+            uint32_t d = p - wbase;
+            if (d >= 4u) {
+              wr = *reinterpret_cast<const Bytes16*>(raws + p);  // (past the fragment's last position: the pool's next bytes, unused)
+              wbase = p;
+              d = 0;
+            }
+            if (p + 16u <= n) c = candidate(p, d == 0u ? wr.x : d == 1u ? wr.y : d == 2u ? wr.z : wr.w);
+            if (c == 0u) {
+              s_mlen[p] = 0;
+              done = true;
+            } else {
+              m = 0;
+              lim = n - p < 258u ? n - p : 258u;  // (>= 16 here)
+            }
           }
-          const uint32_t m = eval(p, d == 0u ? wr.x : d == 1u ? wr.y : d == 2u ? wr.z : wr.w);
-          m8 = m ? m - 3u : 0u;
-          s_mlen[p] = (uint8_t)m8;
-          known |= bit;
         }
-        p += m8 ? m8 + 3u : 1u;
+        if (c != 0u) {  // 16 bytes: both streams as aligned dwords shifted into place
+          const uint32_t ab = p + m + mis, bb = c + m + mis, as = ab & 3u, bs = bb & 3u;
+          const uint32_t* ap = s_src + (ab >> 2);
+          const uint32_t* bp = s_src + (bb >> 2);
+          uint32_t x[4];
+#pragma unroll
+          for (uint32_t i = 0; i < 4; i++)
+            x[i] = __builtin_amdgcn_alignbyte(ap[i + 1], ap[i], as) ^ __builtin_amdgcn_alignbyte(bp[i + 1], bp[i], bs);
+          uint32_t d = 16;
+#pragma unroll
+          for (uint32_t i = 4; i-- > 0;)
+            if (x[i]) d = 4u * i + (((uint32_t)__ffs((int)x[i]) - 1u) >> 3);
+          m += d;
+          if (d < 16u || m >= lim) {
+            if (m > lim) m = lim;
+            m8 = m < 4u ? 0u : m - 3u;
+            s_mlen[p] = (uint8_t)m8;
+            c = 0;
+            done = true;
+          }
+        }
+        if (done) p += m8 ? m8 + 3u : 1u;
       }
       return p;
     };
