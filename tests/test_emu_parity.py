@@ -98,6 +98,31 @@ def test_emu_lds_order_probe(eng):
     assert r.returncode == 0, r.stderr[-2000:]
 
 
+def test_emu_scratch_budget_forced_low():
+    """ZH_SCRATCH_MB=1: the chain levels' scratch holds one deflate block at a time and the split decoder's token
+    pool a few streams at a time -- device-resident plans run their kernels over ranges of the batch, one after
+    the other through the same scratch; same bytes out (a switch read when a plan is made: child process)."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import emu, oracle, parity_cases as pc, synth\n"
+            "from test_emu_parity import _chain_inputs\n"
+            "eng = emu.engine()\n"
+            "mixed, two_blocks = _chain_inputs()\n"
+            "pc.check_compress_identical(eng, [two_blocks, mixed[:90000], b'', mixed[:40000]], levels=(-1,), formats=(oracle.dfGzip,))\n"
+            "pc.check_tokens(eng, two_blocks, -1)\n"
+            "bufs = [b.tobytes() for b in synth.gen_batch('mix', 14, 70001)] + [b'', two_blocks[:300000]]\n"
+            "for mode in (0, 1):\n"
+            "    eng.set_inflate_mode(mode)\n"
+            "    pc.check_roundtrip(eng, bufs, 1)\n"
+            "    pc.check_errors_match_oracle(eng, pc.mutated_fixtures(12, seed=5, max_len=40000))\n"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZH_SCRATCH_MB="1", ZH_PIPE_MIN=str(1 << 60)),
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
 def test_emu_multi_block_buffer(eng):
     # > 4 MiB: two deflate blocks in one buffer (deflate.nim:228-237); runs/zeros keep it fast
     src = (b"\x00" * 3000000 + synth.gen_batch("runs", 1, 1300000)[0].tobytes())

@@ -45,6 +45,34 @@ def test_gpu_damaged_headers(eng, inflate_mode):
     pc.check_damaged_headers(eng)
 
 
+def test_gpu_scratch_budget_forced_low():
+    """ZH_SCRATCH_MB=64 (read when a plan is made: child process): 24 x 1 MiB at DefaultCompression need 288 MiB of
+    chain scratch and run as ranges of five blocks; 48 x 1 MiB streams need 200 MiB of token records and decode
+    as groups of streams -- through the same scratch, one after the other; same bytes as the oracle's."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch; torch.cuda.init()\n"
+            "import oracle, parity_cases as pc, synth\n"
+            "from zippy_amd import api\n"
+            "eng = api.engine(); eng.set_gzip_fname_len(0)\n"
+            "bufs = [b.tobytes() for b in synth.gen_batch('mix', 24, 1 << 20)]\n"
+            "outs, sts = eng.compress_batch(bufs, -1, oracle.dfGzip)\n"
+            "assert all(s == 0 for s in sts)\n"
+            "for i in (0, 4, 5, 11, 23):\n"
+            "    assert outs[i] == oracle.compress(bufs[i], -1, oracle.dfGzip, fname_len=0), i\n"
+            "more = [b.tobytes() for b in synth.gen_batch('mix', 48, 1 << 20)]\n"
+            "blobs, sts = eng.compress_batch(more, 1, oracle.dfGzip)\n"
+            "back, sts = eng.uncompress_batch(blobs + outs, oracle.dfGzip)\n"
+            "assert all(s == 0 for s in sts) and back == more + bufs\n" % (here, os.path.dirname(here)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZH_SCRATCH_MB="64", ZH_PIPE_MIN=str(1 << 60), ZH_TRACE="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "ranges of blocks" in r.stderr and "groups of streams" in r.stderr, r.stderr[-2000:]
+
+
 def test_gpu_fixtures_decode(eng, inflate_mode):
     pc.check_fixtures(eng)
 

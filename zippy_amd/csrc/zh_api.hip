@@ -335,6 +335,19 @@ struct Arena {
   }
 };
 
+// Device-resident plans keep their per-position scratch -- the chain levels' links and best matches (12 bytes a
+// position), the split decoder's token records (4 bytes an output byte) -- for at most this many bytes at a time;
+// a batch that needs more runs those kernels over ranges of its blocks / streams, one range after the other
+// through the same scratch (same bytes out).  ZH_SCRATCH_MB (default 16384; the tests force it low).
+static uint64_t scratch_budget() {
+  const char* e = getenv("ZH_SCRATCH_MB");
+  const uint64_t mb = e ? strtoull(e, nullptr, 10) : 16384ull;
+  return (mb ? mb : 1ull) << 20;
+}
+
+struct ZhPlanRange {
+  uint32_t b0, nb, f0, nf;
+};
 struct zh_plan {
   zh_ctx* ctx = nullptr;
   bool is_compress = true;
@@ -359,6 +372,14 @@ struct zh_plan {
   // did not get as far (a launch that failed between the scatter and the links) leaves it dirty, and the next
   // run clears it before anything reads it
   bool chain_best_dirty = false;
+  // chain levels: the ranges of blocks (first block, blocks, first fragment, fragments) that share the scratch in turn
+  struct ChainRange {
+    uint32_t b0, nb, f0, nf;
+  };
+  std::vector<ChainRange> chain_ranges;
+  size_t chain_scratch_frags = 0;  // fragments the scratch holds (the largest range)
+  // split inflate: the groups of streams (first, count) that share the token pool in turn
+  std::vector<std::pair<uint32_t, uint32_t>> tok_groups;
   uint64_t dst_lo = 0, dst_hi = 0;  // byte range of d_dst covered by the slots
   bool dst_dense = true;            // the slots tile [dst_lo, dst_hi) without gaps
   uint64_t dst_max_cap = 0;
@@ -550,9 +571,36 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
                o_bst = ar.reserve((nb + n) * 8);
   const size_t o_bcrc = ar.reserve(n * 4), o_bad = ar.reserve(n * 4), o_olen = ar.reserve(n * 8),
                o_st = ar.reserve(n * 4);
+  // chain levels: ranges of whole blocks whose scratch (12 bytes a position + the links' tables) fits the budget
+  size_t range_blocks = 0, range_frags = 0;
+  if (chain && nb) {
+    const uint64_t per_frag = (uint64_t)ZH_FRAG_SIZE * 12u, per_block = (uint64_t)ZH_CHAIN_HEAD_WORDS * 4u;
+    const uint64_t budget = scratch_budget();
+    ZhPlanRange cur{0, 0, 0, 0};
+    uint64_t cur_bytes = 0;
+    for (size_t b = 0; b < nb; b++) {
+      const uint64_t need = blocks[b].nfrag * per_frag + per_block;
+      if (cur.nb && cur_bytes + need > budget) {
+        p->chain_ranges.push_back({cur.b0, cur.nb, cur.f0, cur.nf});
+        cur = ZhPlanRange{(uint32_t)b, 0, blocks[b].first_frag, 0};
+        cur_bytes = 0;
+      }
+      cur.nb++;
+      cur.nf += blocks[b].nfrag;
+      cur_bytes += need;
+    }
+    p->chain_ranges.push_back({cur.b0, cur.nb, cur.f0, cur.nf});
+    for (const auto& r : p->chain_ranges) {
+      range_blocks = std::max<size_t>(range_blocks, r.nb);
+      range_frags = std::max<size_t>(range_frags, r.nf);
+    }
+  }
+  p->chain_scratch_frags = range_frags;
+  if (p->chain_ranges.size() > 1 && getenv("ZH_TRACE"))
+    fprintf(stderr, "zippy_hip: chain scratch for %zu of %zu fragments: %zu ranges of blocks\n", range_frags, nf, p->chain_ranges.size());
   p->head_bytes = !chain ? 0
-                  : nb <= zh_chain_prev_slice() ? nb * ((size_t)ZH_CHAIN_HEAD_WORDS * 4)
-                                                : nb * ((size_t)2 << 17);  // (zh_launch_chain_prev)
+                  : range_blocks <= zh_chain_prev_slice() ? range_blocks * ((size_t)ZH_CHAIN_HEAD_WORDS * 4)
+                                                          : range_blocks * ((size_t)2 << 17);  // (zh_launch_chain_prev)
   const size_t o_head = ar.reserve(p->head_bytes);
   // one 32 KiB hash table per persistent matcher wave (zh_launch_l1_match: min(fragments, slots) waves)
   // (the parallel parse, zh_launch_l1p_match, keeps 128 KiB of table results per workgroup there instead)
@@ -560,8 +608,8 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
                                                           std::min<size_t>(nf, zh_l1p_slots()) * 131072)
                                                : 0);
   const size_t o_l1ctr = ar.reserve(256);
-  const size_t o_cprev = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 8 : 0);
-  const size_t o_cbest = ar.reserve(chain ? nf * (size_t)ZH_FRAG_SIZE * 4 : 0);
+  const size_t o_cprev = ar.reserve(chain ? range_frags * (size_t)ZH_FRAG_SIZE * 8 : 0);
+  const size_t o_cbest = ar.reserve(chain ? range_frags * (size_t)ZH_FRAG_SIZE * 4 : 0);
   ar.reserve(256);
 
   if (ctx_malloc(p->ctx, (void**)&p->arena, ar.size) != hipSuccess) {
@@ -586,7 +634,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   chk(hipMemsetAsync(base + o_fex, 0, nf * 4, s));
   // best[] starts out all "not worked out" -- once: every run leaves it that way again (the links kernel
   // clears the sorted positions it has borrowed the array for, zh_chain_class_links_kernel)
-  if (chain && nf) chk(hipMemsetAsync(base + o_cbest, 0, nf * (size_t)ZH_FRAG_SIZE * 4, s));
+  if (chain && nf) chk(hipMemsetAsync(base + o_cbest, 0, range_frags * (size_t)ZH_FRAG_SIZE * 4, s));
   chk(hipStreamSynchronize(s));  // host vectors go out of scope
   if (up != hipSuccess) {
     ctx->last_error = std::string("plan upload: ") + hipGetErrorString(up);
@@ -899,6 +947,29 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
     twords += tcap[i] + 1024;  // (the writer reads whole batches of records, up to 640 behind the last)
   }
   plan_segments(p, bufs, &twords);
+  if (!p->segmented && n) {
+    // groups of streams whose token regions fit the scratch budget share the pool in turn (zh_plan_run); a
+    // stream's region is then counted from its group's first
+    const uint64_t budget_words = scratch_budget() / 4;
+    uint64_t gwords = 0, gmax = 0;
+    uint32_t g0 = 0;
+    for (size_t i = 0; i < n; i++) {
+      const uint64_t need = tcap[i] + 1024;
+      if (i > g0 && gwords + need > budget_words) {
+        p->tok_groups.push_back({g0, (uint32_t)(i - g0)});
+        gmax = std::max(gmax, gwords);
+        g0 = (uint32_t)i;
+        gwords = 0;
+      }
+      toff[i] = gwords;
+      gwords += need;
+    }
+    p->tok_groups.push_back({g0, (uint32_t)(n - g0)});
+    gmax = std::max(gmax, gwords);
+    if (p->tok_groups.size() > 1) twords = gmax;
+    if (p->tok_groups.size() > 1 && getenv("ZH_TRACE"))
+      fprintf(stderr, "zippy_hip: token pool for %zu groups of streams (%zu streams)\n", p->tok_groups.size(), n);
+  }
   p->tok_words = twords + 32768;  // (... and stages them up to 8192 at a time, two stagings ahead)
   hipError_t up = hipMemcpyAsync(base + o_toff, toff.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
   if (up == hipSuccess) up = hipMemcpyAsync(base + o_tcap, tcap.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
@@ -1142,16 +1213,23 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     } else if (p->level != 0) {
       const int* cfg = kChainConfig[p->level == -1 ? 6 : p->level];
       if (p->chain_best_dirty)
-        ZH_HIP(ctx, hipMemsetAsync(p->chain_best, 0, (size_t)a.nfrags * ZH_FRAG_SIZE * 4u, s));
+        ZH_HIP(ctx, hipMemsetAsync(p->chain_best, 0, p->chain_scratch_frags * (size_t)ZH_FRAG_SIZE * 4u, s));
       p->chain_best_dirty = true;
-      prof_mark(p, "zh_chain_prev_kernel");
-      zh_launch_chain_prev(s, d_src, a, p->head_scratch, p->chain_prev, p->chain_best);
-      ZH_HIP(ctx, hipGetLastError());
-      prof_mark(p, "zh_chain_walk_kernel");
-      zh_launch_chain_search(s, d_src, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
-      prof_mark(p, "zh_chain_select_kernel");
-      zh_launch_chain_select(s, d_src, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
-      ZH_HIP(ctx, hipGetLastError());
+      for (const auto& r : p->chain_ranges) {  // (one range unless the scratch budget says otherwise)
+        ZhCompressArgs ar = a;
+        ar.first_block = r.b0;
+        ar.nblocks = r.nb;
+        ar.first_frag = r.f0;
+        ar.nfrags = r.nf;
+        prof_mark(p, "zh_chain_prev_kernel");
+        zh_launch_chain_prev(s, d_src, ar, p->head_scratch, p->chain_prev, p->chain_best);
+        ZH_HIP(ctx, hipGetLastError());
+        prof_mark(p, "zh_chain_walk_kernel");
+        zh_launch_chain_search(s, d_src, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+        prof_mark(p, "zh_chain_select_kernel");
+        zh_launch_chain_select(s, d_src, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+        ZH_HIP(ctx, hipGetLastError());
+      }
       p->chain_best_dirty = false;  // (every launch was accepted: the links kernel hands best[] back cleared)
       prof_mark(p, "zh_frag_stats_kernel");
       zh_launch_frag_stats(s, d_src, a);
@@ -1213,10 +1291,22 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       zh_launch_segments_reduce(s, p->seg, a);
     } else if (split) {
       // two kernels: tokens (parallel over each stream), then bytes (zh_inflate_split.hip)
-      prof_mark(p, "zh_inflate_tokens_kernel");
-      zh_launch_inflate_tokens(s, d_src, a1, p->tok_pool, p->tok_off, p->tok_cap);
-      prof_mark(p, "zh_inflate_write_kernel");
-      zh_launch_inflate_write(s, d_src, d_dst, a1, p->tok_pool, p->tok_off);
+      if (p->tok_groups.size() <= 1) {
+        prof_mark(p, "zh_inflate_tokens_kernel");
+        zh_launch_inflate_tokens(s, d_src, a1, p->tok_pool, p->tok_off, p->tok_cap);
+        prof_mark(p, "zh_inflate_write_kernel");
+        zh_launch_inflate_write(s, d_src, d_dst, a1, p->tok_pool, p->tok_off);
+      } else {
+        for (const auto& g : p->tok_groups) {  // the pool holds a group's records at a time
+          ZhInflateArgs ag = a1;
+          ag.first_buf = g.first;
+          ag.nbufs = g.second;
+          prof_mark(p, "zh_inflate_tokens_kernel");
+          zh_launch_inflate_tokens(s, d_src, ag, p->tok_pool, p->tok_off, p->tok_cap);
+          prof_mark(p, "zh_inflate_write_kernel");
+          zh_launch_inflate_write(s, d_src, d_dst, ag, p->tok_pool, p->tok_off);
+        }
+      }
     } else {
       prof_mark(p, "zh_inflate_kernel");
       zh_launch_inflate(s, d_src, d_dst, a1);
@@ -2443,9 +2533,16 @@ extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int lev
     zh_launch_l1_match(s, d_src.p, a, level == -2, p->l1_tables, p->l1_counter);
   } else {
     const int* cfg = kChainConfig[level == -1 ? 6 : level];
-    zh_launch_chain_prev(s, d_src.p, a, p->head_scratch, p->chain_prev, p->chain_best);
-    zh_launch_chain_search(s, d_src.p, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
-    zh_launch_chain_select(s, d_src.p, a, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+    for (const auto& r : p->chain_ranges) {
+      ZhCompressArgs ar = a;
+      ar.first_block = r.b0;
+      ar.nblocks = r.nb;
+      ar.first_frag = r.f0;
+      ar.nfrags = r.nf;
+      zh_launch_chain_prev(s, d_src.p, ar, p->head_scratch, p->chain_prev, p->chain_best);
+      zh_launch_chain_search(s, d_src.p, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+      zh_launch_chain_select(s, d_src.p, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+    }
   }
   const size_t nf = a.nfrags;
   std::vector<uint32_t> nmatch(nf);

@@ -65,7 +65,7 @@ __device__ __forceinline__ void zh_chain_prev_block(const uint8_t* __restrict__ 
   const unsigned lane = zh_lane();
   const uint8_t* src = d_src + bd.src_off;
   const uint32_t block_len = (uint32_t)bd.len;
-  uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  uint64_t* pw = prevw + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   const uint32_t nins = block_len > 4u ? block_len - 4u : 0u;  // positions with pos + 4 < block end
   for (uint32_t i = lane; i < 1024; i += 64) s_cnt[i] = 0;
   zh_wave_sync();
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64) void zh_chain_prev_ldst_kernel(const uint8_t* _
   const uint8_t* src = d_src + bd.src_off;
   const uint32_t block_len = (uint32_t)bd.len;
   uint16_t* head = head_scratch + ((size_t)blockIdx.x << kHashBits);  // zeroed before the launch
-  uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  uint64_t* pw = prevw + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   const uint32_t nins = block_len > 4u ? block_len - 4u : 0u;  // positions with pos + 4 < block end
   for (uint32_t i = lane; i < 1024; i += 64) s_cnt[i] = 0;
   zh_wave_sync();
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64 * kClsWaves) void zh_chain_class_kernel(const ui
   const unsigned lane = zh_lane();
   const uint32_t wv = threadIdx.x >> 6;
   constexpr uint32_t kGroups = kUnitsPerFrag / kClsWaves;  // workgroups a fragment
-  const uint32_t f = blockIdx.x / kGroups;
+  const uint32_t f = a.first_frag + blockIdx.x / kGroups;
   const uint32_t unit_in_frag = (blockIdx.x % kGroups) * kClsWaves + wv;
   const ZhFragDesc fd = a.frags[f];
   if (unit_in_frag * kUnit >= fd.len) return;
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(64 * kClsWaves) void zh_chain_class_kernel(const ui
   const uint32_t block_len = (uint32_t)bd.len;
   const uint32_t nins = block_len > 4u ? block_len - 4u : 0u;  // positions with pos + 4 < block end
   const uint32_t unit = (f - bd.first_frag) * kUnitsPerFrag + unit_in_frag;  // of the block
-  uint32_t* cls = cls_scratch + (size_t)fd.block * kClsStride + (size_t)unit * kClasses;
-  uint32_t* list = lists + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  uint32_t* cls = cls_scratch + (size_t)(fd.block - a.first_block) * kClsStride + (size_t)unit * kClasses;
+  uint32_t* list = lists + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   if (lane < kClasses) s_c[wv][lane] = kScatter ? cls[lane] : 0u;
   zh_wave_sync();
   for (uint32_t r = 0; r < kUnit / 64u; r++) {
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(512) void zh_chain_class_scan_kernel(ZhCompressArgs
   __shared__ uint32_t s_tot[kClasses];
   const unsigned lane = zh_lane();
   const uint32_t wv = threadIdx.x >> 6;
-  const ZhBlockDesc bd = a.blocks[blockIdx.x];
+  const ZhBlockDesc bd = a.blocks[a.first_block + blockIdx.x];
   const uint32_t block_len = (uint32_t)bd.len;
   const uint32_t nins = block_len > 4u ? block_len - 4u : 0u;
   const uint32_t units = (nins + kUnit - 1u) / kUnit;
@@ -316,16 +316,16 @@ __global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t*
   // (the classes of a block on ONE XCD: their stores fill the same lines of prevw)
   const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   if (bid >= ngroups) return;
-  const uint32_t b = bid >> kClassBits, c = bid & (kClasses - 1u);
-  const ZhBlockDesc bd = a.blocks[b];
+  const uint32_t b = bid >> kClassBits, c = bid & (kClasses - 1u);  // (b: of the range)
+  const ZhBlockDesc bd = a.blocks[a.first_block + b];
   const uint8_t* src = d_src + bd.src_off;
   const uint32_t block_len = (uint32_t)bd.len;
   const uint32_t* cls = cls_scratch + (size_t)b * kClsStride;
   const uint32_t n = cls[kClsInfo + kClasses + c];
   if (!n) return;
-  uint32_t* list_rw = lists + (size_t)bd.first_frag * ZH_FRAG_SIZE + cls[kClsInfo + c];
+  uint32_t* list_rw = lists + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE + cls[kClsInfo + c];
   const uint32_t* list = list_rw;
-  uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  uint64_t* pw = prevw + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   for (uint32_t i = lane; i < kSlots; i += 64) s_head[i] = 0;
   zh_wave_sync();
   // the eight bytes at a listed position (zeros behind the block's end); every load is unconditional
@@ -455,8 +455,8 @@ __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __r
   if (local >= fd.len) return;
   const ZhBlockDesc bd = a.blocks[fd.block];
   const uint32_t pos = (f - bd.first_frag) * ZH_FRAG_SIZE + local;  // block-relative
-  const uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
-  best[(size_t)bd.first_frag * ZH_FRAG_SIZE + pos] =
+  const uint64_t* pw = prevw + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
+  best[(size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE + pos] =
       kBestKnown | zh_chain_search_one(d_src + bd.src_off, pw, pos, (uint32_t)bd.len, good, nice, max_chain);
 }
 
@@ -491,8 +491,8 @@ __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8
   const ZhBlockDesc bd = a.blocks[fd.block];
   const uint8_t* src = d_src + bd.src_off;
   const uint32_t block_len = (uint32_t)bd.len;
-  const uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
-  uint32_t* bst = best + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  const uint64_t* pw = prevw + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
+  uint32_t* bst = best + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   const uint32_t nmain = block_len > 4u ? block_len - 4u : 0u;  // lz77.nim:74-76: behind it only literals
   uint32_t pos = (f - bd.first_frag) * ZH_FRAG_SIZE + local;    // block-relative
   // a walk goes on behind its chunk until it meets a position that is worked out -- or 16 384 positions at
@@ -654,10 +654,10 @@ __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8
 __global__ __launch_bounds__(64) void zh_chain_select_kernel(ZhCompressArgs a,
                                                              const uint32_t* __restrict__ best) {
   const unsigned lane = zh_lane();
-  const uint32_t b = blockIdx.x;
+  const uint32_t b = a.first_block + blockIdx.x;
   const ZhBlockDesc bd = a.blocks[b];
   const uint32_t block_len = (uint32_t)bd.len;
-  const uint32_t* bst = best + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  const uint32_t* bst = best + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
 
   uint32_t cur_frag = 0, frag_matches = 0;  // fragment currently receiving matches
   auto close_frags_until = [&](uint32_t frag) {  // publish counts of fragments [cur_frag, frag)
@@ -725,12 +725,12 @@ __global__ __launch_bounds__(256) void zh_chain_select_par_kernel(const uint8_t*
   __shared__ uint32_t s_wsum[kT / 64];
   const uint32_t tid = threadIdx.x;
   const unsigned lane = zh_lane();
-  const uint32_t b = blockIdx.x;
+  const uint32_t b = a.first_block + blockIdx.x;
   const ZhBlockDesc bd = a.blocks[b];
   const uint32_t block_len = (uint32_t)bd.len;
-  uint32_t* bst = best + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  uint32_t* bst = best + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   const uint8_t* src = d_src + bd.src_off;
-  const uint64_t* pw = prevw + (size_t)bd.first_frag * ZH_FRAG_SIZE;
+  const uint64_t* pw = prevw + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   // lz77.nim:54-56,74-76: the last four positions (and blocks of <= 4 bytes) are literals
   const uint32_t nmain = block_len > 4u ? block_len - 4u : 0u;
   uint32_t entry = 0;  // block-relative position at which the walk enters the next fragment
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(64) void zh_frag_stats_kernel(const uint8_t* __rest
   __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
   __shared__ uint32_t s_cover[ZH_FRAG_SIZE / 32];
   const unsigned lane = zh_lane();
-  const uint32_t f = blockIdx.x;
+  const uint32_t f = a.first_frag + blockIdx.x;
   const ZhFragDesc fd = a.frags[f];
   const uint32_t n = fd.len;
   const uint8_t* src = d_src + fd.src_off;
@@ -1038,13 +1038,13 @@ extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, Z
   const uint32_t slice = zh_chain_prev_slice();
   if (a.nblocks <= slice) {
     (void)hipMemsetAsync(head_scratch, 0, (size_t)a.nblocks * ZH_CHAIN_HEAD_WORDS * 4u, stream);
-    hipLaunchKernelGGL(zh_chain_prev_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a, head_scratch, prevw, 0u);
+    hipLaunchKernelGGL(zh_chain_prev_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a, head_scratch, prevw, a.first_block);
     return;
   }
   // (all blocks at once: this form lives on the number of loads in flight)
   (void)hipMemsetAsync(head_scratch, 0, (size_t)a.nblocks << (kHashBits + 1), stream);
   hipLaunchKernelGGL(zh_chain_prev_ldst_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a,
-                     reinterpret_cast<uint16_t*>(head_scratch), prevw, 0u);
+                     reinterpret_cast<uint16_t*>(head_scratch), prevw, a.first_block);
 }
 // ZH_CHAIN_SEARCH=dense: the best match of EVERY position (kernel 2a) instead of the walks of kernel
 // 2b; ZH_CHAIN_SELECT=serial (one wave per block, needs the dense search): cross-checks and measurement
@@ -1072,7 +1072,7 @@ extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src,
     const uint32_t nf = a.nfrags - f0 < kSlice ? a.nfrags - f0 : kSlice;
     if (chain_search_dense()) {
       hipLaunchKernelGGL(zh_chain_search_kernel, dim3(nf * (ZH_FRAG_SIZE / 256u)), dim3(256), 0, stream,
-                         d_src, a, good, nice, max_chain, prevw, best, f0);
+                         d_src, a, good, nice, max_chain, prevw, best, a.first_frag + f0);
     } else {
       // (nothing is worked out yet -- the walks of one launch may look at the next launch's entries --: the
       // class-sorted links have left best[] cleared; after the in-order kernels it still holds the last run's)
@@ -1080,7 +1080,7 @@ extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src,
       constexpr uint32_t kChunk = 32;
       const uint32_t ng = nf * (ZH_FRAG_SIZE / kChunk / kWalkThreads);
       hipLaunchKernelGGL(zh_chain_walk_kernel<kChunk>, dim3((ng + 7u) & ~7u), dim3(kWalkThreads), 0, stream, d_src, a, good,
-                         nice, max_chain, prevw, best, f0, ng);
+                         nice, max_chain, prevw, best, a.first_frag + f0, ng);
     }
   }
 }

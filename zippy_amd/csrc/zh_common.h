@@ -57,6 +57,11 @@ struct ZhCompressArgs {
   const ZhBufDesc* bufs;
   uint32_t nfrags, nblocks, nbufs;
   int32_t level, data_format;
+  // The chain levels' kernels run on a RANGE of the plan's blocks at a time when their scratch (12 bytes a
+  // position) is smaller than the batch: blocks first_block .. first_block + nblocks - 1 = fragments first_frag ..
+  // first_frag + nfrags - 1; the scratch is indexed from the range's first block / fragment, everything else
+  // by the plan's own numbers.  (0, 0 and the plan's counts everywhere else.)
+  uint32_t first_block, first_frag;
   // per fragment, written by the matcher
   uint16_t* m_pos;   // [nfrags][8192] match start, relative to the fragment
   uint16_t* m_len;   // [nfrags][8192] 4..258 (5..258 for the chain levels)
@@ -113,6 +118,9 @@ struct ZhInflateArgs {
   int32_t single_block;          // stop after one block whatever BFINAL says
   // split decode: streams whose flag is set were decoded segment-wise (ZhSegArgs) and are left alone
   const uint32_t* skip;
+  // split decode: the launch covers streams first_buf .. first_buf + nbufs - 1 (the token pool holds a group of
+  // streams at a time when it is smaller than the batch; 0 and the plan's count otherwise)
+  uint32_t first_buf;
 };
 
 // One large stream decoded by many workgroups (zh_inflate_seg.hip).  The compressed bytes are cut

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
 
   const uint32_t tid = threadIdx.x;
   const unsigned lane = zh_lane();
-  const uint32_t sid = blockIdx.x;                    // token region (a stream, or a segment of one)
+  const uint32_t sid = kSeg ? blockIdx.x : a.first_buf + blockIdx.x;  // token region (a stream, or a segment of one)
   const uint32_t bid = kSeg ? g.parent[sid] : sid;   // the stream
   if (a.status[bid] != ZH_OK) return;  // unwrap already failed this stream
   if (!kSeg && a.skip && a.skip[sid]) return;  // decoded segment-wise
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
   Sym* const s_val = reinterpret_cast<Sym*>(s_val32);
   const uint32_t tid = threadIdx.x, wv = tid >> 6;
   const unsigned lane = zh_lane();
-  const uint32_t sid = blockIdx.x;
+  const uint32_t sid = kSeg ? blockIdx.x : a.first_buf + blockIdx.x;
   const uint32_t bid = kSeg ? g.parent[sid] : sid;
   if (a.status[bid] != ZH_OK) return;
   if (kSeg ? !g.valid[sid] : (a.skip && a.skip[sid])) return;
