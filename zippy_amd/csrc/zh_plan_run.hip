@@ -1,0 +1,325 @@
+// Host side of the C ABI: running a plan -- kernel sequencing on the context's stream, the per-context
+// switches, the token pool, per-kernel timing, results.
+#include "zh_host.h"
+
+static void prof_mark(zh_plan* p, const char* name) {
+  if (!p->profiling) return;
+  size_t i = p->k_names.size();
+  if (p->k_events.size() <= i) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) {  // no timing rather than a failed run
+      p->profiling = false;
+      return;
+    }
+    p->k_events.push_back(e);
+  }
+  if (hipEventRecord(p->k_events[i], p->ctx->stream) != hipSuccess) {
+    p->profiling = false;
+    return;
+  }
+  p->k_names.push_back(name);
+}
+
+extern "C" void zh_plan_set_profiling(zh_plan* plan, int on) {
+  if (plan) plan->profiling = on != 0;
+}
+
+extern "C" int zh_plan_kernel_times(zh_plan* p, const char** names, float* ms, int max_entries) {
+  if (!p || !p->profiling || p->k_names.size() < 2) return 0;
+  if (hipStreamSynchronize(p->ctx->stream) != hipSuccess) return 0;
+  int cnt = 0;
+  for (size_t i = 0; i + 1 < p->k_names.size() && cnt < max_entries; i++) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, p->k_events[i], p->k_events[i + 1]) != hipSuccess) break;
+    names[cnt] = p->k_names[i];  // the marker recorded BEFORE a launch carries its name
+    ms[cnt] = t;
+    cnt++;
+  }
+  return cnt;
+}
+
+extern "C" void zh_plan_destroy(zh_plan* p) {
+  if (!p) return;
+  // (nothing useful can be done about a failure while tearing down)
+  (void)hipStreamSynchronize(p->ctx->stream);
+  if (p->arena) ctx_free(p->ctx, p->arena);
+  if (p->seg_arena) ctx_free(p->ctx, p->seg_arena);
+  if (p->tok_pool && !p->tok_borrowed) ctx_free(p->ctx, p->tok_pool);
+  if (p->sg_arena) ctx_free(p->ctx, p->sg_arena);
+  if (p->sg_sym) ctx_free(p->ctx, p->sg_sym);
+  if (p->sg_windows) ctx_free(p->ctx, p->sg_windows);
+  if (p->sg_winsym) ctx_free(p->ctx, p->sg_winsym);
+  for (auto e : p->k_events) (void)hipEventDestroy(e);
+  delete p;
+}
+
+
+// ZH_INFLATE=serial keeps every stream on the two-wave serial decoder (zh_inflate.hip); the
+// default decodes a stream's Huffman codes in parallel (zh_inflate_split.hip).  Sizing passes and
+// the block-parallel form of one stream always use the serial kernel.
+bool inflate_split_enabled(const zh_ctx* ctx) {
+  static const bool on = [] {
+    const char* e = getenv("ZH_INFLATE");
+    return !(e && strcmp(e, "serial") == 0);
+  }();
+  return ctx->inflate_mode < 0 ? on : ctx->inflate_mode == 0;
+}
+// BestSpeed parse: 0 the reference's (snappy.nim:12-136, byte-identical streams), 1 the parallel
+// parse of zh_l1p_match.hip (valid streams of about the same size, not the reference's bytes)
+bool l1_parallel(const zh_ctx* ctx) {
+  static const bool on = [] {
+    const char* e = getenv("ZH_L1_PARSE");
+    return e && strcmp(e, "parallel") == 0;
+  }();
+  return ctx->l1_parse < 0 ? on : ctx->l1_parse == 1;
+}
+extern "C" void zh_set_l1_parse(zh_ctx* ctx, int mode) {
+  if (ctx) ctx->l1_parse = mode < 0 ? -1 : mode ? 1 : 0;
+}
+extern "C" void zh_set_inflate_mode(zh_ctx* ctx, int mode) {
+  if (ctx) ctx->inflate_mode = mode < 0 ? -1 : mode ? 1 : 0;
+}
+// the token pool of a plan, allocated when it first runs in split mode; a failed allocation
+// (it is several times the output) sends the plan to the serial kernel for good
+bool plan_token_pool(zh_plan* p) {
+  if (!p->tok_pool) {
+    if (p->tok_failed || !p->tok_words) return false;
+    if (ctx_malloc(p->ctx, (void**)&p->tok_pool, p->tok_words * 4) != hipSuccess) {
+      (void)hipGetLastError();
+      p->tok_pool = nullptr;
+      p->tok_failed = true;
+      // not an error (the serial decoder gives the same bytes), but several times slower: leave a note
+      p->ctx->last_error = "note: no memory for a token pool of " + std::to_string(p->tok_words * 4) +
+                           " bytes; this plan decodes with the serial kernel (zh_inflate_kernel)";
+      if (getenv("ZH_TRACE")) fprintf(stderr, "zippy_hip: %s\n", p->ctx->last_error.c_str());
+      return false;
+    }
+  }
+  if (p->segmented && !p->sg_sym) {  // without its buffers the plan simply is not segmented
+    if (ctx_malloc(p->ctx, (void**)&p->sg_sym, p->sg_sym_count * 2) != hipSuccess ||
+        ctx_malloc(p->ctx, (void**)&p->sg_windows, (size_t)p->sg.nsegs * 32768u) != hipSuccess ||
+        ctx_malloc(p->ctx, (void**)&p->sg_winsym, (size_t)p->sg.nsegs * 65536u) != hipSuccess) {
+      (void)hipGetLastError();
+      if (p->sg_sym) ctx_free(p->ctx, p->sg_sym);
+      if (p->sg_windows) ctx_free(p->ctx, p->sg_windows);
+      p->sg_sym = nullptr;
+      p->sg_windows = nullptr;
+      p->sg_winsym = nullptr;
+      p->segmented = false;
+      p->ctx->last_error = "note: no memory for the segment-wise decode's buffers; large streams of this plan "
+                           "are decoded by one workgroup each";
+      if (getenv("ZH_TRACE")) fprintf(stderr, "zippy_hip: %s\n", p->ctx->last_error.c_str());
+    } else {
+      p->sg.sym = p->sg_sym;
+      p->sg.windows = p->sg_windows;
+      p->sg.winsym = p->sg_winsym;
+    }
+  }
+  return true;
+}
+// A token pool that outlives the plan and is shared with other plans whose kernels run on the same
+// stream one after the other (the pool is scratch of a run: tokens kernel -> writer).
+void plan_lend_token_pool(zh_plan* p, uint32_t* pool, uint64_t words) {
+  if (p->tok_pool || p->tok_failed || !p->tok_words || p->tok_words > words) return;
+  p->tok_pool = pool;
+  p->tok_borrowed = true;
+}
+
+// Output slots start out zeroed (every shared output word is OR-ed into place).  Slots that tile
+// one range are cleared with a single memset; slots with gaps between them are cleared one by
+// one, byte-exact, so that caller data lying between two slots is never touched.
+__global__ __launch_bounds__(256) void zh_zero_slots_kernel(uint8_t* __restrict__ d_dst,
+                                                            const ZhBufDesc* __restrict__ bufs,
+                                                            uint32_t parts) {
+  // `parts` workgroups share a slot
+  const uint32_t part = blockIdx.x % parts;
+  const ZhBufDesc b = bufs[blockIdx.x / parts];
+  uint8_t* const base = d_dst + b.dst_off;
+  const uint64_t cap = b.dst_cap;
+  uint64_t head = (16u - ((uintptr_t)base & 15u)) & 15u;
+  if (head > cap) head = cap;
+  const uint64_t nvec = (cap - head) >> 4;
+  uint4* const body = reinterpret_cast<uint4*>(base + head);
+  for (uint64_t i = (uint64_t)part * 256u + threadIdx.x; i < nvec; i += (uint64_t)parts * 256u)
+    body[i] = make_uint4(0, 0, 0, 0);
+  if (part == 0) {
+    if (threadIdx.x < head) base[threadIdx.x] = 0;
+    const uint64_t t0 = head + (nvec << 4);
+    if (t0 + threadIdx.x < cap) base[t0 + threadIdx.x] = 0;
+  }
+}
+
+extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
+  if (!p) return ZH_ERR_ARGUMENT;
+  zh_ctx* ctx = p->ctx;
+  hipStream_t s = ctx->stream;
+  const uint8_t* d_src = (const uint8_t*)d_src_v;
+  uint8_t* d_dst = (uint8_t*)d_dst_v;
+  p->k_names.clear();
+  if (!p->n) return ZH_OK;
+  if (p->is_compress) {
+    const ZhCompressArgs& a = p->ca;
+    const int want_crc = p->fmt == ZH_DF_GZIP || p->force_crc, want_adler = p->fmt == ZH_DF_ZLIB;
+    // every shared output word is OR-ed into place, so the slots start out zeroed
+    // zh_emit_kernel and zh_layout_kernel address the output as aligned 32-bit words
+    if ((uintptr_t)d_dst & 3u) return ZH_ERR_ARGUMENT;
+    prof_mark(p, "memset_dst");
+    if (p->dst_dense) {
+      ZH_HIP(ctx, hipMemsetAsync(d_dst + p->dst_lo, 0, p->dst_hi - p->dst_lo, s));
+    } else {
+      uint32_t gy = (uint32_t)std::min<uint64_t>(64, (p->dst_max_cap >> 16) + 1);
+      while (gy > 1 && (uint64_t)p->n * gy > 0x7fffffffull) gy >>= 1;  // (a grid has fewer than 2^31 workgroups)
+      if ((uint64_t)p->n * gy > 0x7fffffffull) return ZH_ERR_ARGUMENT;
+      hipLaunchKernelGGL(zh_zero_slots_kernel, dim3((uint32_t)p->n * gy), dim3(256), 0, s, d_dst, p->d_bufs, gy);
+      ZH_HIP(ctx, hipGetLastError());
+    }
+    if (p->level == 1 && l1_parallel(ctx)) {
+      prof_mark(p, "zh_l1p_match_kernel");
+      zh_launch_l1p_match(s, d_src, a, p->l1_tables, p->l1_counter);
+    } else if (p->level == 1 || p->level == -2) {
+      prof_mark(p, "zh_l1_match_kernel");
+      zh_launch_l1_match(s, d_src, a, p->level == -2, p->l1_tables, p->l1_counter);
+    } else if (p->level != 0) {
+      const int* cfg = kChainConfig[p->level == -1 ? 6 : p->level];
+      if (p->chain_best_dirty)
+        ZH_HIP(ctx, hipMemsetAsync(p->chain_best, 0, p->chain_scratch_frags * (size_t)ZH_FRAG_SIZE * 4u, s));
+      p->chain_best_dirty = true;
+      for (const auto& r : p->chain_ranges) {  // (one range unless the scratch budget says otherwise)
+        ZhCompressArgs ar = a;
+        ar.first_block = r.b0;
+        ar.nblocks = r.nb;
+        ar.first_frag = r.f0;
+        ar.nfrags = r.nf;
+        prof_mark(p, "zh_chain_prev_kernel");
+        zh_launch_chain_prev(s, d_src, ar, p->head_scratch, p->chain_prev, p->chain_best);
+        ZH_HIP(ctx, hipGetLastError());
+        prof_mark(p, "zh_chain_walk_kernel");
+        zh_launch_chain_search(s, d_src, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+        prof_mark(p, "zh_chain_select_kernel");
+        zh_launch_chain_select(s, d_src, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+        ZH_HIP(ctx, hipGetLastError());
+      }
+      p->chain_best_dirty = false;  // (every launch was accepted: the links kernel hands best[] back cleared)
+      prof_mark(p, "zh_frag_stats_kernel");
+      zh_launch_frag_stats(s, d_src, a);
+    }
+    if (want_crc || want_adler) {
+      prof_mark(p, "zh_checksum_pieces_kernel");
+      zh_launch_checksum_pieces(s, ctx->cktabs, d_src, p->d_pieces, p->npieces, nullptr, want_crc,
+                                want_adler, p->piece_crc, p->piece_adler, p->piece_len);
+      prof_mark(p, "zh_checksum_combine_kernel");
+      zh_launch_checksum_combine(s, p->d_bufs, (uint32_t)p->n, p->piece_crc, p->piece_adler,
+                                 p->piece_len, want_crc, want_adler, p->buf_crc, p->buf_adler);
+    }
+    prof_mark(p, "zh_huffman_kernel");
+    // (contract mode -- zh_set_l1_parse(ctx, 1), BestSpeed only -- also builds the block's codes without the
+    // replay of the reference's heap: optimal codes, other tie-breaks)
+    zh_launch_huffman(s, a, p->level == 1 && l1_parallel(ctx) ? 1 : 0);
+    prof_mark(p, "zh_layout_kernel");
+    zh_launch_layout(s, d_dst, a, p->buf_crc, p->buf_adler);
+    prof_mark(p, "zh_emit_kernel");
+    zh_launch_emit(s, d_src, d_dst, a);
+    prof_mark(p, "end");
+  } else {
+    const ZhInflateArgs& a = p->ia;
+    prof_mark(p, "zh_unwrap_kernel");
+    zh_launch_unwrap(s, d_src, a);
+    const bool split_ok = !p->indexed && inflate_split_enabled(ctx) && plan_token_pool(p);
+    const bool split = split_ok && !a.count_only;
+    ZhInflateArgs a1 = a;
+    if (split_ok && p->segmented) {
+      // a handful of large streams: many workgroups per stream (zh_inflate_seg.hip); streams whose
+      // chain of segments does not hold are left to the ordinary kernels below.  A sizing pass
+      // stops behind the chain kernel, which knows the output size by then.
+      prof_mark(p, "zh_seg_find_kernel");
+      zh_launch_seg_find(s, d_src, a, p->sg);
+      prof_mark(p, "zh_seg_check_kernel");
+      zh_launch_seg_check(s, d_src, a, p->sg);
+      prof_mark(p, "zh_seg_substart_kernel");
+      zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 0);
+      zh_launch_seg_decide(s, a, p->sg);
+      prof_mark(p, "zh_seg_tokens_kernel");
+      zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 1);
+      prof_mark(p, "zh_seg_chain_kernel");
+      zh_launch_seg_chain(s, a, p->sg);
+      if (!a.count_only) {
+        prof_mark(p, "zh_seg_write_kernel");
+        zh_launch_seg_write(s, d_src, a, p->tok_pool, p->sg);
+        prof_mark(p, "zh_seg_windows_kernel");
+        zh_launch_seg_windows(s, a, p->sg);
+        prof_mark(p, "zh_seg_finish_kernel");
+        zh_launch_seg_finish(s, d_dst, a, p->sg);
+      }
+      a1.skip = p->sg.stream_ok;
+    }
+    if (p->indexed) {
+      prof_mark(p, "zh_inflate_kernel");
+      ZH_HIP(ctx, hipMemsetAsync(p->seg.status, 0, (size_t)p->seg.nbufs * 4, s));
+      zh_launch_inflate(s, d_src, d_dst, p->seg);
+      prof_mark(p, "zh_segments_reduce_kernel");
+      zh_launch_segments_reduce(s, p->seg, a);
+    } else if (split) {
+      // two kernels: tokens (parallel over each stream), then bytes (zh_inflate_split.hip)
+      if (p->tok_groups.size() <= 1) {
+        prof_mark(p, "zh_inflate_tokens_kernel");
+        zh_launch_inflate_tokens(s, d_src, a1, p->tok_pool, p->tok_off, p->tok_cap);
+        prof_mark(p, "zh_inflate_write_kernel");
+        zh_launch_inflate_write(s, d_src, d_dst, a1, p->tok_pool, p->tok_off);
+      } else {
+        for (const auto& g : p->tok_groups) {  // the pool holds a group's records at a time
+          ZhInflateArgs ag = a1;
+          ag.first_buf = g.first;
+          ag.nbufs = g.second;
+          prof_mark(p, "zh_inflate_tokens_kernel");
+          zh_launch_inflate_tokens(s, d_src, ag, p->tok_pool, p->tok_off, p->tok_cap);
+          prof_mark(p, "zh_inflate_write_kernel");
+          zh_launch_inflate_write(s, d_src, d_dst, ag, p->tok_pool, p->tok_off);
+        }
+      }
+    } else {
+      prof_mark(p, "zh_inflate_kernel");
+      zh_launch_inflate(s, d_src, d_dst, a1);
+    }
+    if (!a.count_only) {
+      // both checksums: with dfDetect the format is only known per stream on the device
+      const int want_crc = p->fmt == ZH_DF_GZIP || p->fmt == ZH_DF_DETECT || p->force_crc;
+      const int want_adler = p->fmt == ZH_DF_ZLIB || p->fmt == ZH_DF_DETECT;
+      if (want_crc || want_adler) {
+        prof_mark(p, "zh_checksum_pieces_kernel");
+        zh_launch_checksum_pieces(s, ctx->cktabs, d_dst, p->d_pieces, p->npieces, p->out_len,
+                                  want_crc, want_adler, p->piece_crc, p->piece_adler, p->piece_len);
+        prof_mark(p, "zh_checksum_combine_kernel");
+        zh_launch_checksum_combine(s, p->d_bufs, (uint32_t)p->n, p->piece_crc, p->piece_adler,
+                                   p->piece_len, want_crc, want_adler, p->buf_crc, p->buf_adler);
+        prof_mark(p, "zh_verify_kernel");
+        zh_launch_verify(s, a, p->buf_crc, p->buf_adler);
+      }
+    }
+    prof_mark(p, "end");
+  }
+  ZH_HIP(ctx, hipGetLastError());
+  return ZH_OK;
+}
+
+extern "C" int zh_plan_results(zh_plan* p, uint64_t* out_lens, int32_t* statuses) {
+  if (!p) return ZH_ERR_ARGUMENT;
+  zh_ctx* ctx = p->ctx;
+  if (out_lens) ZH_HIP(ctx, hipMemcpyAsync(out_lens, p->out_len, p->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (statuses) ZH_HIP(ctx, hipMemcpyAsync(statuses, p->status, p->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZH_OK;
+}
+extern "C" int zh_plan_request_crc32(zh_plan* p, int on) {
+  if (!p) return ZH_ERR_ARGUMENT;
+  p->force_crc = on != 0;
+  return ZH_OK;
+}
+extern "C" int zh_plan_crc32(zh_plan* p, uint32_t* crcs) {
+  if (!p || !crcs || !p->buf_crc) return ZH_ERR_ARGUMENT;
+  zh_ctx* ctx = p->ctx;
+  ZH_HIP(ctx, hipMemcpyAsync(crcs, p->buf_crc, p->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZH_OK;
+}
+extern "C" const uint64_t* zh_plan_device_lens(zh_plan* p) { return p ? p->out_len : nullptr; }
+extern "C" const int32_t* zh_plan_device_statuses(zh_plan* p) { return p ? p->status : nullptr; }
