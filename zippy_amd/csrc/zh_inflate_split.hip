@@ -811,6 +811,9 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
 // a 1 MiB stream whatever the batch).  A single copy that does not fit a round goes alone.
 // ---------------------------------------------------------------------------
 // kWrThreads: 256 (batches), 512 (a few hundred streams) or 1024 (up to a stream per CU); a round is kB bytes a thread.
+// (Round 4 measured the same kernel on ONE wave a stream -- 512-byte rounds, no barrier that costs anything, all 4096
+// streams of the bench batch resident at once, 16 a CU --: 15.95 ms against 13.57 on the same box, and 7.8 ms against
+// 2.3 for 512 streams: a round is a chain of ~ 9 000 cycles for a lone wave, and four waves a SIMD do not hide it.)
 // kSeg: a workgroup writes a chain SEGMENT of a stream (zh_inflate_seg.hip) as 16-bit symbols into
 // g.sym: a byte, or -- for a byte copied from the 32 KiB before the segment, which some other
 // workgroup is writing at the same time -- 0x8000 | its index in that window.  Copies of symbols are
