@@ -1029,43 +1029,51 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
     for (uint32_t w = 0; w < kWrWaves; w++)
       if (w < wv) carry = max(carry, s_w[4][w]);
     // ---- every byte: literal, copy from before the round (far), or from inside it (near) ----
+    // Without a branch a byte (under each byte's own condition the compiler kept an exec mask a byte: a hundred
+    // scalar instructions a round), and with the stream's output position in scalar registers -- it is the same in
+    // every thread, but only the hardware knows --, so that a far byte's address is one base for the wave plus a
+    // 32-bit offset a lane: a byte from before the round lies at most 32768 before the byte it makes.
     uint32_t par[kB], val[kB];
-    int64_t far_at[kB];  // where a byte copied from before the round comes from
-    uint32_t far_mask = 0;
-    bool any_near = false;
+    uint32_t far_off[kB];  // where a byte copied from before the round comes from: bytes behind (op - 32768)
+    uint32_t far_mask = 0, near_mask = 0;
+    const uint64_t op_s = (uint64_t)zh_bcast((uint32_t)op) | ((uint64_t)zh_bcast((uint32_t)(op >> 32)) << 32);
+    const Sym* const far_base = reinterpret_cast<const Sym*>(reinterpret_cast<uintptr_t>(dst) + (op_s - 32768u) * sizeof(Sym));
 #pragma unroll
     for (uint32_t j = 0; j < kB; j++) {
       const uint32_t pb = kB * tid + j;       // byte of the round
       const uint32_t tk = max(carry, t[j]);  // its record + 1 (>= 1 for every live byte)
       const uint32_t rec = s_tok[(uint32_t)(ti + tk - 1u) & (kWrRing - 1u)];
-      par[j] = pb;
       // a literal record holds one byte or two: its first at bit 16, the one behind it at bit 24
       val[j] = (rec >> ((starts >> j) & 1u ? 16u : 24u)) & 0xffu;
-      far_at[j] = (int64_t)op;  // (a byte of this stream's slot that is read in vain)
-      if (pb < total && !((rec >> 9) & 1u)) {
-        const uint32_t dist = rec >> 16;
-        if (dist <= pb) {
-          par[j] = pb - dist;
-          any_near = true;
-        } else {
-          far_mask |= 1u << j;
-          far_at[j] = (int64_t)(op + pb) - dist;  // (written before this round: visible since its start)
-        }
-      }
+      const uint32_t dist = rec >> 16;
+      const bool copy = pb < total && !((rec >> 9) & 1u);
+      const bool near = copy && dist <= pb;
+      const bool far = copy && dist > pb;
+      par[j] = near ? pb - dist : pb;
+      far_off[j] = far ? 32768u + pb - dist : 32768u;  // (no far byte: the round's first byte, read in vain)
+      near_mask |= near ? 1u << j : 0u;
+      far_mask |= far ? 1u << j : 0u;
     }
-    // the far bytes of a thread are read TOGETHER: unconditional loads (a lane without one reads the round's
-    // first byte in vain) that are all in flight at once -- under their bytes' conditions the compiler waited
-    // for each of the eight before it issued the next, eight trips to L2 a round
+    const bool any_near = near_mask != 0u;
+    // the far bytes of a thread are read TOGETHER: unconditional loads that are all in flight at once -- under
+    // their bytes' conditions the compiler waited for each of the eight before it issued the next, eight trips
+    // to L2 a round.  (Written before this round: visible since its start.)
     {
       uint32_t got[kB];
+      // segment mode: a byte from before the segment is not there yet: it stays a reference into the window (ld_out's rule)
+      uint32_t before_seg = 0;
+      if (kSeg && op_s < 32768u) {
+#pragma unroll
+        for (uint32_t j = 0; j < kB; j++)
+          before_seg |= ((far_mask >> j) & 1u) && (uint32_t)op_s + far_off[j] < 32768u ? 1u << j : 0u;
+      }
 #pragma unroll
       for (uint32_t j = 0; j < kB; j++)
-        got[j] = __hip_atomic_load(dst + (kSeg && far_at[j] < 0 ? (int64_t)op : far_at[j]), __ATOMIC_RELAXED,
+        got[j] = __hip_atomic_load(far_base + ((before_seg >> j) & 1u ? 32768u : far_off[j]), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (uint32_t j = 0; j < kB; j++)
-        if ((far_mask >> j) & 1u)
-          val[j] = kSeg && far_at[j] < 0 ? 0x8000u | (uint32_t)(32768 + far_at[j]) : got[j];  // (ld_out's rule)
+        if ((far_mask >> j) & 1u) val[j] = (before_seg >> j) & 1u ? 0x8000u | ((uint32_t)op_s + far_off[j]) : got[j];
     }
     if (any_near) s_flag[2u + (round & 1u)] = 1;
 #pragma unroll
