@@ -171,6 +171,26 @@ def own_bytes(N, C):
             "zh_inflate_tokens_kernel": C, "zh_inflate_write_kernel": N, "zh_checksum_pieces_kernel": N}
 
 
+def collect_kernel_times(kms, plans):
+    """One step's entries of zh_plan_kernel_times: a kernel that is launched several times a step (the compress pass
+    of a large batch runs in chunks, csrc/zh_plan_run.hip) is one entry -- (ms of all its launches, launches)."""
+    step = {}
+    for pl in plans:
+        if pl is None:
+            continue
+        for name, ms in pl.kernel_times():
+            t, c = step.get(name, (0.0, 0))
+            step[name] = (t + ms, c + 1)
+    for name, tc in step.items():
+        kms.setdefault(name, []).append(tc)
+
+
+def kernel_averages(kms):
+    """-> ({kernel: ms a step, all launches together}, {kernel: launches a step})"""
+    return ({k: sum(t for t, _ in v) / len(v) for k, v in kms.items()},
+            {k: v[-1][1] for k, v in kms.items()})
+
+
 def time_plans(torch, stream, cplan, uplan, bufs, steps, warmup, verify=None):
     """`warmup` untimed passes (verified by `verify`), then `steps` timed ones with HIP events on
     the launch stream: (compress ms, uncompress ms, per-kernel average ms)."""
@@ -197,13 +217,12 @@ def time_plans(torch, stream, cplan, uplan, bufs, steps, warmup, verify=None):
         ev[2].synchronize()
         tc += ev[0].elapsed_time(ev[1])
         tu += ev[1].elapsed_time(ev[2])
-        for pl in (cplan, uplan):
-            if pl is not None:
-                for name, ms in pl.kernel_times():
-                    kms.setdefault(name, []).append(ms)
+        collect_kernel_times(kms, (cplan, uplan))
     if not steps:
         return 0.0, 0.0, {}
-    return tc / steps, tu / steps, {k: sum(v) / len(v) for k, v in kms.items()}
+    avg, launches = kernel_averages(kms)
+    time_plans.launches = launches  # (of the last call: side_configs / pp_fields read it right behind the call)
+    return tc / steps, tu / steps, avg
 
 
 def side_configs(torch, eng, api, synth, stream, host, steps):
@@ -217,14 +236,16 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
     def entry(workload, nbytes, comp_bytes, tc, tu, kms, pmc_key=None):
         ms = (tc if tc else 0.0) + (tu if tu else 0.0)
         own = own_bytes(nbytes, comp_bytes)
+        launches = dict(getattr(time_plans, "launches", {}))
         dom = max((k for k in kms if k.startswith("zh_")), key=lambda k: kms[k])
+        nl = max(1, launches.get(dom, 1))
         e = {"workload": workload, "value": round(nbytes / GIB / (ms * 1e-3), 3), "unit": "GiB/s",
              "ms_per_step": round(ms, 3), "ratio": round(nbytes / comp_bytes, 4),
-             "dominant_kernel": dom, "dominant_kernel_ms": round(kms[dom], 4),
-             "algorithmic_bytes": own.get(dom, nbytes + comp_bytes),
+             "dominant_kernel": dom, "dominant_kernel_ms": round(kms[dom], 4), "dominant_kernel_launches": nl,
+             "algorithmic_bytes": own.get(dom, nbytes + comp_bytes),  # (of all its launches together, like its ms)
              "frac": round(own.get(dom, nbytes + comp_bytes) / (kms[dom] * 1e-3) / HBM_PEAK, 6),
              # measured HBM bytes a launch of that kernel (profiles/hbm_traffic.json, this workload's own PMC passes)
-             "traffic": hbm_traffic(pmc_key).get(dom) if pmc_key and full_size else None,
+             "traffic": (hbm_traffic(pmc_key).get(dom) or 0) * nl or None if pmc_key and full_size else None,
              "kernels_ms": {k: round(v, 4) for k, v in sorted(kms.items(), key=lambda kv: -kv[1]) if k != "end"}}
         if tc and tu:
             e["compress_GiBps"] = round(nbytes / GIB / (tc * 1e-3), 3)
@@ -353,7 +374,9 @@ def pp_fields(pp, N, comp_rank_exact, roof):
             "size_vs_exact_parse": round(pp["comp_rank"] / comp_rank_exact, 5),
             "parity_sample": pp.get("parity_sample"),
             "kernels_ms": {k: round(v, 4) for k, v in sorted(pk.items(), key=lambda kv: -kv[1]) if k != "end"},
-            "roofline_matcher": roof(N, pk["zh_l1p_match_kernel"], "zh_l1p_match_kernel"),
+            "kernel_launches": {k: v for k, v in pp.get("launches", {}).items() if v > 1},
+            "roofline_matcher": roof(N, pk["zh_l1p_match_kernel"], "zh_l1p_match_kernel",
+                                     nl=pp.get("launches", {}).get("zh_l1p_match_kernel", 1)),
         },
     }
 
@@ -534,8 +557,7 @@ def main():
         ev[2].synchronize()
         t_comp += ev[0].elapsed_time(ev[1])
         t_unc += ev[1].elapsed_time(ev[2])
-        for name, ms in (cplan.kernel_times() if do_c else []) + (uplan.kernel_times() if do_u else []):
-            kernel_ms.setdefault(name, []).append(ms)
+        collect_kernel_times(kernel_ms, (cplan if do_c else None, uplan if do_u else None))
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -590,6 +612,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ptc, ptu, pk = time_plans(torch, stream, cplan, uplan, (d_src, d_comp, d_back), args.steps, 0)
+        pp_launches = dict(time_plans.launches)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -604,7 +627,7 @@ def main():
             dist.all_reduce(c)
             p_comp = int(c.item())
         pp = {"elapsed": p_elapsed, "tc": ptc, "tu": ptu, "kernels": pk, "comp_all": p_comp,
-              "comp_rank": pstate["C"], "total": total_uncompressed, "steps": args.steps,
+              "comp_rank": pstate["C"], "total": total_uncompressed, "steps": args.steps, "launches": pp_launches,
               "parity_sample": pstate.get("parity_sample")}
 
     # ---- N > 1: the batch lives on rank 0 and comes home to rank 0 (RCCL over xGMI) ----
@@ -615,7 +638,7 @@ def main():
                                 t_unc / args.steps)
 
     if rank == 0:
-        avg = {k: sum(v) / len(v) for k, v in kernel_ms.items()}
+        avg, launches = kernel_averages(kernel_ms)  # a kernel's launches of a step together, and how many they are
         dom = max((k for k in avg if k.startswith("zh_")), key=lambda k: avg[k])
         # Algorithmic bytes of this rank's shard: a pass moves every uncompressed byte
         # once and every compressed byte once (N + C); a kernel is charged what IT must move:
@@ -624,12 +647,15 @@ def main():
         own = own_bytes(N, C)
         traffic = hbm_traffic("headline") if (n, size, args.level) == (4096, 1 << 20, 1) and args.foreign is None else {}
 
-        def roof(nbytes, ms, name=None):
+        def roof(nbytes, ms, name=None, nl=None):
+            """nbytes / ms: of all launches of the kernel in a step together; reported a launch (`nl` of them), like the
+            rocprofv3 statistics and the PMC counters under profiles/ are."""
+            nl = max(1, nl if nl is not None else launches.get(name, 1))
             a = nbytes / (ms * 1e-3)
             r = {"bound": "hbm", "achieved": round(a / 1e9, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                  "frac": round(a / HBM_PEAK, 6), "frac_of_copy_peak": round(a / HBM_COPY_PEAK, 6),
                  "traffic": traffic.get(name) if name else None,
-                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(ms, 4)}
+                 "algorithmic_bytes_per_launch": nbytes // nl, "avg_launch_ms": round(ms / nl, 4), "launches_per_step": nl}
             if name:
                 r["kernel"] = name
             return r
@@ -660,6 +686,12 @@ def main():
             "uncompress_GiBps": round(total_uncompressed * args.steps / GIB / (t_unc * 1e-3), 3) if do_u else None,
             "ratio": round(total_uncompressed / comp_all, 4),
             "kernels_ms": {k: round(v, 4) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
+            "kernel_launches": {k: v for k, v in launches.items() if v > 1},
+            "kernels_note": "ms a step, all launches of a kernel together.  A large BestSpeed batch is compressed in chunks "
+                            "(kernel_launches): the match finder of chunk c + 1 on the context's stream beside the other "
+                            "compress kernels of chunk c on a second one, so the compress kernels' times add up to more "
+                            "than the compress pass takes; behind_the_last_matcher is what the last chunk's other kernels "
+                            "take behind the last matcher",
             "roofline": roof(own.get(dom, N + C), avg[dom], dom),
             "roofline_passes": {},
             "roofline_kernels": {k: roof(b, avg[k], k) for k, b in own.items() if k in avg},
@@ -667,9 +699,9 @@ def main():
             "parity_sample": parity_sample,
         }
         if do_c:
-            out["roofline_passes"]["compress"] = roof(N + C, t_comp / args.steps)
+            out["roofline_passes"]["compress"] = roof(N + C, t_comp / args.steps, nl=1)
         if do_u:
-            out["roofline_passes"]["uncompress"] = roof(N + C, t_unc / args.steps)
+            out["roofline_passes"]["uncompress"] = roof(N + C, t_unc / args.steps, nl=1)
         if transfer:
             out["transfer"] = transfer
             out["value_incl_transfer"] = transfer["value_incl_transfer"]
