@@ -115,10 +115,12 @@ def cpu_baseline(bufs, level, cores, reps=8):
 
     one = leg(bufs[:max(1, min(len(bufs), (8 << 20) // max(1, len(bufs[0]))))], 1)
     # every logical CPU, and -- where there are enough of them to be SMT siblings and for memory bandwidth to
-    # matter -- half as many (one thread a core): the better of the two is the baseline
+    # matter -- half, a quarter, an eighth as many: the best of them is the baseline
     legs = {cores: leg(bufs, cores)}
-    if cores >= 32:
-        legs[cores // 2] = leg(bufs, cores // 2)
+    t = cores // 2
+    while t >= 32 and len(legs) < 4:  # (256 logical CPUs: 256, 128, 64, 32 threads)
+        legs[t] = leg(bufs, t)
+        t //= 2
     best = max(legs, key=lambda t: legs[t]["oracle"]["both_GiBps_at_avg"])
     many = legs[best]
     return {
@@ -694,7 +696,9 @@ def main():
                             "take behind the last matcher",
             "roofline": roof(own.get(dom, N + C), avg[dom], dom),
             "roofline_passes": {},
-            "roofline_kernels": {k: roof(b, avg[k], k) for k, b in own.items() if k in avg},
+            # (the checksum kernels run in both passes, N bytes each time: a launch reads `b`, all of them `b` x launches)
+            "roofline_kernels": {k: roof(b * (launches.get(k, 1) if k.startswith("zh_checksum") else 1), avg[k], k)
+                                 for k, b in own.items() if k in avg},
             "source_sha": source_sha(),
             "parity_sample": parity_sample,
         }

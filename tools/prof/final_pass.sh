@@ -19,7 +19,7 @@ timeout 300 python tools/bench_host_api.py --reps 2 --buffers 4096 2>/dev/null |
 timeout 300 python tools/bench_single_call.py 2>/dev/null | tail -1 > $O/${T}_single_call.json
 timeout 600 python tools/bench_one_stream.py 2>/dev/null | tail -1 > $O/${T}_one_stream.json
 ZH_L1_PARSE=parallel timeout 300 python tools/bench_single_call.py 2>/dev/null | tail -1 > $O/${T}_single_call_parallel_parse.json
-ZH_L1_PARSE=parallel timeout 300 python bench.py --buffers 512 --steps 10 --warmup 2 --no-cpu-baseline --no-configs --no-parallel-parse 2>/dev/null | tail -1 > $O/${T}_share512_parallel_parse.json
+ZH_L1_PARSE=parallel timeout 300 python bench.py --buffers 512 --steps 10 --warmup 2 --no-cpu-baseline --no-configs --no-parallel-parse --no-parity-sample 2>/dev/null | tail -1 > $O/${T}_share512_parallel_parse.json
 timeout 1200 python tools/gpu_fuzz.py 1000 120 2>&1 | tail -4 > $O/${T}_fuzz.log
 timeout 900 python tools/gpu_fuzz_chain.py 600 20 2>&1 | tail -2 > $O/${T}_fuzz_chain.log
 (timeout 900 python tools/gpu_fuzz.py --mutations 10000 2>&1 | tail -3; timeout 900 python tools/gpu_fuzz.py --seg-mutations 4000 2>&1 | tail -2) > $O/${T}_fuzz_damaged.log 2>&1
