@@ -174,8 +174,9 @@ def own_bytes(N, C):
 
 
 def collect_kernel_times(kms, plans):
-    """One step's entries of zh_plan_kernel_times: a kernel that is launched several times a step (the compress pass
-    of a large batch runs in chunks, csrc/zh_plan_run.hip) is one entry -- (ms of all its launches, launches)."""
+    """One step's entries of zh_plan_kernel_times: a kernel that is launched several times a step (the checksums of
+    both passes; ranges of a batch whose scratch is bounded, csrc/zh_plan_run.hip) is one entry -- (ms of all its
+    launches, launches)."""
     step = {}
     for pl in plans:
         if pl is None:
@@ -689,11 +690,9 @@ def main():
             "ratio": round(total_uncompressed / comp_all, 4),
             "kernels_ms": {k: round(v, 4) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
             "kernel_launches": {k: v for k, v in launches.items() if v > 1},
-            "kernels_note": "ms a step, all launches of a kernel together.  A large BestSpeed batch is compressed in chunks "
-                            "(kernel_launches): the match finder of chunk c + 1 on the context's stream beside the other "
-                            "compress kernels of chunk c on a second one, so the compress kernels' times add up to more "
-                            "than the compress pass takes; behind_the_last_matcher is what the last chunk's other kernels "
-                            "take behind the last matcher",
+            "kernels_note": "ms a step, all launches of a kernel together (kernel_launches: the checksum kernels run in both "
+                            "passes; a batch whose per-position scratch exceeds ZH_SCRATCH_MB runs the chain kernels / the inflate "
+                            "pair over ranges of it, DESIGN.md 3); the roofline entries are a launch",
             "roofline": roof(own.get(dom, N + C), avg[dom], dom),
             "roofline_passes": {},
             # (the checksum kernels run in both passes, N bytes each time: a launch reads `b`, all of them `b` x launches)
