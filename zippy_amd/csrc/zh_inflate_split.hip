@@ -443,10 +443,9 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
     if (hdr_st == (uint32_t)ZH_OK && s_c_btype != 0u) {
       // the decode tables, by everybody (the staged header is done with: its bytes behind the first 320 words are scratch)
       const uint32_t hlit = s_c_hlit, hdist = s_c_hdist, dist_at = s_c_btype == 1u ? 288u : hlit;
-      int t = build_table_wg<kSplitThreads, kLitBits, kLitSub, 0>(s_lens, hlit, s_lit, &s_tab_lit, s_val_lit, s_cnt, s_in + 320);
-      if (t == ZH_OK)
-        t = build_table_wg<kSplitThreads, kDistBits, kDistSub, 1>(s_lens + dist_at, hdist, s_dst, &s_tab_dist, s_val_dist, s_cnt,
-                                                                  s_in + 320);
+      static_assert(kDistSub == 256u, "");
+      const int t = build_tables_wg<kSplitThreads>(s_lens, hlit, s_lit, &s_tab_lit, s_val_lit, s_lens + dist_at, hdist, s_dst,
+                                                   &s_tab_dist, s_val_dist, s_in + 320);
       hdr_st = (uint32_t)t;
     }
     KPROF_MARK(0);

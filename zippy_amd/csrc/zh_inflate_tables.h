@@ -191,155 +191,194 @@ __device__ __forceinline__ uint32_t dist_entry_a(uint32_t sym, uint32_t len) {
   return len | (kKindBad << 8);
 }
 
-constexpr uint32_t kWgScratchWords = 128u;  // build_table_wg's scratch (dwords)
+constexpr uint32_t kWgScratchWords = 256u;  // build_tables_wg's scratch (dwords): 128 a table
 
-// T threads (256 or 1024), all of them; R-bit root table, SUBCAP second-level entries behind it; KIND 0 litlen
-// (up to 288 symbols), 1 distance (up to 32).  lens[0..n) in LDS.  `scratch`: kWgScratchWords dwords of LDS nobody
-// else uses meanwhile.  Ends with a barrier (the tables are ready for every thread); the returned status is the
-// same in every thread.
+// One table of build_tables_wg: its share of every step (the steps of both tables run between the same barriers).
+// R-bit root table, SUBCAP second-level entries behind it; KIND 0 litlen (up to 288 symbols), 1 distance (up to 32).
 // A canonical code is an ordered partition of the 15-bit values: the codes of l bits, left-justified, are the
 // values [lim[l - 1], lim[l]) with lim[l] = (first code of l bits + their count) << (15 - l).  So the length of the
 // code a bit pattern starts with is a count of comparisons, not a search -- for a root prefix (its first R bits) and
 // for a second-level entry (prefix + its index bits) alike.
 template <uint32_t T, uint32_t R, uint32_t SUBCAP, int KIND>
-__device__ int build_table_wg(const uint8_t* lens, uint32_t n, uint32_t* lut, HuffTab* tab, uint16_t* values,
-                              uint32_t* s_cnt, uint32_t* scratch) {
+struct WgTable {
   static_assert(T % 64u == 0 && R <= 10u, "");
-  constexpr uint32_t kGroups = KIND == 0 ? 5u : 1u;             // symbols in groups of 64
-  constexpr uint32_t kSlots = (kGroups * 64u + T - 1u) / T;  // symbol slots a thread
-  constexpr uint32_t kPP = ((1u << R) + T - 1u) / T;         // prefixes a thread
-  const uint32_t tid = threadIdx.x, wv = tid >> 6;
-  const unsigned lane = zh_lane();
-  uint32_t* const s_g = scratch;            // [kGroups][16] symbols of a length in a group
-  uint32_t* const s_lim = scratch + 80;     // [16] lim[l]; [0]: over-subscribed
-  uint32_t* const s_ws = scratch + 96;      // [T / 64] wave sums of the second-level sizes
-  // ---- 1. every symbol's rank among the symbols of its length in its group ----
-  uint32_t sl[kSlots], srank[kSlots];
+  static constexpr uint32_t kGroups = KIND == 0 ? 5u : 1u;          // symbols in groups of 64
+  static constexpr uint32_t kSlots = (kGroups * 64u + T - 1u) / T;  // symbol slots a thread
+  static constexpr uint32_t kPP = ((1u << R) + T - 1u) / T;         // prefixes a thread
+  const uint8_t* lens;  // [n] code lengths (LDS)
+  uint32_t n;
+  uint32_t* lut;
+  HuffTab* tab;
+  uint16_t* values;
+  uint32_t* scratch;  // 128 dwords: [0, 80) symbols of a length in a group, [80, 96) lim[] ([80]: over-subscribed), [96, ..) wave sums
+  uint32_t sl[kSlots], srank[kSlots], lim[16], pl[kPP], size_sum, incl;
+
+  // 1. every symbol's rank among the symbols of its length in its group; `vt`: the thread's number among the
+  // threads that take this table's symbols (>= kGroups * 64: none)
+  __device__ __forceinline__ void ranks(uint32_t vt) {
+    const unsigned lane = zh_lane();
 #pragma unroll
-  for (uint32_t j = 0; j < kSlots; j++) {
-    const uint32_t s = tid + j * T;
-    sl[j] = 0;
-    srank[j] = 0;
-    if (s < kGroups * 64u) {  // (wave-uniform)
-      const uint32_t l = s < n ? lens[s] : 0u;
-      sl[j] = l;
+    for (uint32_t j = 0; j < kSlots; j++) {
+      const uint32_t s = vt + j * T;
+      sl[j] = 0;
+      srank[j] = 0;
+      if (s < kGroups * 64u) {  // (wave-uniform)
+        const uint32_t l = s < n ? lens[s] : 0u;
+        sl[j] = l;
 #pragma unroll
-      for (uint32_t L = 1; L < 16; L++) {
-        const uint64_t m = __ballot(l == L);
-        if (l == L) srank[j] = (uint32_t)__popcll(m & zh_lanemask_lt());
-        if (lane == L) s_g[(s >> 6) * 16u + L] = (uint32_t)__popcll(m);
+        for (uint32_t L = 1; L < 16; L++) {
+          const uint64_t m = __ballot(l == L);
+          if (l == L) srank[j] = (uint32_t)__popcll(m & zh_lanemask_lt());
+          if (lane == L) scratch[(s >> 6) * 16u + L] = (uint32_t)__popcll(m);
+        }
       }
     }
   }
-  __syncthreads();
-  // ---- 2. inflate.nim:32-51: counts, first codes, first canonical indices: lane l of wave 0 for length l ----
-  if (tid < 64) {
+  // 2. inflate.nim:32-51: counts, first codes, first canonical indices: lane l of ONE wave for length l
+  __device__ __forceinline__ void counts() {
+    const unsigned lane = zh_lane();
     uint32_t h = 0;
     if (lane >= 1 && lane < 16) {
 #pragma unroll
-      for (uint32_t g = 0; g < kGroups; g++) h += s_g[g * 16u + lane];
+      for (uint32_t g = 0; g < kGroups; g++) h += scratch[g * 16u + lane];
     }
     // first code of length l = sum over shorter lengths l' of count[l'] << (l - l'), i.e. lim[l - 1] >> (15 - l);
     // lim[l] = sum over l' <= l of count[l'] << (15 - l')
-    const uint32_t lim = zh_wave_scan(lane >= 1 && lane < 16 ? h << (15u - lane) : 0u);
+    const uint32_t lm = zh_wave_scan(lane >= 1 && lane < 16 ? h << (15u - lane) : 0u);
     const uint32_t first_sym = zh_wave_scan(h) - h;
-    const uint32_t first_code = lane >= 1 && lane < 16 ? (lim - (h << (15u - lane))) >> (15u - lane) : 0u;
+    const uint32_t first_code = lane >= 1 && lane < 16 ? (lm - (h << (15u - lane))) >> (15u - lane) : 0u;
     // over-subscribed (inflate.nim:41-46): more codes of a length than that length has, or past its last value
     const bool bad = lane >= 1 && lane < 16 && (h > (1u << lane) || (h > 0 && first_code + h - 1u >= (1u << lane)));
     const uint64_t anybad = __ballot(bad);
     if (lane >= 1 && lane < 16) {
-      s_cnt[lane] = h;
       tab->first_code[lane] = (uint16_t)first_code;
       tab->first_symbol[lane] = (uint16_t)first_sym;
       tab->max_codes[lane] = (first_code + h) << (16u - lane);
-      s_lim[lane] = lim;
+      scratch[80u + lane] = lm;
     }
     if (lane == 0) {
       tab->max_codes[16] = 1u << 16;
-      s_cnt[0] = 0;
-      s_lim[0] = anybad ? 1u : 0u;
+      scratch[80] = anybad ? 1u : 0u;
     }
   }
-  __syncthreads();
-  if (s_lim[0]) {
-    __syncthreads();  // (everybody has read the flag before the scratch is used again)
-    return ZH_ERR_INVALID_BUFFER;
-  }
-  uint32_t lim[16];
+  __device__ __forceinline__ bool oversubscribed() const { return scratch[80] != 0u; }
+  // 3. symbols in canonical order (and the partition's limits into registers)
+  __device__ __forceinline__ void canonical(uint32_t vt) {
 #pragma unroll
-  for (uint32_t i = 1; i < 16; i++) lim[i] = s_lim[i];
-  // ---- 3. symbols in canonical order ----
+    for (uint32_t i = 1; i < 16; i++) lim[i] = scratch[80u + i];
 #pragma unroll
-  for (uint32_t j = 0; j < kSlots; j++) {
-    const uint32_t s = tid + j * T;
-    if (s < kGroups * 64u && sl[j]) {
-      uint32_t before = tab->first_symbol[sl[j]];
-      for (uint32_t g = 0; g < (s >> 6); g++) before += s_g[g * 16u + sl[j]];
-      values[before + srank[j]] = (uint16_t)s;
+    for (uint32_t j = 0; j < kSlots; j++) {
+      const uint32_t s = vt + j * T;
+      if (s < kGroups * 64u && sl[j]) {
+        uint32_t before = tab->first_symbol[sl[j]];
+        for (uint32_t g = 0; g < (s >> 6); g++) before += scratch[g * 16u + sl[j]];
+        values[before + srank[j]] = (uint16_t)s;
+      }
     }
   }
-  __syncthreads();
   // the code that the 15-bit value v starts with: its length (16: none, the code is incomplete there)
-  auto len_of = [&](uint32_t v) -> uint32_t {
+  __device__ __forceinline__ uint32_t len_of(uint32_t v) const {
     uint32_t l = 1;
 #pragma unroll
     for (uint32_t i = 1; i < 16; i++) l += v >= lim[i] ? 1u : 0u;
     return l;
-  };
-  auto entry_of = [&](uint32_t v, uint32_t l) -> uint32_t {
+  }
+  __device__ __forceinline__ uint32_t entry_of(uint32_t v, uint32_t l) const {
     const uint32_t sym = values[(uint32_t)tab->first_symbol[l] + (v >> (15u - l)) - (uint32_t)tab->first_code[l]];
     return KIND == 0 ? litlen_entry_a(sym, l) : dist_entry_a(sym, l);
-  };
-  // ---- 4. a root entry per prefix (prefix p = the first R bits of the stream as a number, first bit on top) ----
-  uint32_t pl[kPP], size_sum = 0;  // length of the code the prefix starts with, or (R + index bits of its second-level table) | 32
-#pragma unroll
-  for (uint32_t k = 0; k < kPP; k++) {
-    const uint32_t p = tid * kPP + k;
-    pl[k] = 0;
-    if (p < (1u << R)) {
-      const uint32_t v0 = p << (15u - R);
-      const uint32_t l = len_of(v0);
-      if (l <= R) {
-        pl[k] = l;
-      } else if (v0 < lim[15]) {  // codes below the prefix: the longest is the one its last assigned value starts with
-        const uint32_t top = (v0 + (1u << (15u - R)) < lim[15] ? v0 + (1u << (15u - R)) : lim[15]) - 1u;
-        const uint32_t jl = len_of(top);
-        pl[k] = jl | 32u;
-        size_sum += 1u << (jl - R);
-      }
-    }
   }
-  // second-level tables in prefix order (= canonical order), as long as they fit
-  const uint32_t incl = zh_wave_scan(size_sum);
-  if (lane == 63) s_ws[wv] = incl;
-  __syncthreads();
-  uint32_t at = incl - size_sum;
-  for (uint32_t w = 0; w < wv; w++) at += s_ws[w];
+  // 4a. every root prefix (prefix p = the first R bits of the stream as a number, first bit on top): the length of
+  // the code it starts with, or (R + index bits of its second-level table) | 32; the tables' sizes, summed a wave
+  __device__ __forceinline__ void classify() {
+    const uint32_t tid = threadIdx.x;
+    size_sum = 0;
 #pragma unroll
-  for (uint32_t k = 0; k < kPP; k++) {
-    const uint32_t p = tid * kPP + k;
-    if (p < (1u << R)) {
-      const uint32_t x = __brev(p) >> (32u - R);  // where the decoder looks: the stream carries codes first bit first
-      const uint32_t v0 = p << (15u - R);
-      uint32_t e = 0;
-      if (pl[k] & 32u) {
-        const uint32_t sb = (pl[k] & 31u) - R, size = 1u << sb;
-        if (at + size <= SUBCAP) {  // (the sums grow: behind the first table that does not fit none does)
-          const uint32_t base = (1u << R) + at;
-          e = sb | 0x400u | (base << 16);
-          for (uint32_t q = 0; q < size; q++) {
-            const uint32_t v = v0 | ((__brev(q) >> (32u - sb)) << (15u - R - sb));
-            const uint32_t l = len_of(v);
-            lut[base + q] = l <= R + sb && v < lim[15] ? entry_of(v, l) : 0u;
-          }
+    for (uint32_t k = 0; k < kPP; k++) {
+      const uint32_t p = tid * kPP + k;
+      pl[k] = 0;
+      if (p < (1u << R)) {
+        const uint32_t v0 = p << (15u - R);
+        const uint32_t l = len_of(v0);
+        if (l <= R) {
+          pl[k] = l;
+        } else if (v0 < lim[15]) {  // codes below the prefix: the longest is the one its last assigned value starts with
+          const uint32_t top = (v0 + (1u << (15u - R)) < lim[15] ? v0 + (1u << (15u - R)) : lim[15]) - 1u;
+          const uint32_t jl = len_of(top);
+          pl[k] = jl | 32u;
+          size_sum += 1u << (jl - R);
         }
-        at += size;
-      } else if (pl[k]) {
-        e = entry_of(v0, pl[k]);
       }
-      lut[x] = e;
+    }
+    incl = zh_wave_scan(size_sum);
+    if (zh_lane() == 63) scratch[96u + (tid >> 6)] = incl;
+  }
+  // 4b. the root entries, and the second-level tables in prefix order (= canonical order) as long as they fit
+  __device__ __forceinline__ void fill() {
+    const uint32_t tid = threadIdx.x, wv = tid >> 6;
+    uint32_t at = incl - size_sum;
+    for (uint32_t w = 0; w < wv; w++) at += scratch[96u + w];
+#pragma unroll
+    for (uint32_t k = 0; k < kPP; k++) {
+      const uint32_t p = tid * kPP + k;
+      if (p < (1u << R)) {
+        const uint32_t x = __brev(p) >> (32u - R);  // where the decoder looks: the stream carries codes first bit first
+        const uint32_t v0 = p << (15u - R);
+        uint32_t e = 0;
+        if (pl[k] & 32u) {
+          const uint32_t sb = (pl[k] & 31u) - R, size = 1u << sb;
+          if (at + size <= SUBCAP) {  // (the sums grow: behind the first table that does not fit none does)
+            const uint32_t base = (1u << R) + at;
+            e = sb | 0x400u | (base << 16);
+            for (uint32_t q = 0; q < size; q++) {
+              const uint32_t v = v0 | ((__brev(q) >> (32u - sb)) << (15u - R - sb));
+              const uint32_t l = len_of(v);
+              lut[base + q] = l <= R + sb && v < lim[15] ? entry_of(v, l) : 0u;
+            }
+          }
+          at += size;
+        } else if (pl[k]) {
+          e = entry_of(v0, pl[k]);
+        }
+        lut[x] = e;
+      }
     }
   }
+};
+
+// Both decode tables of a block by the whole workgroup (T threads, 256 or 1024, all of them), the two tables' steps
+// between the same five barriers: the literal / length code's symbols on every wave, the distance code's on wave 1;
+// the counts of the one by wave 0, of the other by wave 1; the prefixes of both on every thread.  lens in LDS,
+// `scratch`: kWgScratchWords dwords of LDS nobody else uses meanwhile.  Ends with a barrier (the tables are ready
+// for every thread); the returned status is the same in every thread.
+template <uint32_t T>
+__device__ __noinline__ int build_tables_wg(const uint8_t* lit_lens, uint32_t hlit, uint32_t* lit_lut, HuffTab* lit_tab,
+                                            uint16_t* lit_values, const uint8_t* dist_lens, uint32_t hdist,
+                                            uint32_t* dist_lut, HuffTab* dist_tab, uint16_t* dist_values,
+                                            uint32_t* scratch) {
+  const uint32_t tid = threadIdx.x;
+  WgTable<T, kLitBits, kLitSub, 0> lit;
+  lit.lens = lit_lens; lit.n = hlit; lit.lut = lit_lut; lit.tab = lit_tab; lit.values = lit_values; lit.scratch = scratch;
+  WgTable<T, kDistBits, 256u, 1> dst;
+  dst.lens = dist_lens; dst.n = hdist; dst.lut = dist_lut; dst.tab = dist_tab; dst.values = dist_values; dst.scratch = scratch + 128;
+  const uint32_t dvt = tid - 64u;  // the distance code's symbols on wave 1 (other threads: a number past its symbols)
+  lit.ranks(tid);
+  dst.ranks(dvt);
+  __syncthreads();
+  if (tid < 64u) lit.counts();
+  else if (tid < 128u) dst.counts();
+  __syncthreads();
+  if (lit.oversubscribed() || dst.oversubscribed()) {
+    __syncthreads();  // (everybody has read the flags before the scratch is used again)
+    return ZH_ERR_INVALID_BUFFER;
+  }
+  lit.canonical(tid);
+  dst.canonical(dvt);
+  __syncthreads();
+  lit.classify();
+  dst.classify();
+  __syncthreads();
+  lit.fill();
+  dst.fill();
   __syncthreads();
   return ZH_OK;
 }
