@@ -60,3 +60,36 @@ def test_reference_api_names():
             zippy_amd.DefaultCompression, zippy_amd.HuffmanOnly) == (0, 1, 9, -1, -2)
     for name in ("compress", "uncompress", "crc32", "adler32"):
         assert callable(getattr(api, name))
+
+
+def _c_prototypes():
+    """name -> number of parameters, from include/zippy_hip.h"""
+    hdr = open(os.path.join(ROOT, "include", "zippy_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(zh_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_nim_shim_matches_the_header(lib):
+    """bindings/nim/hip.nim -- the reference-side binding of INTEGRATION.md as a file; Nim is not in the image, so
+    it cannot be compiled here: every `importc` proc must at least name a symbol the header declares and the library
+    exports, and take as many parameters as the C prototype (`a, b: cint` counts two)."""
+    src = open(os.path.join(ROOT, "bindings", "nim", "hip.nim")).read()
+    protos = _c_prototypes()
+    procs = re.findall(r"proc\s+(zh_[a-z0-9_]+)\s*\((.*?)\)\s*(?::\s*[A-Za-z_]+\s*)?\{\.importc", src, flags=re.S)
+    assert len(procs) >= 20
+    for name, params in procs:
+        assert name in protos, name
+        assert getattr(lib, name) is not None
+        n = 0
+        for group in params.split(","):  # "level, dataFormat: cint" -> two names before one type
+            if group.strip():
+                n += 1
+        assert n == protos[name], (name, n, protos[name])
+    # the shim text in INTEGRATION.md is this file's (so that the two cannot drift apart)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name, _ in procs:
+        assert ("proc %s(" % name) in doc, name
