@@ -17,7 +17,7 @@ L1 = ["stage-in", "step: vector part", "step: fast walk", "step: slow walk", "st
       "stats phase", "#steps", "#fast steps", "#events fast", "#events slow", "#match extensions",
       "#waves", "#slow: all lanes miss", "#slow: (unused)", "#slow: shared-slot lane",
       "#slow: plain hit"]
-L1P = ["stage-in", "P1 links (one wave)", "P2 lengths", "P3 parse", "P4 output", "#turns", "#waves", "#(unused)"]
+L1P = ["stage-in", "P1 links (one wave)", "P2 first walks (lengths on demand)", "P3 hand-over turns", "P4 output", "#turns", "#waves", "#(unused)"]
 EMIT = ["flush + loop", "chunk bitmaps", "bitmaps, source, scan, match fields", "codes", "scan + LDS ORs",
         "last flush", "#waves", "#(unused)"]
 HUFF = ["histogram sum", "litlen code", "distance code", "run-length coding", "code-length code", "header bits",

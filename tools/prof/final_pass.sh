@@ -8,6 +8,9 @@
 R=$(pwd); T=${1:-r03}
 O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
+# the PMC passes first: profiles/hbm_traffic.json has to be there (with these sources' hash) for the bench lines to quote it
+bash tools/prof/pmc_passes.sh > $O/${T}_pmc.log 2>&1   # -> gpurun_out/hbm_traffic.json: the headline and configs 2-5, a pair of PMC passes each
+mkdir -p profiles && cp $O/hbm_traffic.json profiles/hbm_traffic.json
 timeout 1200 python -m pytest tests -m gpu -q > $O/${T}_pytest_gpu.log 2>&1
 timeout 900 python bench.py --steps 10 --warmup 2 2>$O/${T}_bench.err | tail -1 > $O/${T}_bench.json
 timeout 600 python bench.py --level -1 --compress-only --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c4.json
@@ -24,10 +27,10 @@ timeout 1200 python tools/gpu_fuzz.py 1000 120 2>&1 | tail -4 > $O/${T}_fuzz.log
 timeout 900 python tools/gpu_fuzz_chain.py 600 20 2>&1 | tail -2 > $O/${T}_fuzz_chain.log
 (timeout 900 python tools/gpu_fuzz.py --mutations 10000 2>&1 | tail -3; timeout 900 python tools/gpu_fuzz.py --seg-mutations 4000 2>&1 | tail -2) > $O/${T}_fuzz_damaged.log 2>&1
 timeout 300 python tools/kprof.py --l1-parse 1 --buffers 1024 2>&1 | head -13 > $O/${T}_kprof_l1p.txt
+timeout 300 python tools/kprof.py --foreign 6 --buffers 1024 > $O/${T}_kprof_foreign6.txt 2>&1
 cd /tmp
 rm -rf /tmp/kt
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $O/${T}_rocprof_bench.log 2>&1
 cd $R
 python tools/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) > $O/${T}_kernel_stats.csv 2>$O/${T}_summary.err
-bash tools/prof/pmc_passes.sh > $O/${T}_pmc.log 2>&1   # -> gpurun_out/hbm_traffic.json: the headline and configs 2-5, a pair of PMC passes each
 tail -2 $O/${T}_pytest_gpu.log; for f in bench c4 share512; do echo "== $f"; cut -c1-600 $O/${T}_$f.json; done; head -14 $O/${T}_kernel_stats.csv

@@ -242,7 +242,6 @@ struct FastWork {  // overlays HuffWork (5.8 KiB)
   uint32_t lf[kMaxSyms];       // leaf frequencies, ascending
   uint32_t nf[kMaxSyms];       // internal nodes' frequencies, in creation (= ascending) order
   uint16_t sym_of[kMaxSyms];   // rank -> symbol
-  uint16_t rank_of[kMaxSyms];  // symbol -> rank (used symbols)
   uint16_t par[2 * kMaxSyms];  // node -> parent (leaves 0 .. n-1 by rank, internal nodes n .. 2n-2)
   uint16_t dep[2 * kMaxSyms];  // node -> depth
 };
@@ -301,7 +300,6 @@ __device__ int huffman_codes_fast(const uint32_t* freq, int num_freq, int min_co
       if (f[k]) {
         w.lf[rk[k]] = f[k];
         w.sym_of[rk[k]] = (uint16_t)sidx;
-        w.rank_of[sidx] = (uint16_t)rk[k];
       }
     }
     zh_wave_sync();
@@ -493,7 +491,7 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   uint32_t* const s_clfreq = s_freq;        // [32] the code-length alphabet's histogram: the block's own is done with
   uint16_t* const s_clcodes = reinterpret_cast<uint16_t*>(s_freq + 32);  // [20]
   uint8_t* const s_cllens = reinterpret_cast<uint8_t*>(s_freq + 48);     // [20]
-  int* const s_n = reinterpret_cast<int*>(s_freq + 64);  // [3] litlen codes, distance codes, run-length items (behind the litlen build)
+  int* const s_n = reinterpret_cast<int*>(s_freq + 64);  // [2] litlen codes, distance codes (behind the litlen build)
 
   const unsigned lane = zh_lane();
   KPROF_DECL(8);

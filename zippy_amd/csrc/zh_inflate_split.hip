@@ -6,24 +6,28 @@
 // next code starts.  Huffman decoding re-synchronises by itself, though: a decoder started at an
 // arbitrary bit falls in step with the real code sequence after a few dozen symbols.  So:
 //
-//   zh_inflate_tokens_kernel (256 threads per stream)
-//     blocks in order (inflate.nim:273-289): wave 0 reads the block header and builds the tables
-//     exactly like the serial kernel (zh_inflate_tables.h); then the block's bits are taken
-//     131 072 at a time ("superchunk", staged in LDS), one 512-bit SUBCHUNK per thread.  Every
-//     thread decodes whole tokens (literal, or length+extra+distance+extra, inflate.nim:93-100 /
-//     199-222) from its guessed start to the first token start at or behind its subchunk's end;
-//     that end is the next thread's true start, so starts are handed on and threads whose start
-//     changed decode again until no start changes.  Thread 0's start is exact, so by induction
-//     every start then is: the result is the serial decoder's token sequence -- self-
-//     synchronisation only decides how many turns that takes (two or three), never what comes
-//     out.  Token counts are prefix-summed and a last pass writes the tokens (one 32-bit record
-//     each, the serial kernel's round-record format) to the stream's token buffer in HBM.
-//     End of block, invalid symbols and the end of the input are found by the thread that owns
+//   zh_inflate_tokens_kernel (256 or 1024 threads per stream)
+//     blocks in order (inflate.nim:273-289).  A block's header: wave 0 reads the fixed fields and -- for a clean
+//     dynamic header -- the code lengths with all its lanes (code_lengths_wave: the symbols that start at 64
+//     consecutive bits at once, a readlane walk picks the real ones); anything else goes to the serial reader,
+//     which raises the reference's errors.  The two decode tables are built by the whole workgroup
+//     (build_tables_wg, zh_inflate_tables.h).  Then the block's bits are taken 131 072 at a time ("superchunk",
+//     staged in LDS), one 512-bit SUBCHUNK per thread.  Every thread decodes whole tokens (literal, or
+//     length+extra+distance+extra, inflate.nim:93-100 / 199-222) from its guessed start -- found by a run-up
+//     through the subchunk before -- to the first token start at or behind its subchunk's end; that end is the
+//     next thread's true start, so starts are handed on and threads whose start changed decode again until no
+//     start changes.  Thread 0's start is exact, so by induction every start then is: the result is the serial
+//     decoder's token sequence -- self-synchronisation only decides how many turns that takes (one or two),
+//     never what comes out.  Token counts are prefix-summed and a last pass writes the tokens (one 32-bit record
+//     each -- a pair of literals shares one --, the serial kernel's round-record format) to the stream's token
+//     buffer in HBM.  End of block, invalid symbols and the end of the input are found by the thread that owns
 //     the bit position, in stream order; stored blocks (inflate.nim:252-266) become one record.
-//   zh_inflate_write_kernel (one wave per stream)
-//     the serial kernel's output wave fed from the token buffer: rounds of up to 64 output bytes,
-//     one lane per byte, LZ window = the output itself.  Keeps inflate.nim:224-225's distance
-//     check and the capacity check; produces out_len and the status.
+//   zh_inflate_write_kernel (256, 512 or 1024 threads per stream)
+//     records into bytes, rounds of eight output bytes a thread: a prefix sum places a round's records, a byte ->
+//     record map tells every byte its record; literals carry their value, bytes copied from before the round are
+//     read back through L2 (the LZ window is the output itself), bytes copied from inside it chase their source
+//     by pointer doubling in LDS.  Keeps inflate.nim:224-225's distance check and the capacity check; produces
+//     out_len and the status.
 //
 // Same checks, same accept/reject decision and the same bytes as zh_inflate_kernel (the tests
 // run both against the oracle).  Algorithmic traffic: C read + N written, plus the token
