@@ -1,0 +1,48 @@
+"""The kernel sources and the host side of the library under AddressSanitizer: the g++ / emulator build of
+zippy_amd/csrc (tests/hipemu) with -fsanitize=address, a run through every family of kernels -- both BestSpeed
+parses and code builders, a chain level, both inflate paths on fixtures, damaged headers and streams, the `_into`
+calls, plans whose scratch is forced into ranges -- in a child process (the sanitizer runtime has to be the first
+library the process loads).  `__shared__` arrays are plain memory under the emulator, so an index that runs off
+one is an error here where the hardware would read its neighbour."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+import emu, oracle, synth, parity_cases as pc
+eng = emu.engine()
+inputs = [synth.corpus_file("alice29.txt")[:70000], synth.corpus_file("geo.protodata")[:40000]] + pc.edge_inputs()[:12]
+pc.check_compress_identical(eng, inputs, levels=(1,), formats=(oracle.dfGzip,))
+pc.check_compress_identical(eng, inputs[:2], levels=(-1, -2, 0), formats=(oracle.dfDeflate,))
+pc.check_huffman_builders(eng)
+pc.check_parallel_parse(eng, [b.tobytes() for b in synth.gen_batch("mix", 2, 70000)] + pc.edge_inputs()[:8])
+for mode in (0, 1):
+    eng.set_inflate_mode(mode)
+    pc.check_fixtures(eng, max_len=40000)
+    pc.check_damaged_headers(eng, 11)
+    pc.check_errors_match_oracle(eng, pc.mutated_fixtures(12, seed=3, max_len=40000))
+eng.set_inflate_mode(-1)
+pc.check_batch_into(eng)
+print("sanitized emulator run ok")
+"""
+
+
+def test_emulator_build_under_asan():
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan.so not found")
+    env = dict(os.environ, LD_PRELOAD=asan, ZH_EMU_VARIANT="asan", ZH_EMU_DEFINES="-fsanitize=address -fno-omit-frame-pointer",
+               ZH_SCRATCH_MB="1", ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:detect_stack_use_after_return=0")
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}],
+                       capture_output=True, text=True, env=env, timeout=1500)
+    if r.returncode != 0 and "emu build failed" in r.stderr and "sanitize" in r.stderr:
+        pytest.skip("no sanitizer runtime in this toolchain")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "sanitized emulator run ok" in r.stdout
+    assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
