@@ -59,6 +59,12 @@ def test_emu_chain_levels_across_windows(eng):
     pc.check_compress_identical(eng, [mixed], levels=(-1, 5), formats=(oracle.dfDeflate,))
     pc.check_tokens(eng, mixed, -1)
     pc.check_compress_identical(eng, [two_blocks], levels=(-1,), formats=(oracle.dfGzip,))
+    # equal hashes mostly MORE than a window apart (random bytes: ~ 2 positions a slot in 300 KB): `head` entries that
+    # have gone stale, whose links lead the reference's walk to positions of OTHER hashes (lz77.nim:88-93), text between
+    stale = (synth.gen_batch("rand", 1, 150000)[0].tobytes() + synth.corpus_file("alice29.txt")[:40000] +
+             synth.gen_batch("rand", 1, 150000)[0].tobytes()[:110000] + synth.corpus_file("alice29.txt")[:70000])
+    pc.check_compress_identical(eng, [stale], levels=(-1, 9), formats=(oracle.dfDeflate,))
+    pc.check_tokens(eng, stale, -1)
 
 
 def test_emu_chain_cross_check_kernels():
