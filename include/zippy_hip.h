@@ -387,6 +387,12 @@ int zh_debug_tokens(zh_ctx *ctx, const void *src, size_t len, int level, uint16_
  * go into the stream) and lens hold num_freq + 2 entries; *num_codes is the reference's numCodes. */
 int zh_debug_huffman(zh_ctx *ctx, const uint32_t *freq, int num_freq, int min_codes, int limit, int contract,
                      uint16_t *codes, uint8_t *lens, int *num_codes);
+/* Large streams are decoded by many workgroups each (segment-wise) when the chain of their segments holds, by one
+ * workgroup otherwise -- same bytes and statuses either way, so only a count can tell the two apart: since the
+ * context was made, *cut = streams that uncompress calls cut into segments, *held = those of them whose chain held
+ * (counted when a call's / a plan's results are read).  A stream that is damaged, or has fewer than four block
+ * starts and sub-starts, legitimately does not hold. */
+int zh_debug_segment_stats(zh_ctx *ctx, uint64_t *cut, uint64_t *held);
 
 #ifdef __cplusplus
 }

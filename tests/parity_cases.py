@@ -862,6 +862,7 @@ def check_segmented(eng, scale, monkeypatch, seg_bytes):
     monkeypatch.setenv("ZH_SEG_BYTES", str(seg_bytes))
     monkeypatch.setenv("ZH_SEG_SETUP", "0")  # (the set-up cost that keeps small jobs off this path)
     cases = segmented_streams(scale)
+    n_foreign = len(cases)
     # this library's own streams: ONE block (the last one) however long -- every decoder but the
     # first starts inside it; raw deflate has no checksum to catch a wrong byte, only this comparison
     own_src = [synth.gen_batch(kind, 1, 72 * scale, first_index=9)[0].tobytes() for kind in ("text", "mix")]
@@ -870,10 +871,35 @@ def check_segmented(eng, scale, monkeypatch, seg_bytes):
             comp, sts = eng.compress_batch(own_src, level, fmt)
             assert sts == [0, 0]
             cases += [(c, fmt, p) for c, p in zip(comp, own_src) if len(c) >= 4 * seg_bytes]
-    for blob, fmt, plain in cases:
+    n_own = len(cases) - n_foreign
+    held_foreign = 0
+    for i, (blob, fmt, plain) in enumerate(cases):
         assert len(blob) >= 4 * seg_bytes, len(blob)
+        before = eng.segment_stats()
         outs, sts = eng.uncompress_batch([blob], fmt)
         assert sts == [0] and outs[0] == plain, (fmt, len(blob), sts)
+        # ... and by MANY workgroups: a chain of segments that does not hold is decoded by one workgroup, with the same
+        # bytes -- only the count tells (zh_debug_segment_stats).  This library's own streams always hold; a foreign
+        # one with fewer than four block starts (fixed codes, one block) legitimately does not.
+        cut, held = (a - b for a, b in zip(eng.segment_stats(), before))
+        assert cut >= 1, (i, cut)
+        if i >= n_foreign:
+            assert held == cut, ("own stream left to one workgroup", i, fmt, len(blob), cut, held)
+        else:
+            held_foreign += held == cut
+    assert held_foreign >= n_foreign - 1, (held_foreign, n_foreign)
+    # Bits of the payload that read like a block header and are none (about one a GiB; ZH_SEG_FAKE_START plants one):
+    # the decoder before runs past it, the segments behind it still find their sub-starts (from the real header, one
+    # found start further back), and the stream is still decoded segment-wise -- such a guess once cost a 1 GiB
+    # stream of this library a factor of 100 (tools/gpu_big_buffer.py).
+    for blob, fmt, plain in cases[n_foreign:n_foreign + 2]:
+        for fake_bit in (len(blob) * 2 + 3, len(blob) * 9 // 2):
+            monkeypatch.setenv("ZH_SEG_FAKE_START", str(fake_bit))
+            before = eng.segment_stats()
+            outs, sts = eng.uncompress_batch([blob], fmt)
+            cut, held = (a - b for a, b in zip(eng.segment_stats(), before))
+            assert sts == [0] and outs[0] == plain and cut >= 1 and held == cut, (fmt, len(blob), fake_bit, sts, cut, held)
+    monkeypatch.delenv("ZH_SEG_FAKE_START")
     # a batch of them at once (same format), small streams (no segments) in between: zlib streams
     zl = [c for c in cases if c[1] == oracle.dfZlib]
     small = [(zlib.compress(c[2][:k], 6), c[1], c[2][:k]) for c, k in zip(zl, (0, 1, 3000))]

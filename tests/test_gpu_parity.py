@@ -394,3 +394,18 @@ def test_gpu_segmented_streams(eng, monkeypatch):
     assert sts == [0]
     outs, sts = eng.uncompress_batch(comp, oracle.dfGzip)
     assert sts == [0] and outs[0] == big
+
+
+def test_gpu_one_gib_stream_decodes_segment_wise():
+    """ONE stream of 1 GiB (this library's own, BestSpeed: blocks of 4 MiB of input, each many segments long): the
+    round trip, the gzip trailer -- and that it is DECODED by many workgroups.  This very stream holds bits inside a
+    block's payload that pass for a block header; they once cost the segments behind them their sub-starts, the
+    decoder before them its token room and the stream the segment-wise decode: 2 s instead of 20 ms, with the right
+    bytes.  (tools/gpu_big_buffer.py: also 4 GiB + 12345 bytes against the oracle, byte for byte.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gpu_big_buffer
+    res = gpu_big_buffer.run(1024, level=1, with_oracle=False, with_zlib=False)
+    assert res["trailer_ok"] and res["decoded_segment_wise"], res
+    assert max(res["uncompress_s"][1:]) < 0.5, res  # (20 ms on an MI355X; one workgroup takes 2 s)

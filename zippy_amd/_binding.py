@@ -118,6 +118,7 @@ _SIGS = {
                                    _c.POINTER(_c.POINTER(_c.c_uint16)), _c.POINTER(_c.c_size_t)]),
     "zh_debug_huffman": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint32), _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                     _c.POINTER(_c.c_uint16), _c.POINTER(_c.c_uint8), _c.POINTER(_c.c_int)]),
+    "zh_debug_segment_stats": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)  # every entry point include/zippy_hip.h declares
@@ -415,6 +416,12 @@ class Engine:
     def uncompress(self, src, data_format=dfDetect):
         outs, sts = self.uncompress_batch([src], data_format)
         return self._raise_first(outs, sts)[0]
+
+    def segment_stats(self):
+        """(streams cut into segments, streams whose chain of segments held) since the context was made."""
+        cut, held = _c.c_uint64(), _c.c_uint64()
+        self._check(self.lib.zh_debug_segment_stats(self._h, _c.byref(cut), _c.byref(held)))
+        return cut.value, held.value
 
     def debug_huffman(self, freq, min_codes, limit, contract=False):
         """One prefix code from a histogram, by the byte-identical builder or by contract mode's

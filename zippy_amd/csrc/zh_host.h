@@ -44,6 +44,7 @@ void zh_launch_inflate_write(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, 
                              const uint32_t* tok_pool, const uint64_t* tok_off);
 void zh_launch_segments_reduce(hipStream_t, ZhInflateArgs seg, ZhInflateArgs whole);
 void zh_launch_seg_find(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g);
+void zh_launch_seg_fake_start(hipStream_t, ZhSegArgs g, uint64_t bit);
 void zh_launch_seg_check(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_seg_tokens(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, uint32_t* tok_pool, ZhSegArgs g, int phase);
 void zh_launch_seg_decide(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
@@ -88,6 +89,7 @@ struct zh_ctx {
   int inflate_mode = -1;  // -1: ZH_INFLATE or the default (split), 0 split, 1 serial
   int l1_parse = -1;      // -1: ZH_L1_PARSE or the default (exact), 0 exact (the reference's parse), 1 parallel
   std::string last_error;
+  uint64_t seg_cut = 0, seg_held = 0;  // zh_debug_segment_stats
   const void* cktabs = nullptr;
   std::mt19937 rng{std::random_device{}()};
   // host-buffer calls: two pinned staging chunks between the caller's pageable memory and HBM
@@ -220,6 +222,7 @@ struct zh_plan {
   // large streams decoded segment-wise (zh_inflate_seg.hip); the symbol and window buffers come
   // with the token pool
   bool segmented = false;
+  bool seg_ran = false;  // the segment kernels of a run whose results have not been read yet
   ZhSegArgs sg{};
   uint8_t* sg_arena = nullptr;
   uint16_t* sg_sym = nullptr;

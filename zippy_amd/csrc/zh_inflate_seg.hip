@@ -517,6 +517,23 @@ __global__ __launch_bounds__(64) void zh_seg_decide_kernel(ZhInflateArgs a, ZhSe
       g.eff_tok_cap[k] = room;
     }
   }
+  // A decoder carries on through the segments behind it that have no start of their own (a stretch without
+  // block starts and without sub-starts: a stored block; a block whose sub-starts a wrong guess before them has
+  // spoilt), and their token regions, which lie right behind its own, are nobody's: they are its room, too.
+  __threadfence();
+  zh_wave_sync();
+  auto start_of = [&](uint32_t k) -> uint64_t {
+    return __hip_atomic_load(&g.start_bit[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  for (uint32_t k = first + lane; go && k < last; k += 64u) {
+    if (start_of(k) == kSegNone) continue;
+    uint32_t j = k + 1u;
+    while (j < last && start_of(j) == kSegNone) j++;
+    const uint64_t off = __hip_atomic_load(&g.eff_tok_off[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t room_end = j < last ? __hip_atomic_load(&g.eff_tok_off[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : g.tok_off[last - 1u] + g.tok_cap[last - 1u];
+    if (room_end > off) g.eff_tok_cap[k] = room_end - off;
+  }
   if (lane == 0) g.go[bid] = go ? 1u : 0u;
 }
 
@@ -820,6 +837,19 @@ extern "C" void zh_launch_seg_check(hipStream_t stream, const uint8_t* d_src, Zh
     return e && strcmp(e, "serial") == 0 ? 1 : 0;
   }();
   hipLaunchKernelGGL(zh_seg_check_kernel, dim3(g.nfind), dim3(kFindSlots), 0, stream, d_src, a, g, serial);
+}
+// ZH_SEG_FAKE_START=<bit> (tests): bits that read like a block header and are none happen in any long stream's
+// payload, about once a GiB -- too rare for a test to wait for.  This plants one: the segment whose search range
+// holds stream bit `bit` reports a block start there (unless it found an earlier one), the way zh_seg_check_kernel
+// would have.
+__global__ __launch_bounds__(64) void zh_seg_fake_start_kernel(ZhSegArgs g, uint64_t bit) {
+  const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+  if (k >= g.nsegs || k == g.first_seg[g.parent[k]]) return;
+  if (g.nominal_bit[k] <= bit && bit < g.nominal_bit[k] + g.search_bits[k] && bit < g.start_bit[k]) g.start_bit[k] = bit;
+}
+extern "C" void zh_launch_seg_fake_start(hipStream_t stream, ZhSegArgs g, uint64_t bit) {
+  if (!g.nsegs) return;
+  hipLaunchKernelGGL(zh_seg_fake_start_kernel, dim3((g.nsegs + 63u) / 64u), dim3(64), 0, stream, g, bit);
 }
 extern "C" void zh_launch_seg_decide(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g) {
   if (!g.nsegs) return;

@@ -491,24 +491,38 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
 
   if (kSeg && phase == 0) {
     // ---- phase 0: a sub-start for this segment ----
-    // the block it lies in, if any found start tells: the nearest one before it
-    uint64_t hdr = kSegNone;
-    for (uint32_t k = sid, lo = g.first_seg[bid], n = 0; k > lo && n < 256u; n++) {
-      k--;
-      const uint64_t sk = g.start_bit[k];
-      if (sk != kSegNone) {
-        hdr = sk;
-        break;
-      }
-    }
-    uint64_t found = kSegNone;
+    // The block it lies in, if a found start tells: the nearest one before it -- if that IS a block's start.  Bits
+    // that read like a header and are none turn up about once a GiB of payload, and one such guess used to cost
+    // every segment from there to its block's end the sub-start (and their decoder, left alone with a dozen
+    // segments and more, its token room: the whole stream then fell back to one workgroup).  Tables read from
+    // such bits mostly do not decode the payload -- what passes for a header often has a distance code of one
+    // symbol, and the 64 decoders below meet invalid symbols within a few tokens --: when a header does not parse
+    // or its decoders die like that, the found start before it is asked, three at most.  (Not when they merely do
+    // not fall in step: any complete code "decodes" any bits, and an older block's tables would hand this segment
+    // a start that is none.)
+    uint64_t hdr = kSegNone, found = kSegNone;
     const uint64_t target = (uint64_t)mis * 8 + g.nominal_bit[sid];
-    // (a header less than a segment and a half back: the decoder that starts there is about to arrive
-    // anyway -- ordinary blocks of a few tens of KiB -- and parsing it once more costs more than it saves)
-    if (hdr != kSegNone && target < end * 8 && g.nominal_bit[sid] - hdr >= g.search_bits[sid] + g.search_bits[sid] / 2) {
-      pos = (uint64_t)mis * 8 + hdr;
+    const uint64_t end_bit = end * 8;
+    uint32_t k = sid, seen = 0;
+    for (uint32_t attempt = 0; attempt < 3u && target < end_bit; attempt++) {
+      uint64_t h = kSegNone;
+      for (const uint32_t lo = g.first_seg[bid]; k > lo && seen < 256u; seen++) {
+        k--;
+        const uint64_t sk = g.start_bit[k];
+        if (sk != kSegNone) {
+          h = sk;
+          break;
+        }
+      }
+      if (h == kSegNone) break;
+      hdr = h;
+      // (a header less than a segment and a half back: the decoder that starts there is about to arrive
+      // anyway -- ordinary blocks of a few tens of KiB -- and parsing it once more costs more than it saves)
+      if (g.nominal_bit[sid] - h < g.search_bits[sid] + g.search_bits[sid] / 2) break;
+      pos = (uint64_t)mis * 8 + h;
       parse_header();
       const uint64_t payload = s_c_pos;
+      uint32_t verdict = hdr_st == (uint32_t)ZH_OK ? 0u : 2u;  // 0 nothing here, 1 a sub-start, 2 this was no header
       if (hdr_st == (uint32_t)ZH_OK && s_c_btype != 0u && payload < target) {
         constexpr uint64_t kBefore = 4096;  // bits of run-up
         const bool exact = payload + kBefore >= target;  // (the block starts that close: no guessing)
@@ -517,7 +531,6 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
         __syncthreads();
         stage_super(base_bit);
         __syncthreads();
-        const uint64_t end_bit = end * 8;
         const uint32_t end_rel = (uint32_t)(end_bit - base_bit < 0xfffffff0ull ? end_bit - base_bit : 0xfffffff0ull);
         if (tid < 64u) {
           // 64 decoders a bit apart: after 4096 bits they have all fallen in step with the block's
@@ -527,8 +540,19 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
           const uint32_t e0 = zh_bcast(r.end);
           const uint64_t ok = __ballot(r.term == 0u && r.end == e0);
           if ((ok & 1ull) && __popcll(ok) >= 56) found = base_bit + e0 - (uint64_t)mis * 8;
+          // a real block's codes decode whatever bits they are given; decoders that meet invalid symbols by the
+          // dozen were handed tables that are not this payload's
+          const uint32_t dead = (uint32_t)__popcll(__ballot(r.term >= 2u && r.term != (uint32_t)ZH_ERR_END_OF_BUFFER));
+          verdict = found != kSegNone ? 1u : dead >= 16u ? 2u : 0u;
         }
       }
+      // (every thread has to know: the next attempt is the workgroup's)
+      if (tid == 0) s_wbytes[0] = verdict;
+      __syncthreads();
+      const uint32_t all = s_wbytes[0];
+      __syncthreads();
+      if (all != 2u) break;
+      hdr = kSegNone;
     }
     if (tid == 0) {
       g.sub_start[sid] = found;
@@ -600,16 +624,23 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
       if (kSeg) {
         const uint64_t rel = pos - (uint64_t)mis * 8;
         next_start(rel);
-        if (seg_tj < seg_last && seg_target != kSegNone && g.is_sub[seg_tj] && g.sub_hdr[seg_tj] == cur_hdr) {
-          if (seg_target == rel) {  // landed on it: that segment's decoder takes over
-            seg_landed = true;
-            break;
-          }
-          const uint64_t t_abs = seg_target + (uint64_t)mis * 8;
-          if (t_abs < base_bit + kSuperBits) {
-            cut_rel = (uint32_t)(t_abs - base_bit);
+        if (seg_tj < seg_last && seg_target == rel && g.is_sub[seg_tj] && g.sub_hdr[seg_tj] == cur_hdr) {
+          seg_landed = true;  // landed on it: that segment's decoder takes over
+          break;
+        }
+        // the first sub-start of THIS block inside the superchunk.  Found starts before it that are no such thing --
+        // bits of the payload that read like a header: the decoder runs past them -- must not hide it: without the
+        // cut this decoder takes the rest of the superchunk, the tokens of a dozen segments that have decoders
+        // and regions of their own, and runs out of room.
+        const uint64_t super_end = base_bit + kSuperBits - (uint64_t)mis * 8;  // (stream bits)
+        for (uint32_t cj = seg_tj; cj < seg_last && g.nominal_bit[cj] < super_end; cj++) {
+          const uint64_t ct = cj == seg_tj ? seg_target : g.start_bit[cj];
+          if (ct == kSegNone || ct <= rel || !g.is_sub[cj] || g.sub_hdr[cj] != cur_hdr) continue;
+          if (ct < super_end) {
+            cut_rel = (uint32_t)(ct + (uint64_t)mis * 8 - base_bit);
             cut_t = (cut_rel - 1u) / kSubBits;
           }
+          break;
         }
       }
       __syncthreads();  // (everybody is done with the previous contents of s_in)

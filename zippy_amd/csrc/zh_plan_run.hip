@@ -149,6 +149,60 @@ __global__ __launch_bounds__(256) void zh_zero_slots_kernel(uint8_t* __restrict_
   }
 }
 
+// ZH_TRACE_SEG: why a large stream was not decoded segment-wise (the run waits for the chain kernel and reads its
+// verdicts back; a stream whose chain does not hold is decoded by one workgroup, correctly and slowly)
+static void seg_trace(zh_plan* p, hipStream_t s) {
+  const ZhSegArgs& g = p->sg;
+  if (hipStreamSynchronize(s) != hipSuccess) return;
+  std::vector<uint32_t> first(g.nstreams + 1), go(g.nstreams), ok(g.nstreams), nchain(g.nstreams);
+  (void)hipMemcpy(first.data(), g.first_seg, first.size() * 4, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(go.data(), g.go, go.size() * 4, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(ok.data(), g.stream_ok, ok.size() * 4, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(nchain.data(), g.nchain, nchain.size() * 4, hipMemcpyDeviceToHost);
+  for (uint32_t i = 0; i < g.nstreams; i++) {
+    const uint32_t n = first[i + 1] - first[i];
+    if (!n) continue;
+    fprintf(stderr, "zippy_hip: stream %u: %u segments, go %u, chain holds %u, %u on it\n", i, n, go[i], ok[i], nchain[i]);
+    if (ok[i]) continue;
+    std::vector<uint64_t> nominal(n), start(n), end(n), out(n), cap(n);
+    std::vector<int32_t> st(n);
+    std::vector<uint32_t> fin(n), sub(n);
+    (void)hipMemcpy(nominal.data(), g.nominal_bit + first[i], n * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(start.data(), g.start_bit + first[i], n * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(end.data(), g.end_bit + first[i], n * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(out.data(), g.seg_out + first[i], n * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(cap.data(), g.eff_tok_cap + first[i], n * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(st.data(), g.seg_status + first[i], n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(fin.data(), g.final_block + first[i], n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(sub.data(), g.is_sub + first[i], n * 4, hipMemcpyDeviceToHost);
+    // follow the chain the way zh_seg_chain_kernel does, and say where it ends
+    uint64_t want = start[0];
+    uint32_t k = 0, links = 0, none = 0, bad = 0;
+    for (uint32_t j = 0; j < n; j++) {
+      none += start[j] == ~0ull;
+      bad += start[j] != ~0ull && st[j] != 0;
+    }
+    fprintf(stderr, "  %u segments without a start, %u with a failed decoder\n", none, bad);
+    while (k < n) {
+      while (k < n && start[k] != want) k++;
+      if (k == n) break;
+      links++;
+      if (st[k] != 0 || fin[k]) break;
+      want = end[k];
+    }
+    const uint32_t lo = k < n ? k : 0;
+    fprintf(stderr, "  chain: %u links, %s; wanted bit %llu\n", links,
+            k == n ? "no segment starts where the last one stopped" : st[k] ? "a decoder failed" : "reached the last block",
+            (unsigned long long)want);
+    uint32_t near = 0;
+    while (near + 1 < n && nominal[near + 1] <= want) near++;
+    for (uint32_t j = (k == n ? near : lo) > 2 ? (k == n ? near : lo) - 2 : 0; j < n && j < (k == n ? near : lo) + 4; j++)
+      fprintf(stderr, "  seg %u: nominal %llu start %lld (sub %u) end %llu status %d final %u out %llu tokens' room %llu\n", j,
+              (unsigned long long)nominal[j], (long long)start[j], sub[j], (unsigned long long)end[j], st[j], fin[j],
+              (unsigned long long)out[j], (unsigned long long)cap[j]);
+  }
+}
+
 extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
   if (!p) return ZH_ERR_ARGUMENT;
   zh_ctx* ctx = p->ctx;
@@ -235,6 +289,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       zh_launch_seg_find(s, d_src, a, p->sg);
       prof_mark(p, "zh_seg_check_kernel");
       zh_launch_seg_check(s, d_src, a, p->sg);
+      if (const char* e = getenv("ZH_SEG_FAKE_START")) zh_launch_seg_fake_start(s, p->sg, strtoull(e, nullptr, 10));
       prof_mark(p, "zh_seg_substart_kernel");
       zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 0);
       zh_launch_seg_decide(s, a, p->sg);
@@ -242,6 +297,8 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 1);
       prof_mark(p, "zh_seg_chain_kernel");
       zh_launch_seg_chain(s, a, p->sg);
+      p->seg_ran = true;
+      if (getenv("ZH_TRACE_SEG")) seg_trace(p, s);
       if (!a.count_only) {
         prof_mark(p, "zh_seg_write_kernel");
         zh_launch_seg_write(s, d_src, a, p->tok_pool, p->sg);
@@ -307,6 +364,24 @@ extern "C" int zh_plan_results(zh_plan* p, uint64_t* out_lens, int32_t* statuses
   if (out_lens) ZH_HIP(ctx, hipMemcpyAsync(out_lens, p->out_len, p->n * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (statuses) ZH_HIP(ctx, hipMemcpyAsync(statuses, p->status, p->n * 4, hipMemcpyDeviceToHost, ctx->stream));
   ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!p->is_compress && p->segmented && p->seg_ran) {  // zh_debug_segment_stats
+    p->seg_ran = false;
+    const ZhSegArgs& g = p->sg;
+    std::vector<uint32_t> first(g.nstreams + 1), ok(g.nstreams);
+    ZH_HIP(ctx, hipMemcpy(first.data(), g.first_seg, first.size() * 4, hipMemcpyDeviceToHost));
+    ZH_HIP(ctx, hipMemcpy(ok.data(), g.stream_ok, ok.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < g.nstreams; i++)
+      if (first[i + 1] > first[i]) {
+        ctx->seg_cut++;
+        ctx->seg_held += ok[i] != 0;
+      }
+  }
+  return ZH_OK;
+}
+extern "C" int zh_debug_segment_stats(zh_ctx* ctx, uint64_t* cut, uint64_t* held) {
+  if (!ctx) return ZH_ERR_ARGUMENT;
+  if (cut) *cut = ctx->seg_cut;
+  if (held) *held = ctx->seg_held;
   return ZH_OK;
 }
 extern "C" int zh_plan_request_crc32(zh_plan* p, int on) {
