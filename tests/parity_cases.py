@@ -899,6 +899,20 @@ def check_segmented(eng, scale, monkeypatch, seg_bytes):
             outs, sts = eng.uncompress_batch([blob], fmt)
             cut, held = (a - b for a, b in zip(eng.segment_stats(), before))
             assert sts == [0] and outs[0] == plain and cut >= 1 and held == cut, (fmt, len(blob), fake_bit, sts, cut, held)
+    # ... and such a guess just BEFORE a real block start of the same segment (blocks of many segments: the block-parallel
+    # form's, 32 KiB of input each): a segment reports the lowest position that passes for a start, so the guess used to
+    # hide the start every segment of the block behind it needs; a segment keeps two candidates now and the first is
+    # probed (a superchunk decoded) before anybody relies on it
+    if seg_bytes <= 2048:
+        src = synth.gen_batch("text", 1, 200 * scale, first_index=3)[0].tobytes()
+        blob, index = eng.compress_blocks(src, 1, oracle.dfGzip, 32 * scale)
+        for j in (2, 4):
+            for back in (40, 300):
+                monkeypatch.setenv("ZH_SEG_FAKE_START", str(index[j][0] - back))
+                before = eng.segment_stats()
+                outs, sts = eng.uncompress_batch([blob], oracle.dfGzip)
+                cut, held = (a - b for a, b in zip(eng.segment_stats(), before))
+                assert sts == [0] and outs[0] == src and cut >= 1 and held == cut, (j, back, sts, cut, held)
     monkeypatch.delenv("ZH_SEG_FAKE_START")
     # a batch of them at once (same format), small streams (no segments) in between: zlib streams
     zl = [c for c in cases if c[1] == oracle.dfZlib]

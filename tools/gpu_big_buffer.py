@@ -17,7 +17,9 @@ import zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(mib, level=1, with_oracle=True, with_zlib=True):
+def run(mib, level=1, with_oracle=True, with_zlib=True, kind="mix", foreign=None):
+    """kind: synth.gen_batch's (mix, text, rand, zeros, runs ...); foreign: the stream is made by system zlib at that
+    level instead (one gzip member; only the decoder is under test then)."""
     import argparse as _a
     args = _a.Namespace(mib=mib, level=level, no_oracle=not with_oracle)
     import numpy as np
@@ -31,7 +33,7 @@ def run(mib, level=1, with_oracle=True, with_zlib=True):
     per = 512
     for i in range(0, args.mib, per):  # G-mix, 512 MiB at a time
         k = min(per, args.mib - i)
-        host[i << 20:(i + k) << 20] = synth.gen_batch("mix", k, 1 << 20, first_index=i).reshape(-1)
+        host[i << 20:(i + k) << 20] = synth.gen_batch(kind, k, 1 << 20, first_index=i).reshape(-1)
     host[args.mib << 20:] = np.arange(12345, dtype=np.uint32).astype(np.uint8)
     t_gen = time.perf_counter() - t
     stream = torch.cuda.current_stream()
@@ -41,10 +43,17 @@ def run(mib, level=1, with_oracle=True, with_zlib=True):
     cap = eng.compress_bound(n, api.dfGzip)
     d_comp = torch.zeros(cap + 256, dtype=torch.uint8, device="cuda")
     d_back = torch.empty(n + 256, dtype=torch.uint8, device="cuda")
-    cplan = eng.plan_compress([0], [n], [0], [cap], args.level, api.dfGzip)
-    torch.cuda.synchronize()
     t_c = []
-    for _ in range(2):  # (a plan's first run also pays for its scratch)
+    if foreign is not None:
+        c = zlib.compressobj(foreign, zlib.DEFLATED, 31)
+        zz = c.compress(host) + c.flush()
+        clens = [len(zz)]
+        d_comp[:len(zz)] = torch.frombuffer(bytearray(zz), dtype=torch.uint8).cuda()
+        del zz
+    else:
+        cplan = eng.plan_compress([0], [n], [0], [cap], args.level, api.dfGzip)
+    torch.cuda.synchronize()
+    for _ in range(0 if foreign is not None else 2):  # (a plan's first run also pays for its scratch)
         d_comp.zero_()
         torch.cuda.synchronize()
         t = time.perf_counter()
@@ -83,7 +92,10 @@ def run(mib, level=1, with_oracle=True, with_zlib=True):
     res = {"bytes": n, "level": args.level, "compressed_bytes": clens[0], "compress_s": [round(x, 3) for x in t_c],
            "uncompress_s": [round(x, 3) for x in t_u], "uncompress_kernels_ms": kernels, "gen_s": round(t_gen, 1), "zlib_ok": bool(with_zlib), "trailer_ok": True,
            "decoded_segment_wise": held == cut and cut >= 2}  # (both runs: by many workgroups, zh_debug_segment_stats)
-    if not args.no_oracle:
+    res["kind"] = kind
+    if foreign is not None:
+        res["made_by"] = "system zlib level %d" % foreign
+    if not args.no_oracle and foreign is None:
         import oracle
         t = time.perf_counter()
         ref = oracle.compress(host, args.level, oracle.dfGzip, fname_len=0)
@@ -98,8 +110,11 @@ def main():
     ap.add_argument("--mib", type=int, default=4100)
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--no-zlib", action="store_true")
+    ap.add_argument("--kind", default="mix")
+    ap.add_argument("--foreign", type=int, default=None)
     args = ap.parse_args()
-    print(json.dumps(run(args.mib, args.level, not args.no_oracle)))
+    print(json.dumps(run(args.mib, args.level, not args.no_oracle, not args.no_zlib, args.kind, args.foreign)))
 
 
 if __name__ == "__main__":

@@ -127,6 +127,7 @@ struct ZhInflateArgs {
 // into segments; a segment's decoder starts at the first deflate block found at or behind the
 // segment's nominal first bit and stops at the block boundary where the next segment's begins.
 constexpr uint64_t kSegNone = ~0ull;
+constexpr uint32_t kSegFindSlots = 256;  // candidates a search batch hands on (ZhSegArgs.cand_off: zh_inflate_seg.hip, the plan's arena)
 struct ZhSegArgs {
   uint32_t nsegs, nstreams;
   const uint32_t* parent;       // [nsegs] the stream a segment belongs to
@@ -151,6 +152,8 @@ struct ZhSegArgs {
   uint32_t* is_sub;             // [nsegs] start_bit is such a boundary, not a block start
   // find / tokens results
   uint64_t* start_bit;          // [nsegs] first bit of the segment's first block, or kSegNone
+  uint64_t* start2_bit;         // [nsegs] the next position of the segment that reads like a block's start (the probe of
+                                //   zh_inflate_tokens_kernel falls back on it), or kSegNone
   uint64_t* end_bit;            // [nsegs] the block boundary the tokens kernel stopped at
   uint32_t* final_block;        // [nsegs] ... which was the end of the stream
   int32_t* seg_status;          // [nsegs] tokens kernel, then writer
@@ -163,6 +166,7 @@ struct ZhSegArgs {
   uint32_t* stream_ok;          // [nstreams] the chain holds: the stream is decoded segment-wise
   uint32_t* order;              // [nsegs] a stream's chain segments in order, from first_seg[i] on
   uint32_t* nchain;             // [nstreams] ... and how many they are
+  uint32_t* repair;             // [nstreams] the chain did not hold, found starts that were none are out: once more (zh_seg_repair_kernel)
   uint32_t* ordinal;            // [nsegs] a chain segment's place in that order
   // 16-bit output symbols (a byte, or 0x8000 | index into the 32 KiB window before the segment)
   uint16_t* sym;

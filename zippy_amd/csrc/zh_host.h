@@ -47,8 +47,9 @@ void zh_launch_seg_find(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, ZhSe
 void zh_launch_seg_fake_start(hipStream_t, ZhSegArgs g, uint64_t bit);
 void zh_launch_seg_check(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_seg_tokens(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, uint32_t* tok_pool, ZhSegArgs g, int phase);
-void zh_launch_seg_decide(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
-void zh_launch_seg_chain(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
+void zh_launch_seg_decide(hipStream_t, ZhInflateArgs a, ZhSegArgs g, int rerun);
+void zh_launch_seg_chain(hipStream_t, ZhInflateArgs a, ZhSegArgs g, int rerun);
+void zh_launch_seg_repair(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_seg_write(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, const uint32_t* tok_pool, ZhSegArgs g);
 void zh_launch_seg_windows(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_seg_finish(hipStream_t, uint8_t* d_dst, ZhInflateArgs a, ZhSegArgs g);
@@ -223,6 +224,7 @@ struct zh_plan {
   // with the token pool
   bool segmented = false;
   bool seg_ran = false;  // the segment kernels of a run whose results have not been read yet
+  int sg_repair_rounds = 1;  // zh_seg_repair_kernel: twice where there is a lot to go wrong (plan_segments)
   ZhSegArgs sg{};
   uint8_t* sg_arena = nullptr;
   uint16_t* sg_sym = nullptr;

@@ -59,7 +59,9 @@ namespace {
 
 constexpr uint32_t kFindThreads = 256;
 constexpr uint32_t kFindBatch = 65536;  // bit positions a workgroup of the search takes
-constexpr uint32_t kFindSlots = 64;     // candidates it can hand on
+constexpr uint32_t kFindSlots = kSegFindSlots;  // candidates it can hand on (measured on 1 GiB streams of this library: 32-39 a batch on
+                                        // average, 700 at most; with 64 slots a batch in six of a stream of literals dropped some --
+                                        // among them block starts that every segment of a 4 MiB block depends on)
 constexpr uint32_t kWin = 32768;
 
 // A batch of the search: 65536 bit positions and the 74 bits of header behind the last of them,
@@ -239,8 +241,10 @@ __global__ __launch_bounds__(kFindThreads) void zh_seg_find_kernel(const uint8_t
   const uint32_t bid = g.parent[sid];
   const bool first = sid == g.first_seg[bid];
   const bool live = a.status[bid] == ZH_OK;
-  if (batch == 0 && tid == 0)  // the stream's first block: behind the container header, exact
+  if (batch == 0 && tid == 0) {  // the stream's first block: behind the container header, exact
     g.start_bit[sid] = first && live ? (uint64_t)a.body_pos[bid] * 8 : kSegNone;
+    g.start2_bit[sid] = kSegNone;
+  }
   if (first || !live) return;
   const ZhBufDesc bd = a.bufs[bid];
   const uint8_t* src = d_src + bd.src_off;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(kFindThreads) void zh_seg_find_kernel(const uint8_t
   // fifteen a batch)
   const uint32_t nc = s_ncand < kFindSlots ? s_ncand : kFindSlots;
   if (tid < nc) g.cand_off[(size_t)blockIdx.x * kFindSlots + tid] = s_cand[tid];
-  if (tid == 0) g.cand_n[blockIdx.x] = nc;
+  if (tid == 0) g.cand_n[blockIdx.x] = s_ncand;  // (all of them: who reads the queue clamps; ZH_TRACE_SEG counts the overflows)
   KPROF_FLUSH(56, 8);
 }
 
@@ -434,12 +438,19 @@ __device__ bool seg_lengths_ok_wave(const uint8_t* src, uint64_t len, uint64_t p
 
 // A wave per batch of the search: its queued candidates, one after the other; the segment keeps its
 // lowest position that passes.
-__global__ __launch_bounds__(kFindSlots) void zh_seg_check_kernel(const uint8_t* __restrict__ d_src, ZhInflateArgs a,
+// A segment keeps the TWO lowest positions that read like a block's start: what reads like one and is none (bits of
+// a payload: about one a GiB, many more in streams of literals only) would otherwise hide the block start behind it
+// in the same segment -- and with blocks of many segments that start is the one every segment of its block needs.
+__device__ __forceinline__ void seg_note_start(const ZhSegArgs& g, uint32_t sid, uint64_t p) {
+  const uint64_t old = atomicMin((unsigned long long*)&g.start_bit[sid], (unsigned long long)p);
+  if (old != p) atomicMin((unsigned long long*)&g.start2_bit[sid], (unsigned long long)(old > p ? old : p));
+}
+__global__ __launch_bounds__(64) void zh_seg_check_kernel(const uint8_t* __restrict__ d_src, ZhInflateArgs a,
                                                                   ZhSegArgs g, int serial) {
   __shared__ uint8_t s_lut[128];
   __shared__ uint32_t s_hdr[kHdrWords + 2];
   const uint32_t w = blockIdx.x, lane = threadIdx.x;
-  const uint32_t nc = g.cand_n[w];
+  const uint32_t nc = g.cand_n[w] < kFindSlots ? g.cand_n[w] : kFindSlots;
   if (!nc) return;
   const uint32_t sid = g.find_seg[w];
   const uint64_t base = g.nominal_bit[sid] + (uint64_t)(g.find_batch[w] & 0x7fffffffu) * kFindBatch;
@@ -447,23 +458,26 @@ __global__ __launch_bounds__(kFindSlots) void zh_seg_check_kernel(const uint8_t*
   const ZhBufDesc bd = a.bufs[bid];
   const uint64_t len = a.src_len_dev ? a.src_len_dev[bid] : bd.src_len;
   if (serial) {  // a thread per candidate
-    if (lane >= nc) return;
-    const uint64_t p = base + g.cand_off[(size_t)w * kFindSlots + lane];
-    if (p >= *(volatile uint64_t*)&g.start_bit[sid]) return;  // (a lower position has passed already)
-    if (seg_lengths_ok(d_src + bd.src_off, len, p)) atomicMin((unsigned long long*)&g.start_bit[sid], (unsigned long long)p);
+    for (uint32_t c = lane; c < nc; c += 64u) {
+      const uint64_t p = base + g.cand_off[(size_t)w * kFindSlots + c];
+      if (p >= *(volatile uint64_t*)&g.start2_bit[sid]) continue;  // (two lower positions have passed already)
+      if (seg_lengths_ok(d_src + bd.src_off, len, p)) seg_note_start(g, sid, p);
+    }
     return;
   }
-  const uint32_t mine = lane < nc ? g.cand_off[(size_t)w * kFindSlots + lane] : 0u;
   KPROF_DECL(8);  // cycles: 0 set-up, 1 candidates; counts: 3 candidates, 4 passed, 5 waves
   KPROF_COUNT(5, 1);
   KPROF_MARK(0);
-  for (uint32_t c = 0; c < nc; c++) {
-    const uint64_t p = base + (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)c);
-    if (p >= zh_bcast64(*(volatile uint64_t*)&g.start_bit[sid])) continue;  // (a lower position has passed already)
-    KPROF_COUNT(3, 1);
-    if (seg_lengths_ok_wave(d_src + bd.src_off, len, p, s_lut, s_hdr)) {
-      KPROF_COUNT(4, 1);
-      if (lane == 0) atomicMin((unsigned long long*)&g.start_bit[sid], (unsigned long long)p);
+  for (uint32_t c0 = 0; c0 < nc; c0 += 64u) {
+    const uint32_t mine = c0 + lane < nc ? g.cand_off[(size_t)w * kFindSlots + c0 + lane] : 0u;
+    for (uint32_t c = 0; c < 64u && c0 + c < nc; c++) {
+      const uint64_t p = base + (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)c);
+      if (p >= zh_bcast64(*(volatile uint64_t*)&g.start2_bit[sid])) continue;  // (two lower positions have passed already)
+      KPROF_COUNT(3, 1);
+      if (seg_lengths_ok_wave(d_src + bd.src_off, len, p, s_lut, s_hdr)) {
+        KPROF_COUNT(4, 1);
+        if (lane == 0) seg_note_start(g, sid, p);
+      }
     }
   }
   KPROF_MARK(1);
@@ -477,9 +491,10 @@ __global__ __launch_bounds__(kFindSlots) void zh_seg_check_kernel(const uint8_t*
 // the starts): only a group's first found start keeps its decoder, and that decoder gets the token
 // regions of the whole group, which lie back to back -- so that a region holds the tokens of a
 // block or two whatever the block size.
-__global__ __launch_bounds__(64) void zh_seg_decide_kernel(ZhInflateArgs a, ZhSegArgs g) {
+__global__ __launch_bounds__(64) void zh_seg_decide_kernel(ZhInflateArgs a, ZhSegArgs g, int rerun) {
   const uint32_t bid = blockIdx.x;
   const unsigned lane = zh_lane();
+  if (rerun && !g.repair[bid]) return;
   const uint32_t first = g.first_seg[bid], last = g.first_seg[bid + 1u], n = last - first;
   // segments inside long blocks take the sub-starts phase 0 of the tokens kernel guessed for them
   uint32_t found = 0;
@@ -537,12 +552,45 @@ __global__ __launch_bounds__(64) void zh_seg_decide_kernel(ZhInflateArgs a, ZhSe
   if (lane == 0) g.go[bid] = go ? 1u : 0u;
 }
 
+// One wave per stream, behind the chain kernel: a chain that does not hold, ONCE MORE without the found starts that
+// were none.  Bits of a payload that read like a block header turn up about once a GiB (in streams of literals
+// only: dozens), and where blocks are many segments long such a guess costs more than its own decoder: the
+// segments behind it take their sub-starts from its "tables" and find none or wrong ones, it may hide the block's
+// real start behind it in the same segment, and the decoder before is left alone with the rest of its block until
+// its token room runs out -- the chain breaks and the whole stream falls back to one workgroup, a hundred times
+// slower.  What is none gives itself away: its decoder fails within a few hundred bytes (an invalid symbol, a
+// distance before the start of the data, an "end of block" with no header behind it), which in a sound stream no
+// real block's decoder does.  So: every found start whose decoder failed makes room for its segment's second
+// candidate (g.start2_bit), every sub-start is forgotten, and phase 0, the decision, the tokens and the chain run
+// again for this stream (g.repair).  A damaged stream fails again and goes to the ordinary kernels, which report
+// what is wrong with it.
+__global__ __launch_bounds__(64) void zh_seg_repair_kernel(ZhInflateArgs a, ZhSegArgs g) {
+  const uint32_t bid = blockIdx.x;
+  const unsigned lane = zh_lane();
+  const uint32_t first = g.first_seg[bid], last = g.first_seg[bid + 1u];
+  const bool broken = last > first && a.status[bid] == ZH_OK && g.go[bid] != 0u && g.stream_ok[bid] == 0u;
+  uint32_t dropped = 0;
+  for (uint32_t k = first + 1u + lane; broken && k < last; k += 64u) {  // (the stream's first block is where it is)
+    if (g.start_bit[k] == kSegNone) continue;
+    if (g.is_sub[k]) {
+      g.start_bit[k] = kSegNone;
+    } else if (g.seg_status[k] != ZH_OK && g.seg_status[k] != ZH_ERR_DST_TOO_SMALL) {
+      g.start_bit[k] = g.start2_bit[k];
+      g.start2_bit[k] = kSegNone;
+      dropped++;
+    }
+  }
+  dropped = zh_wave_sum(dropped);
+  if (lane == 0) g.repair[bid] = dropped ? 1u : 0u;
+}
+
 // One wave per stream: the chain of segments.  It starts with the stream's first segment; the next
 // link is the segment whose found start is exactly where the decoder of the last one stopped (it
 // stops nowhere else, unless the stream ends or fails); found starts in between were wrong guesses.
-__global__ __launch_bounds__(64) void zh_seg_chain_kernel(ZhInflateArgs a, ZhSegArgs g) {
+__global__ __launch_bounds__(64) void zh_seg_chain_kernel(ZhInflateArgs a, ZhSegArgs g, int rerun) {
   const uint32_t bid = blockIdx.x;
   const unsigned lane = zh_lane();
+  if (rerun && !g.repair[bid]) return;
   const uint32_t first = g.first_seg[bid], last = g.first_seg[bid + 1u];
   bool ok = a.status[bid] == ZH_OK && g.go[bid] != 0u;
   bool done = false;
@@ -641,7 +689,9 @@ __global__ __launch_bounds__(64) void zh_seg_chain_kernel(ZhInflateArgs a, ZhSeg
     c += 64u;
     load_chunk();
   }
-  ok = ok && done;
+  // (a chain of a few links -- a stream of stored blocks: no starts to land on, the first decoder has taken it all --
+  // is one workgroup's work whatever it is called, and the ordinary kernels are the faster way to do that)
+  ok = ok && done && nchain >= 4u;
   bool write = ok;
   if (ok && a.count_only) {  // a sizing pass: `total` is the answer
     write = false;
@@ -836,7 +886,7 @@ extern "C" void zh_launch_seg_check(hipStream_t stream, const uint8_t* d_src, Zh
     const char* e = getenv("ZH_SEG_CHECK");
     return e && strcmp(e, "serial") == 0 ? 1 : 0;
   }();
-  hipLaunchKernelGGL(zh_seg_check_kernel, dim3(g.nfind), dim3(kFindSlots), 0, stream, d_src, a, g, serial);
+  hipLaunchKernelGGL(zh_seg_check_kernel, dim3(g.nfind), dim3(64), 0, stream, d_src, a, g, serial);
 }
 // ZH_SEG_FAKE_START=<bit> (tests): bits that read like a block header and are none happen in any long stream's
 // payload, about once a GiB -- too rare for a test to wait for.  This plants one: the segment whose search range
@@ -845,19 +895,30 @@ extern "C" void zh_launch_seg_check(hipStream_t stream, const uint8_t* d_src, Zh
 __global__ __launch_bounds__(64) void zh_seg_fake_start_kernel(ZhSegArgs g, uint64_t bit) {
   const uint32_t k = blockIdx.x * 64u + threadIdx.x;
   if (k >= g.nsegs || k == g.first_seg[g.parent[k]]) return;
-  if (g.nominal_bit[k] <= bit && bit < g.nominal_bit[k] + g.search_bits[k] && bit < g.start_bit[k]) g.start_bit[k] = bit;
+  if (g.nominal_bit[k] <= bit && bit < g.nominal_bit[k] + g.search_bits[k]) {
+    if (bit < g.start_bit[k]) {
+      g.start2_bit[k] = g.start_bit[k];
+      g.start_bit[k] = bit;
+    } else if (bit > g.start_bit[k] && bit < g.start2_bit[k]) {
+      g.start2_bit[k] = bit;
+    }
+  }
 }
 extern "C" void zh_launch_seg_fake_start(hipStream_t stream, ZhSegArgs g, uint64_t bit) {
   if (!g.nsegs) return;
   hipLaunchKernelGGL(zh_seg_fake_start_kernel, dim3((g.nsegs + 63u) / 64u), dim3(64), 0, stream, g, bit);
 }
-extern "C" void zh_launch_seg_decide(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g) {
+extern "C" void zh_launch_seg_decide(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g, int rerun) {
   if (!g.nsegs) return;
-  hipLaunchKernelGGL(zh_seg_decide_kernel, dim3(g.nstreams), dim3(64), 0, stream, a, g);
+  hipLaunchKernelGGL(zh_seg_decide_kernel, dim3(g.nstreams), dim3(64), 0, stream, a, g, rerun);
 }
-extern "C" void zh_launch_seg_chain(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g) {
+extern "C" void zh_launch_seg_chain(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g, int rerun) {
   if (!g.nstreams) return;
-  hipLaunchKernelGGL(zh_seg_chain_kernel, dim3(g.nstreams), dim3(64), 0, stream, a, g);
+  hipLaunchKernelGGL(zh_seg_chain_kernel, dim3(g.nstreams), dim3(64), 0, stream, a, g, rerun);
+}
+extern "C" void zh_launch_seg_repair(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g) {
+  if (!g.nstreams) return;
+  hipLaunchKernelGGL(zh_seg_repair_kernel, dim3(g.nstreams), dim3(64), 0, stream, a, g);
 }
 extern "C" void zh_launch_seg_windows(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g) {
   if (!g.nstreams) return;

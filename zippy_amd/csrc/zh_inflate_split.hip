@@ -150,6 +150,10 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
   uint64_t seg_start = 0, seg_target = 0, cur_hdr = kSegNone;
   uint32_t seg_tj = sid, seg_last = 0;
   bool sub_first = false, seg_landed = false;
+  // A rerun (phases 4 / 5 = 0 / 1 once more, zh_seg_repair_kernel): only the streams under repair.
+  const bool rerun = kSeg && phase >= 4;
+  phase &= 3;
+  if (rerun && !g.repair[bid]) return;
   if (kSeg && phase != 0) {
     if (!g.go[bid]) return;  // too few starts were found: the stream is left to the ordinary kernels
     seg_start = g.start_bit[sid];
@@ -491,39 +495,32 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
 
   if (kSeg && phase == 0) {
     // ---- phase 0: a sub-start for this segment ----
-    // The block it lies in, if a found start tells: the nearest one before it -- if that IS a block's start.  Bits
-    // that read like a header and are none turn up about once a GiB of payload, and one such guess used to cost
-    // every segment from there to its block's end the sub-start (and their decoder, left alone with a dozen
-    // segments and more, its token room: the whole stream then fell back to one workgroup).  Tables read from
-    // such bits mostly do not decode the payload -- what passes for a header often has a distance code of one
-    // symbol, and the 64 decoders below meet invalid symbols within a few tokens --: when a header does not parse
-    // or its decoders die like that, the found start before it is asked, three at most.  (Not when they merely do
-    // not fall in step: any complete code "decodes" any bits, and an older block's tables would hand this segment
-    // a start that is none.)
-    uint64_t hdr = kSegNone, found = kSegNone;
+    // The block it lies in, if a found start tells: the nearest one before it -- if that IS a block's start.  Bits of a
+    // payload that read like a header (about one a GiB; dozens in a stream of literals only) mislead every segment
+    // from there to their block's end.  Tables that are not the payload's all but never bring the 64 decoders below
+    // in step (and what does not even read as a dynamic block, the only kind the search finds, is no header at all),
+    // while a real block's tables all but always do: when a header yields nothing it is doubted, not the method, and
+    // the found start before it is asked as well.  (What this lets through, its own decoder gives away:
+    // zh_seg_repair_kernel.)
+    uint64_t hdr = kSegNone, found = kSegNone, payload = 0;
     const uint64_t target = (uint64_t)mis * 8 + g.nominal_bit[sid];
     const uint64_t end_bit = end * 8;
-    uint32_t k = sid, seen = 0;
-    for (uint32_t attempt = 0; attempt < 3u && target < end_bit; attempt++) {
-      uint64_t h = kSegNone;
-      for (const uint32_t lo = g.first_seg[bid]; k > lo && seen < 256u; seen++) {
-        k--;
-        const uint64_t sk = g.start_bit[k];
-        if (sk != kSegNone) {
-          h = sk;
-          break;
-        }
-      }
-      if (h == kSegNone) break;
-      hdr = h;
+    bool readable = false;
+    for (uint32_t k = sid, lo = g.first_seg[bid], n = 0, tried = 0; k > lo && n < 256u && tried < 2u && target < end_bit; n++) {
+      k--;
+      const uint64_t sk = g.start_bit[k];
+      if (sk == kSegNone) continue;
+      hdr = sk;
       // (a header less than a segment and a half back: the decoder that starts there is about to arrive
       // anyway -- ordinary blocks of a few tens of KiB -- and parsing it once more costs more than it saves)
-      if (g.nominal_bit[sid] - h < g.search_bits[sid] + g.search_bits[sid] / 2) break;
-      pos = (uint64_t)mis * 8 + h;
+      if (g.nominal_bit[sid] - hdr < g.search_bits[sid] + g.search_bits[sid] / 2) break;
+      tried++;
+      pos = (uint64_t)mis * 8 + hdr;
       parse_header();
-      const uint64_t payload = s_c_pos;
-      uint32_t verdict = hdr_st == (uint32_t)ZH_OK ? 0u : 2u;  // 0 nothing here, 1 a sub-start, 2 this was no header
-      if (hdr_st == (uint32_t)ZH_OK && s_c_btype != 0u && payload < target) {
+      payload = s_c_pos;
+      // (the search only ever finds dynamic blocks; other kinds begin a stream -- or sit where ZH_SEG_FAKE_START put them)
+      readable = hdr_st == (uint32_t)ZH_OK && (s_c_btype == 2u || (k == lo && s_c_btype != 0u)) && payload < target;
+      if (readable) {
         constexpr uint64_t kBefore = 4096;  // bits of run-up
         const bool exact = payload + kBefore >= target;  // (the block starts that close: no guessing)
         const uint64_t s0 = exact ? payload : target - kBefore;
@@ -540,21 +537,22 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
           const uint32_t e0 = zh_bcast(r.end);
           const uint64_t ok = __ballot(r.term == 0u && r.end == e0);
           if ((ok & 1ull) && __popcll(ok) >= 56) found = base_bit + e0 - (uint64_t)mis * 8;
-          // a real block's codes decode whatever bits they are given; decoders that meet invalid symbols by the
-          // dozen were handed tables that are not this payload's
-          const uint32_t dead = (uint32_t)__popcll(__ballot(r.term >= 2u && r.term != (uint32_t)ZH_ERR_END_OF_BUFFER));
-          verdict = found != kSegNone ? 1u : dead >= 16u ? 2u : 0u;
         }
       }
       // (every thread has to know: the next attempt is the workgroup's)
-      if (tid == 0) s_wbytes[0] = verdict;
+      if (tid == 0) s_wbytes[0] = found != kSegNone ? 1u : 0u;
       __syncthreads();
-      const uint32_t all = s_wbytes[0];
+      const bool got = s_wbytes[0] != 0u;
       __syncthreads();
-      if (all != 2u) break;
-      hdr = kSegNone;
+      if (got) break;
+      if (k == lo) break;  // (nothing lies before the stream's first block)
     }
     if (tid == 0) {
+#ifdef ZH_EMU
+      if (getenv("ZH_DBG_SUB"))
+        fprintf(stderr, "  segment %u (nominal %llu): header %lld readable %d payload %llu -> sub-start %lld\n", sid,
+                (unsigned long long)g.nominal_bit[sid], (long long)hdr, (int)readable, (unsigned long long)payload, (long long)found);
+#endif
       g.sub_start[sid] = found;
       g.sub_hdr[sid] = hdr;
     }
@@ -1230,7 +1228,8 @@ extern "C" void zh_launch_inflate_tokens(hipStream_t stream, const uint8_t* d_sr
   else
     hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, false>), dim3(a.nbufs), dim3(256), 0, stream, d_src, a, tok_pool, tok_off, tok_cap, ZhSegArgs{}, 1);
 }
-// phase 0: sub-starts for the segments inside long blocks (before zh_seg_decide_kernel); phase 1: the tokens
+// phase 0: sub-starts for the segments inside long blocks
+// (before zh_seg_decide_kernel); phase 1: the tokens; 4 / 5: the same once more for the streams under repair
 extern "C" void zh_launch_seg_tokens(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a, uint32_t* tok_pool,
                                      ZhSegArgs g, int phase) {
   if (!g.nsegs) return;

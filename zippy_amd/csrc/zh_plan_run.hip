@@ -159,12 +159,24 @@ static void seg_trace(zh_plan* p, hipStream_t s) {
   (void)hipMemcpy(go.data(), g.go, go.size() * 4, hipMemcpyDeviceToHost);
   (void)hipMemcpy(ok.data(), g.stream_ok, ok.size() * 4, hipMemcpyDeviceToHost);
   (void)hipMemcpy(nchain.data(), g.nchain, nchain.size() * 4, hipMemcpyDeviceToHost);
+  {
+    std::vector<uint32_t> cn(g.nfind);
+    (void)hipMemcpy(cn.data(), g.cand_n, cn.size() * 4, hipMemcpyDeviceToHost);
+    uint64_t total = 0, over = 0, most = 0;
+    for (uint32_t c : cn) {
+      total += c;
+      over += c > 256u;
+      most = std::max<uint64_t>(most, c);
+    }
+    fprintf(stderr, "zippy_hip: %u search batches of 65536 bits: %llu candidates for a block start, %llu at most, %llu batches with more than the queue's 256\n",
+            g.nfind, (unsigned long long)total, (unsigned long long)most, (unsigned long long)over);
+  }
   for (uint32_t i = 0; i < g.nstreams; i++) {
     const uint32_t n = first[i + 1] - first[i];
     if (!n) continue;
     fprintf(stderr, "zippy_hip: stream %u: %u segments, go %u, chain holds %u, %u on it\n", i, n, go[i], ok[i], nchain[i]);
     if (ok[i]) continue;
-    std::vector<uint64_t> nominal(n), start(n), end(n), out(n), cap(n);
+    std::vector<uint64_t> nominal(n), start(n), end(n), out(n), cap(n), shdr(n);
     std::vector<int32_t> st(n);
     std::vector<uint32_t> fin(n), sub(n);
     (void)hipMemcpy(nominal.data(), g.nominal_bit + first[i], n * 8, hipMemcpyDeviceToHost);
@@ -172,6 +184,7 @@ static void seg_trace(zh_plan* p, hipStream_t s) {
     (void)hipMemcpy(end.data(), g.end_bit + first[i], n * 8, hipMemcpyDeviceToHost);
     (void)hipMemcpy(out.data(), g.seg_out + first[i], n * 8, hipMemcpyDeviceToHost);
     (void)hipMemcpy(cap.data(), g.eff_tok_cap + first[i], n * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(shdr.data(), g.sub_hdr + first[i], n * 8, hipMemcpyDeviceToHost);
     (void)hipMemcpy(st.data(), g.seg_status + first[i], n * 4, hipMemcpyDeviceToHost);
     (void)hipMemcpy(fin.data(), g.final_block + first[i], n * 4, hipMemcpyDeviceToHost);
     (void)hipMemcpy(sub.data(), g.is_sub + first[i], n * 4, hipMemcpyDeviceToHost);
@@ -189,6 +202,7 @@ static void seg_trace(zh_plan* p, hipStream_t s) {
       links++;
       if (st[k] != 0 || fin[k]) break;
       want = end[k];
+      k++;
     }
     const uint32_t lo = k < n ? k : 0;
     fprintf(stderr, "  chain: %u links, %s; wanted bit %llu\n", links,
@@ -197,8 +211,8 @@ static void seg_trace(zh_plan* p, hipStream_t s) {
     uint32_t near = 0;
     while (near + 1 < n && nominal[near + 1] <= want) near++;
     for (uint32_t j = (k == n ? near : lo) > 2 ? (k == n ? near : lo) - 2 : 0; j < n && j < (k == n ? near : lo) + 4; j++)
-      fprintf(stderr, "  seg %u: nominal %llu start %lld (sub %u) end %llu status %d final %u out %llu tokens' room %llu\n", j,
-              (unsigned long long)nominal[j], (long long)start[j], sub[j], (unsigned long long)end[j], st[j], fin[j],
+      fprintf(stderr, "  seg %u: nominal %llu start %lld (sub %u of the block at %lld) end %llu status %d final %u out %llu tokens' room %llu\n", j,
+              (unsigned long long)nominal[j], (long long)start[j], sub[j], (long long)shdr[j], (unsigned long long)end[j], st[j], fin[j],
               (unsigned long long)out[j], (unsigned long long)cap[j]);
   }
 }
@@ -292,11 +306,20 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       if (const char* e = getenv("ZH_SEG_FAKE_START")) zh_launch_seg_fake_start(s, p->sg, strtoull(e, nullptr, 10));
       prof_mark(p, "zh_seg_substart_kernel");
       zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 0);
-      zh_launch_seg_decide(s, a, p->sg);
+      zh_launch_seg_decide(s, a, p->sg, 0);
       prof_mark(p, "zh_seg_tokens_kernel");
       zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 1);
       prof_mark(p, "zh_seg_chain_kernel");
-      zh_launch_seg_chain(s, a, p->sg);
+      zh_launch_seg_chain(s, a, p->sg, 0);
+      // a chain broken by found starts that were none: once more without them (streams whose chain holds sit it out)
+      for (int round = 0; round < p->sg_repair_rounds; round++) {
+        prof_mark(p, "zh_seg_repair_kernel");
+        zh_launch_seg_repair(s, a, p->sg);
+        zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 4);
+        zh_launch_seg_decide(s, a, p->sg, 1);
+        zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 5);
+        zh_launch_seg_chain(s, a, p->sg, 1);
+      }
       p->seg_ran = true;
       if (getenv("ZH_TRACE_SEG")) seg_trace(p, s);
       if (!a.count_only) {

@@ -86,15 +86,15 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   Arena ar;
   const size_t o_parent = ar.reserve(ns * 4), o_first = ar.reserve((n + 1) * 4), o_nom = ar.reserve(ns * 8),
                o_search = ar.reserve(ns * 8), o_toff = ar.reserve(ns * 8), o_tcap = ar.reserve(ns * 8),
-               o_symb = ar.reserve(n * 8), o_start = ar.reserve(ns * 8), o_end = ar.reserve(ns * 8),
+               o_symb = ar.reserve(n * 8), o_start = ar.reserve(ns * 8), o_start2 = ar.reserve(ns * 8), o_end = ar.reserve(ns * 8),
                o_final = ar.reserve(ns * 4), o_sst = ar.reserve(ns * 4), o_sout = ar.reserve(ns * 8),
                o_wlen = ar.reserve(ns * 8), o_valid = ar.reserve(ns * 4), o_prev = ar.reserve(ns * 4),
                o_ostart = ar.reserve(ns * 8), o_sok = ar.reserve(n * 4), o_order = ar.reserve(ns * 4),
-               o_nchain = ar.reserve(n * 4), o_ordinal = ar.reserve(ns * 4), o_go = ar.reserve(n * 4), o_etoff = ar.reserve(ns * 8), o_etcap = ar.reserve(ns * 8), o_substart = ar.reserve(ns * 8), o_subhdr = ar.reserve(ns * 8),
+               o_nchain = ar.reserve(n * 4), o_repair = ar.reserve(n * 4), o_ordinal = ar.reserve(ns * 4), o_go = ar.reserve(n * 4), o_etoff = ar.reserve(ns * 8), o_etcap = ar.reserve(ns * 8), o_substart = ar.reserve(ns * 8), o_subhdr = ar.reserve(ns * 8),
                o_issub = ar.reserve(ns * 4);
   const size_t nfind = find_seg.size();
   const size_t o_fseg = ar.reserve(nfind * 4), o_fbatch = ar.reserve(nfind * 4), o_cn = ar.reserve(nfind * 4),
-               o_coff = ar.reserve(nfind * 64 * 4);
+               o_coff = ar.reserve(nfind * (size_t)kSegFindSlots * 4);
   ar.reserve(256);
   if (ctx_malloc(p->ctx, (void**)&p->sg_arena, ar.size) != hipSuccess) {
     (void)hipGetLastError();
@@ -134,6 +134,7 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   g.tok_cap = carve<uint64_t>(base, o_tcap);
   g.sym_base = carve<uint64_t>(base, o_symb);
   g.start_bit = carve<uint64_t>(base, o_start);
+  g.start2_bit = carve<uint64_t>(base, o_start2);
   g.end_bit = carve<uint64_t>(base, o_end);
   g.final_block = carve<uint32_t>(base, o_final);
   g.seg_status = carve<int32_t>(base, o_sst);
@@ -145,6 +146,7 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   g.stream_ok = carve<uint32_t>(base, o_sok);
   g.order = carve<uint32_t>(base, o_order);
   g.nchain = carve<uint32_t>(base, o_nchain);
+  g.repair = carve<uint32_t>(base, o_repair);
   g.ordinal = carve<uint32_t>(base, o_ordinal);
   g.go = carve<uint32_t>(base, o_go);
   g.eff_tok_off = carve<uint64_t>(base, o_etoff);
@@ -158,6 +160,12 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   g.cand_n = carve<uint32_t>(base, o_cn);
   g.cand_off = carve<uint32_t>(base, o_coff);
   p->sg_sym_count = nsym + 64;
+  {  // (a false start a GiB or so: a second round of repairs only pays where the first is likely to leave something)
+    uint64_t cut_bytes = 0;
+    for (const ZhBufDesc& b : bufs)
+      if (large(b)) cut_bytes += b.src_len;
+    p->sg_repair_rounds = cut_bytes >= (256ull << 20) ? 2 : 1;
+  }
   p->segmented = true;
 }
 
