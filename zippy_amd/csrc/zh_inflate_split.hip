@@ -189,11 +189,9 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
   bool final_block = false;
 
   // ---- one token at superchunk-relative bit p, decoded by the calling lane alone ----
-  // returns the token's bits (0: not a token, see *kind) and its record
-  // `tb2` / `rec2` (optional): a literal right behind a literal comes out of the same 32 bits -- its bits and
-  // record, 0 if what follows is anything else (it is then decoded on its own as usual)
-  auto decode_at = [&](uint32_t p, uint32_t* rec, uint32_t* kind, uint32_t* tb2 = nullptr,
-                       uint32_t* rec2 = nullptr) -> uint32_t {
+  // returns the token's bits (0: not a token, see *kind) and its record (the all-starts pass; the passes proper
+  // live in run() below)
+  auto decode_at = [&](uint32_t p, uint32_t* rec, uint32_t* kind) -> uint32_t {
     const uint32_t wi = p >> 5, sh = p & 31u;
     const uint32_t si = wi + 3u * (p / kSubBits);
     const uint32_t d0 = s_in[si], d1 = s_in[si + 1u], d2 = s_in[si + 2u];
@@ -210,17 +208,9 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
       e = litlen_entry(sym, cl < 16 ? cl : 0);
     }
     const uint32_t L = e & 15u;
-    if (tb2) *tb2 = 0;
     if (e & 0x8000u) {
       *kind = 0;
       *rec = 1u | (1u << 9) | (((e >> 16) & 0xffu) << 16);
-      if (tb2) {  // (L <= 15: at least 17 of the 32 bits are left, a root entry needs kLitBits)
-        const uint32_t e2 = s_lit[(v_lo >> L) & ((1u << kLitBits) - 1u)];
-        if ((e2 & 0x8400u) == 0x8000u) {
-          *tb2 = e2 & 15u;
-          *rec2 = 1u | (1u << 9) | (((e2 >> 16) & 0xffu) << 16);
-        }
-      }
       return L;
     }
     const uint32_t k1 = (e >> 8) & 3u;
@@ -256,44 +246,124 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
     *rec = length | (dist << 16);
     return o3 + deb;
   };
-  // tokens from p up to the first token start at or behind `limit`; `end_rel`: the input's end
-  auto run = [&](uint32_t p, uint32_t limit, uint32_t end_rel, uint32_t* out) -> RunResult {
+  // the rare litlen entries (not "plain", zh_inflate_tables.h): a link to a second-level table, or an empty entry --
+  // inflate.nim:67-91 decodeSymbolSlow: longer than the tables reach, or unassigned.  What comes back is a plain
+  // entry, end of block, or an invalid symbol (kKindBad).
+  auto lit_rare = [&](uint32_t e, uint32_t v_lo) -> uint32_t {
+    if (e & 0x400u) e = s_lit[(e >> 16) + ((v_lo >> kLitBits) & ((1u << (e & 15u)) - 1u))];
+    if (e == 0) {
+      const uint32_t k = __brev(v_lo) >> 16;
+      uint32_t cl = kLitBits + 1;
+      while (cl < 16 && k >= s_tab_lit.max_codes[cl]) cl++;
+      uint32_t sym = 0xffffu;
+      if (cl < 16)
+        sym = s_val_lit[((k >> (16 - cl)) - s_tab_lit.first_code[cl] + s_tab_lit.first_symbol[cl]) & 0xffffu];
+      e = litlen_entry(sym, cl < 16 ? cl : 0);
+    }
+    return e;
+  };
+  auto dist_rare = [&](uint32_t de, uint32_t dv) -> uint32_t {
+    if (de & 0x400u) de = s_dst[(de >> 16) + ((dv >> kDistBits) & ((1u << (de & 15u)) - 1u))];
+    if (de == 0) {
+      const uint32_t k = __brev(dv) >> 16;
+      uint32_t cl = kDistBits + 1;
+      while (cl < 16 && k >= s_tab_dist.max_codes[cl]) cl++;
+      uint32_t sym = 0xffffu;
+      if (cl < 16)
+        sym = s_val_dist[((k >> (16 - cl)) - s_tab_dist.first_code[cl] + s_tab_dist.first_symbol[cl]) & 0xffffu];
+      de = dist_entry(sym, cl < 16 ? cl : 0);
+    }
+    return de;
+  };
+  // tokens from p up to the first token start at or behind `limit`; `end_rel`: the input's end.
+  // The loop every pass of the kernel lives in (run-up, turns, writing pass), so it is written for the instructions it
+  // issues (round 5: 123 -> ~ 90 an iteration of a wave with literals and copies in it): ONE test sends everything rare
+  // out of the way (table entries carry a "plain" bit), the endings -- an invalid symbol (inflate.nim:202-204, 211-213),
+  // the input's end (the role of `bitsBuffered < 0`), end of block -- are selected into one `term` and leave through
+  // one exit, in the order the checks had as branches: an invalid symbol before the token's bits are taken, the
+  // input's end before the end of block.
+  // `one_row` (std::true_type): the run stays in the subchunk it starts in -- every pass of a superchunk does: a
+  // run-up ends where it enters the next subchunk, a thread's own run where it leaves its own, and what a token
+  // needs beyond a subchunk's end is in the row's three spare dwords.  Positions then count in the STAGED layout
+  // (19 dwords a subchunk: + 96 bits a row, which leaves a position's low five bits alone), and a token's dwords
+  // are at (position >> 5) without the row arithmetic.
+  auto run = [&](auto one_row, uint32_t p, uint32_t limit, uint32_t end_rel, uint32_t* out) -> RunResult {
+    constexpr bool kRow = decltype(one_row)::value;
     RunResult r;
     r.n = 0;
     r.term = 0;
     r.bytes = 0;
-    while (p < limit) {
-      uint32_t rec, kind, tb2, rec2;
-      const uint32_t tb = decode_at(p, &rec, &kind, &tb2, &rec2);
-      if (kind > 1u) {
-        r.term = kind;
-        break;
+    uint32_t t = 0;
+    bool go = p < limit;
+    const uint32_t row_bits = kRow ? (p / kSubBits) * (32u * (kSubStride - kSubWords)) : 0u;
+    if (kRow) {
+      p += row_bits;
+      limit += row_bits;
+      end_rel = end_rel < 0xf0000000u ? end_rel + row_bits : end_rel;  // (a superchunk is 2^19 bits at most)
+    }
+    while (go) {
+      const uint32_t si = kRow ? p >> 5 : (p >> 5) + 3u * (p / kSubBits);
+      const uint32_t d0 = s_in[si], d1 = s_in[si + 1u], d2 = s_in[si + 2u];
+      const uint32_t v_lo = zh_alignbit(d1, d0, p);
+      uint32_t e = s_lit[v_lo & ((1u << kLitBits) - 1u)];
+      if (__builtin_expect(!(e & kEntryPlain), 0)) e = lit_rare(e, v_lo);
+      const uint32_t L = e & 15u;
+      uint32_t tb, rec, tb2 = 0, rec2 = 0;
+      t = 0;
+      if (e & 0x8000u) {
+        tb = L;
+        rec = 1u | (1u << 9) | (e & 0xff0000u);
+        // a literal right behind a literal comes out of the same 32 bits (L <= 15: at least 17 are left, a root
+        // entry needs kLitBits): its bits and what it adds to the record, 0 if what follows is anything else
+        const uint32_t e2 = s_lit[(v_lo >> L) & ((1u << kLitBits) - 1u)];
+        if (e2 & 0x8000u) {
+          tb2 = e2 & 15u;
+          rec2 = ((e2 & 0xff0000u) << 8) + 1u;
+        }
+      } else {
+        // a length and its distance (for an end of block or an invalid symbol the same arithmetic on whatever
+        // the bits hold: in range, and thrown away below)
+        const uint32_t v_hi = zh_alignbit(d2, d1, p);
+        const uint32_t eb = (e >> 4) & 15u;
+        const uint32_t length = (e >> 16) + ((v_lo >> L) & ((1u << eb) - 1u));
+        const uint32_t o2 = L + eb;  // <= 20
+        const uint32_t dv = zh_alignbit(v_hi, v_lo, o2);
+        uint32_t de = s_dst[dv & ((1u << kDistBits) - 1u)];
+        if (__builtin_expect(!(de & kEntryPlain), 0)) de = dist_rare(de, dv);
+        const uint32_t dl = de & 15u, deb = (de >> 4) & 15u;  // dl + deb <= 28: the extra bits are in dv
+        const uint32_t dist = (de >> 16) + ((dv >> dl) & ((1u << deb) - 1u));
+        tb = o2 + dl + deb;  // the token <= 48 bits
+        rec = length | (dist << 16);
+        if (__builtin_expect(!(e & de & kEntryPlain), 0)) {
+          const bool eob = !(e & kEntryPlain) && ((e >> 8) & 3u) == kKindEob;
+          t = eob ? 1u : (uint32_t)ZH_ERR_INVALID_BUFFER;
+          tb = eob ? L : 0u;
+        }
       }
       p += tb;
-      if (p > end_rel) {  // the token reaches past the input (the role of `bitsBuffered < 0`)
-        r.term = (uint32_t)ZH_ERR_END_OF_BUFFER;
-        break;
-      }
-      if (kind == 1u) {
-        r.term = 1u;
-        break;
-      }
+      // the last token of a run: an ending (t), or one that reaches past the input (the role of `bitsBuffered < 0`)
+      const bool last = t != 0u || p > end_rel;
       // A second literal out of the same bits, if it starts before `limit` and ends inside the input: the
       // decisions the loop would take on its next turn, so every pass over these bits finds the same tokens.
       // (Two tokens in three of the bench data are literals: 15.4 -> 11.6 ms.  Up to one / two / three more out
       // of a 64-bit window: 12.6 / 12.8 / 14.0 ms; a literal behind a COPY out of the copy's 64 bits as well: 12.3
-      // against 11.4.)  The two share ONE record: length 2, the second byte on top.
-      if (tb2 && p < limit && p + tb2 <= end_rel) {
+      // against 11.4.)  The two share ONE record: length 2, the second byte on top.  (Nothing follows: tb2 = rec2 = 0.)
+      const bool pair = !last && p < limit && p + tb2 <= end_rel;
+      if (pair) {
         p += tb2;
-        rec = 2u | (1u << 9) | (rec & 0xff0000u) | ((rec2 & 0xff0000u) << 8);
+        rec += rec2;
       }
-      if (out) {
+      if (out && !last) {
         out[r.n] = rec;
         if (kSeg) r.bytes += rec & 0x1ffu;
       }
-      r.n++;
+      r.n += last ? 0u : 1u;
+      go = !last && p < limit;
     }
-    r.end = p;
+    // the ending: an invalid symbol counts before the input's end (its bits are never taken), the input's end before
+    // an end of block
+    r.term = t > 1u ? t : p > end_rel ? (uint32_t)ZH_ERR_END_OF_BUFFER : t;
+    r.end = p - row_bits;
     return r;
   };
 
@@ -533,7 +603,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
           // 64 decoders a bit apart: after 4096 bits they have all fallen in step with the block's
           // real token sequence, or this is no place to start
           const uint32_t from = (uint32_t)(s0 - base_bit) + (exact ? 0u : tid);
-          const RunResult r = run(from, (uint32_t)(target - base_bit), end_rel, nullptr);
+          const RunResult r = run(std::false_type{}, from, (uint32_t)(target - base_bit), end_rel, nullptr);
           const uint32_t e0 = zh_bcast(r.end);
           const uint64_t ok = __ballot(r.term == 0u && r.end == e0);
           if ((ok & 1ull) && __popcll(ok) >= 56) found = base_bit + e0 - (uint64_t)mis * 8;
@@ -665,7 +735,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
       // boundary it crosses at is the start the thread before will hand it -- no second turn for it.
       if (kRunUp && tid != 0 && my_start != kNoStart) {
         const uint32_t from = tid * kSubBits - kRunUp;  // (kRunUp <= kSubBits; thread 1 may as well start where thread 0 does)
-        const RunResult pre = run(from > rel0 ? from : rel0, tid * kSubBits, end_rel, nullptr);
+        const RunResult pre = run(std::true_type{}, from > rel0 ? from : rel0, tid * kSubBits, end_rel, nullptr);
         if (pre.term == 0u) my_start = pre.end;
       }
       bool dirty = true;
@@ -684,7 +754,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
             r.n = 0;
             r.term = 0;
           } else {
-            r = run(my_start, limit, end_rel, nullptr);
+            r = run(std::true_type{}, my_start, limit, end_rel, nullptr);
           }
           s_end[tid] = r.term ? kNoStart : r.end;
         }
@@ -798,7 +868,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
       // (parking every run's records in HBM and copying them into place here was tried: the
       // scattered 4-byte stores of the speculative turns cost more than this second decode)
       uint32_t made = 0;
-      if (active && r.n) made = run(my_start, limit, end_rel, tok + ntok + before).bytes;
+      if (active && r.n) made = run(std::true_type{}, my_start, limit, end_rel, tok + ntok + before).bytes;
       if (kSeg) {
         made = zh_wave_sum(made);
         if (lane == 0) s_wbytes[tid >> 6] = made;

@@ -31,12 +31,15 @@ constexpr uint32_t kInWords = 128;   // staging ring of the compressed stream (d
 //   bit  10    link: the code is longer than the root table; bits 0-3 = index bits of its
 //              second-level table, bits 16-31 = where that table starts (entries of a
 //              second-level table carry the code's full length)
+//   bit  11    plain: a literal, a length or a distance, decoded by this entry alone -- the ONE test of the split
+//              decoder's hot loop; everything rare (a link, an empty entry, end of block, an invalid symbol) has it clear
 //   bit  15    set for literals (single-bit test on the hot path)
 //   bits 16-31 literal byte / base length / base distance
 // ---------------------------------------------------------------------------
 namespace {
 
 enum { kKindLit = 0, kKindBase = 1, kKindEob = 2, kKindBad = 3 };
+constexpr uint32_t kEntryPlain = 0x800u;
 
 struct HuffTab {
   uint16_t first_code[16];
@@ -45,17 +48,17 @@ struct HuffTab {
 };
 
 __device__ __forceinline__ uint32_t litlen_entry(uint32_t sym, uint32_t len) {
-  if (sym < 256) return len | (kKindLit << 8) | 0x8000u | (sym << 16);
+  if (sym < 256) return len | (kKindLit << 8) | kEntryPlain | 0x8000u | (sym << 16);
   if (sym == 256) return len | (kKindEob << 8);
   if (sym < 286) {  // inflate.nim:199-209
     const uint32_t li = sym - 257;
-    return len | ((uint32_t)c_len.extra[li] << 4) | (kKindBase << 8) | ((uint32_t)c_len.base[li] << 16);
+    return len | ((uint32_t)c_len.extra[li] << 4) | (kKindBase << 8) | kEntryPlain | ((uint32_t)c_len.base[li] << 16);
   }
   return len | (kKindBad << 8);  // 286, 287 and the 0xffff "unassigned code" marker
 }
 __device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t len) {
   if (sym < 30)  // inflate.nim:210-222
-    return len | ((uint32_t)c_dist.extra[sym] << 4) | (kKindBase << 8) | ((uint32_t)c_dist.base[sym] << 16);
+    return len | ((uint32_t)c_dist.extra[sym] << 4) | (kKindBase << 8) | kEntryPlain | ((uint32_t)c_dist.base[sym] << 16);
   return len | (kKindBad << 8);
 }
 __device__ __forceinline__ uint32_t cl_entry(uint32_t sym, uint32_t len) { return len | (sym << 16); }
@@ -178,16 +181,16 @@ __device__ int build_table(const uint8_t* lens, uint32_t n, uint32_t* lut, uint3
 // ---------------------------------------------------------------------------
 // entry encoders without the constant tables (a per-lane lookup there is a trip to memory)
 __device__ __forceinline__ uint32_t litlen_entry_a(uint32_t sym, uint32_t len) {
-  if (sym < 256) return len | (kKindLit << 8) | 0x8000u | (sym << 16);
+  if (sym < 256) return len | (kKindLit << 8) | kEntryPlain | 0x8000u | (sym << 16);
   if (sym == 256) return len | (kKindEob << 8);
   if (sym < 286) {
     const uint32_t li = sym - 257;
-    return len | (zh_len_extra_bits(li) << 4) | (kKindBase << 8) | (zh_len_base(li) << 16);
+    return len | (zh_len_extra_bits(li) << 4) | (kKindBase << 8) | kEntryPlain | (zh_len_base(li) << 16);
   }
   return len | (kKindBad << 8);
 }
 __device__ __forceinline__ uint32_t dist_entry_a(uint32_t sym, uint32_t len) {
-  if (sym < 30) return len | (zh_dist_extra_bits(sym) << 4) | (kKindBase << 8) | (zh_dist_base(sym) << 16);
+  if (sym < 30) return len | (zh_dist_extra_bits(sym) << 4) | (kKindBase << 8) | kEntryPlain | (zh_dist_base(sym) << 16);
   return len | (kKindBad << 8);
 }
 
