@@ -69,6 +69,41 @@ def cpu_model():
     return "unknown"
 
 
+def host_cpu_info():
+    """What the process may use of the host: the CPUs it may run on, the cgroup's quota and CPU set, the NUMA nodes --
+    so that a cpu_baseline that stops scaling can be told from a lease that is smaller than the box."""
+    def read(path):
+        try:
+            with open(path) as fh:
+                return fh.read().strip()
+        except OSError:
+            return None
+    info = {"logical_cpus": os.cpu_count(),
+            "sched_getaffinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "cgroup_cpu_max": read("/sys/fs/cgroup/cpu.max"),
+            "cgroup_cpuset_effective": read("/sys/fs/cgroup/cpuset.cpus.effective"),
+            "numa_nodes": None, "threads_per_core": None}
+    if info["cgroup_cpu_max"] is None:  # cgroup v1
+        q, per = read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+        if q and per:
+            info["cgroup_cpu_max"] = "%s %s" % (q, per)
+    try:
+        info["numa_nodes"] = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except OSError:
+        pass
+    sib = read("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list")
+    if sib:
+        info["threads_per_core"] = len([x for part in sib.split(",") for x in
+                                        (range(int(part.split("-")[0]), int(part.split("-")[-1]) + 1))])
+    cm = info["cgroup_cpu_max"]
+    if cm and cm.split()[0] not in ("max", "-1"):
+        try:
+            info["cgroup_cpu_quota_cpus"] = round(float(cm.split()[0]) / float(cm.split()[1]), 2)
+        except (ValueError, IndexError, ZeroDivisionError):
+            pass
+    return info
+
+
 def cpu_baseline(bufs, level, cores, reps=8):
     """The oracle (C restatement of zippy, oracle/zippy_oracle.c) timed on the host cores the way
     the reference times itself (tests/bench.nim:27-28,63-64 with benchy: warm-up, >= 10 repetitions,
@@ -123,7 +158,13 @@ def cpu_baseline(bufs, level, cores, reps=8):
         t //= 2
     best = max(legs, key=lambda t: legs[t]["oracle"]["both_GiBps_at_avg"])
     many = legs[best]
+    one_v = one["oracle"]["both_GiBps_at_avg"]
     return {
+        "host": host_cpu_info(),
+        # the harness's scaling, thread count by thread count: x one thread (compress, uncompress, both)
+        "speedup_over_1_thread": {str(t): [round(v["oracle"]["compress"]["GiBps_at_avg"] / one["oracle"]["compress"]["GiBps_at_avg"], 1),
+                                           round(v["oracle"]["uncompress"]["GiBps_at_avg"] / one["oracle"]["uncompress"]["GiBps_at_avg"], 1),
+                                           round(v["oracle"]["both_GiBps_at_avg"] / one_v, 1)] for t, v in sorted(legs.items())},
         "value": many["oracle"]["both_GiBps_at_avg"],
         "value_at_min": many["oracle"]["both_GiBps_at_min"],
         "unit": "GiB/s",
@@ -142,6 +183,18 @@ def cpu_baseline(bufs, level, cores, reps=8):
         "one_thread": one,
         "zlib_level": zl,
     }
+
+
+def cpu_level_leg(sample, level, threads, reps=3):
+    """compress(level, gzip) of `sample` by the oracle on `threads` pinned C threads: GiB/s and ratio (the CPU line of a
+    side config; the same harness as cpu_baseline)."""
+    import oracle
+    nbytes = sum(len(b) for b in sample)
+    _, blobs = oracle.batch_mt(sample, 0, level, oracle.dfGzip, threads, keep=True)  # warm-up
+    tc = [oracle.batch_mt(sample, 0, level, oracle.dfGzip, threads)[0] for _ in range(reps)]
+    return {"compress": _stats(tc, nbytes), "threads": threads, "kind": "port", "ratio": round(nbytes / sum(len(z) for z in blobs), 4),
+            "sample": "%d x %d B of the same batch, oracle.compress(level %d, gzip), %d repetitions" % (
+                len(sample), len(sample[0]), level, reps)}
 
 
 def hbm_traffic(workload="headline"):
@@ -255,7 +308,51 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
             e["uncompress_GiBps"] = round(nbytes / GIB / (tu * 1e-3), 3)
         return e
 
-    def batch(tag, workload, n, size, level, do_c, do_u, foreign=None, nsteps=steps, l1_parse=-1):
+    def oracle_sample(cplan, d_comp, data, comp_off, level, k):
+        """k of the batch's streams (evenly spread) against oracle.compress, byte for byte: the side configs' own
+        evidence of identity, like the headline's parity_sample (checker only, outside every timed region)."""
+        import oracle
+        clens, _ = cplan.results()
+        pick = sorted(set(int(i * len(clens) / k) for i in range(k)))
+        same = 0
+        for i in pick:
+            got = d_comp[comp_off[i]:comp_off[i] + clens[i]].cpu().numpy().tobytes()
+            same += got == oracle.compress(data[i].tobytes(), level, oracle.dfGzip, fname_len=0)  # (the engine's FNAME is pinned to 0 letters in main)
+        return {"streams": len(pick), "identical": same == len(pick), "against": "oracle.compress(level %d, gzip)" % level}
+
+    def pack_times(cplan, uplan, d_comp, d_back, d_src, n, slot):
+        """zh_plan_pack (slots -> streams back to back + device offsets) and zh_plan_unpack (the inverse, into the
+        uncompress plan's slots) on this batch: what one GPU adds to a transfer leg, HIP events on the launch stream;
+        the unpacked streams are decoded once more and compared."""
+        d_packed = torch.empty(n * slot, dtype=torch.uint8, device="cuda")
+        d_offs = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+        d_comp2 = torch.zeros_like(d_comp)
+        cplan.run(d_src.data_ptr(), d_comp.data_ptr())
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        tp = tu = 0.0
+        reps = 5
+        for it in range(reps + 1):
+            ev[0].record(stream)
+            cplan.pack(d_comp.data_ptr(), d_packed.data_ptr(), d_packed.numel(), d_offs.data_ptr())
+            ev[1].record(stream)
+            uplan.unpack(d_packed.data_ptr(), d_offs.data_ptr(), d_comp2.data_ptr())
+            ev[2].record(stream)
+            ev[2].synchronize()
+            if it:  # (the first pass allocates the plan's length array)
+                tp += ev[0].elapsed_time(ev[1])
+                tu += ev[1].elapsed_time(ev[2])
+        uplan.run(d_comp2.data_ptr(), d_back.data_ptr())
+        _, usts = uplan.results()
+        assert all(x == 0 for x in usts) and torch.equal(d_back, d_src), "pack / unpack round trip"
+        uplan.set_src_lens_device(cplan.device_lens())
+        packed_bytes = int(d_offs[n].item())
+        del d_packed, d_comp2
+        return {"pack_ms": round(tp / reps, 4), "unpack_ms": round(tu / reps, 4), "packed_bytes": packed_bytes,
+                "slot_bytes": n * slot}
+
+    def batch(tag, workload, n, size, level, do_c, do_u, foreign=None, nsteps=steps, l1_parse=-1, sample=0, pack=False):
+        """sample: that many of the streams against oracle.compress at the same level, byte for byte (outside the
+        timed region; the exact parse only); pack: time zh_plan_pack / zh_plan_unpack on the batch's streams."""
         eng.set_l1_parse(l1_parse)
         data = host.reshape(-1)[:n * size].reshape(n, size)
         d_src = torch.from_numpy(data.reshape(-1)).cuda()
@@ -315,6 +412,10 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
                                  (d_src, d_comp, d_back), nsteps, 0)
         out[tag] = entry(workload, n * size, state["C"], tc if do_c else None, tu if do_u else None, kms,
                          "headline" if tag == "c3_own" else tag)
+        if sample and cplan is not None and l1_parse != 1:
+            out[tag]["parity_sample"] = oracle_sample(cplan, d_comp, data, comp_off, level, sample)
+        if pack and cplan is not None and uplan is not None:
+            out[tag].update(pack_times(cplan, uplan, d_comp, d_back, d_src, n, slot))
         for pl in (cplan, uplan):
             if pl is not None:
                 pl.close()
@@ -324,7 +425,7 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
 
     nb = host.shape[0]
     full_size = nb == 4096  # (the PMC passes were taken on BASELINE's sizes)
-    batch("c2", "config 2: 1024 x 64 KiB, compress BestSpeed gzip", min(1024, nb * 16), 65536, 1, True, False)
+    batch("c2", "config 2: 1024 x 64 KiB, compress BestSpeed gzip", min(1024, nb * 16), 65536, 1, True, False, sample=8)
     batch("c2_parallel_parse", "config 2 with the opt-in parallel BestSpeed parse (valid streams, not the "
           "reference's bytes)", min(1024, nb * 16), 65536, 1, True, False, l1_parse=1)
     batch("c3_own", "config 3: %d x 1 MiB uncompress only (this library's BestSpeed streams), CRC-32 verified" % nb,
@@ -333,7 +434,13 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
           "(multi-block dynamic streams), CRC-32 verified" % nb, nb, 1 << 20, 1, False, True, foreign=6)
     share = max(1, nb // 8)
     batch("c4_share", "config 4: one GPU's share of eight (%d x 1 MiB), compress DefaultCompression gzip" % share,
-          share, 1 << 20, -1, True, False, nsteps=max(2, steps // 2))
+          share, 1 << 20, -1, True, False, nsteps=max(2, steps // 2), sample=8)
+    # one GPU's share of the HEADLINE step when eight split the batch (strong scaling, SCALE_rNN's N = 8 point as
+    # far as one GPU can show it), with what the GPU adds to a transfer leg (pack / unpack)
+    batch("share512", "one GPU's share of eight of the headline step (%d x 1 MiB, compress BestSpeed gzip + "
+          "uncompress)" % share, share, 1 << 20, 1, True, True, pack=True)
+    batch("share512_parallel_parse", "the same share with the opt-in parallel BestSpeed parse", share, 1 << 20, 1,
+          True, True, l1_parse=1)
 
     # config 5: ONE large buffer as independent 32 KiB deflate blocks (tools/bench_c5.py)
     mib = min(128, nb)
@@ -356,6 +463,18 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
     tc, tu, kms = time_plans(torch, stream, cplan, uplan, (d_src, d_comp, d_back), steps, 1, verify5)
     out["c5"] = entry("config 5: 1 x %d MiB as independent 32 KiB deflate blocks, compress BestSpeed gzip + "
                       "indexed uncompress" % mib, size, clen, tc, tu, kms, "c5")
+    import oracle  # (checker only, outside the timed region: the first 8 MiB as 32 KiB blocks, bytes and index)
+    part = 8 << 20
+    if size >= part:
+        want, windex = oracle.compress_blocks(host.reshape(-1)[:part].tobytes(), 1, oracle.dfGzip, 32768, fname_len=0)
+        pplan = eng.plan_compress_blocks([0], [part], [0], [cap], 1, api.dfGzip, 32768)
+        pplan.run(d_src.data_ptr(), d_comp.data_ptr())
+        (plen,), (pst,) = pplan.results()
+        got = d_comp[:plen].cpu().numpy().tobytes()
+        out["c5"]["parity_sample"] = {"bytes": part, "identical": pst == 0 and got == want and
+                                      [tuple(e) for e in pplan.block_index(0)] == [tuple(e) for e in windex],
+                                      "against": "oracle.compress_blocks(level 1, gzip, 32 KiB): stream and block index"}
+        pplan.close()
     cplan.close()
     uplan.close()
     return out
@@ -719,6 +838,13 @@ def main():
             del d_comp, d_back, d_src
             torch.cuda.empty_cache()
             out["configs"] = side_configs(torch, eng, api, synth, stream, host, max(2, min(args.steps, 5)))
+            # strong-scaling proxy: the share's time against a perfect eighth of the full batch's step
+            for tag, full_ms in (("share512", ms_per_step),
+                                 ("share512_parallel_parse", out.get("parallel_parse", {}).get("ms_per_step"))):
+                e = out["configs"].get(tag)
+                if e and full_ms and n == 8 * (n // 8):
+                    e["perfect_eighth_ms"] = round(full_ms / 8.0, 3)
+                    e["efficiency_vs_perfect_eighth"] = round(full_ms / 8.0 / e["ms_per_step"], 4)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             # every host core this process may run on (no cap); a repetition is >= 2 core-seconds of
             # work a core pair, i.e. ~ 32 MiB a thread, so that thread start-up and a straggler are
@@ -731,6 +857,15 @@ def main():
             sample = [host[i].tobytes() for i in range(min(n, 2048, cores * per_core))]
             out["cpu_baseline"] = cpu_baseline(sample, args.level, cores)
             out["cpu_baseline"]["nproc"] = os.cpu_count()
+            if "configs" in out and "c4_share" in out["configs"]:
+                # config 4 "ratio vs CPU zippy reported": the oracle at DefaultCompression on the same threads, a
+                # bounded sample (level -1 runs at ~ 30 MB/s a thread)
+                out["configs"]["c4_share"]["cpu_baseline_level_-1"] = cpu_level_leg(
+                    [host[i].tobytes() for i in range(min(n, max(32, out["cpu_baseline"]["cores"])))], -1,
+                    out["cpu_baseline"]["cores"])
+                g = out["configs"]["c4_share"]
+                g["cpu_baseline_level_-1"]["gpu_ratio_vs_cpu_ratio"] = round(
+                    g["ratio"] / g["cpu_baseline_level_-1"]["ratio"], 5)
         out["host_gen_s"] = round(t_gen, 1)
         print(json.dumps(out), flush=True)
     if use_dist:
@@ -767,23 +902,19 @@ def transfer_leg(torch, dist, sharding, synth, rank, world, n_total, size, slot,
         cplan.run(mine.data_ptr(), d_comp.data_ptr())
         clens, csts = cplan.results()
         assert all(s == 0 for s in csts)
-        lens_t = torch.tensor(clens, dtype=torch.int64, device=dev)
 
-        def pack():
-            return torch.cat([d_comp[i * slot:i * slot + clens[i]] for i in range(n)]) if n else d_comp[:0]
-        packed, res["pack_ms"] = timed(pack)
+        # the streams alone go over the links, not their worst-case slots: packed back to back on the device
+        # (sharding.pack_plan -> zh_plan_pack: two launches, the lengths are the ones the run left on the device; no
+        # per-buffer copy anywhere in this leg)
+        (packed, lens_t), res["pack_ms"] = timed(lambda: sharding.pack_plan(cplan, d_comp, n))
+        assert lens_t.tolist() == clens
         (all_c, all_lens), res["gather_compressed_ms"] = timed(
             lambda: sharding.gather_variable(packed, lens_t, root=0))
         (mine_c, mine_lens), res["scatter_compressed_ms"] = timed(
             lambda: sharding.scatter_variable(all_c, all_lens if rank == 0 else None, n_total, root=0, device=dev))
         assert torch.equal(mine_c, packed) and mine_lens.tolist() == clens
-
-        def unpack():
-            off = 0
-            for i in range(n):
-                d_comp[i * slot:i * slot + clens[i]] = mine_c[off:off + clens[i]]
-                off += clens[i]
-        _, res["unpack_ms"] = timed(unpack)
+        d_comp.zero_()
+        _keep, res["unpack_ms"] = timed(lambda: sharding.unpack_into_plan(uplan, mine_c, mine_lens, d_comp))
         uplan.run(d_comp.data_ptr(), d_back.data_ptr())
         _, usts = uplan.results()
         assert all(s == 0 for s in usts)

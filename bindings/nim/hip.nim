@@ -130,6 +130,20 @@ proc zh_uncompress_batch_multi(ctxs: ptr ZhCtx, nCtx: csize_t, srcs: ptr pointer
                                n: csize_t, dataFormat: cint, dsts: ptr pointer, dstLens: ptr csize_t,
                                statuses: ptr int32): cint {.importc, cdecl, dynlib: zhLib.}
 
+# ---- device-resident batches (one process a GPU: buffers and slots already in HBM, e.g. on their way between GPUs) ----
+type ZhPlan = pointer
+proc zh_plan_compress(ctx: ZhCtx, n: csize_t, srcOff, srcLen, dstOff, dstCap: ptr uint64, level, dataFormat: cint,
+                      plan: ptr ZhPlan): cint {.importc, cdecl, dynlib: zhLib.}
+proc zh_plan_uncompress(ctx: ZhCtx, n: csize_t, srcOff, srcLen, dstOff, dstCap: ptr uint64, dataFormat: cint,
+                        plan: ptr ZhPlan): cint {.importc, cdecl, dynlib: zhLib.}
+proc zh_plan_run(plan: ZhPlan, dSrc, dDst: pointer): cint {.importc, cdecl, dynlib: zhLib.}
+proc zh_plan_results(plan: ZhPlan, outLens: ptr uint64, statuses: ptr int32): cint {.importc, cdecl, dynlib: zhLib.}
+proc zh_plan_pack(plan: ZhPlan, dSlots, dPacked: pointer, packedCap: uint64,
+                  dOffsets: ptr uint64): cint {.importc, cdecl, dynlib: zhLib.}
+proc zh_plan_unpack(plan: ZhPlan, dPacked: pointer, dOffsets: ptr uint64,
+                    dSlots: pointer): cint {.importc, cdecl, dynlib: zhLib.}
+proc zh_plan_destroy(plan: ZhPlan) {.importc, cdecl, dynlib: zhLib.}
+
 # ---- the archive layer (src/zippy/ziparchives.nim) ----
 type
   ZhZipEntry {.bycopy.} = object

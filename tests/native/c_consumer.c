@@ -208,6 +208,73 @@ int main(void) {
       return fail("the same context twice must be refused", -1);
     zh_destroy(pair[0]);
   }
+  /* device-resident plans without a HIP binding: the batch compressed in device slots, the streams packed back to
+   * back (what would go over a link to another GPU), scattered into an uncompress plan's slots and decoded */
+  {
+    uint64_t src_off[N], src_len[N], dst_off[N], dst_cap[N], offs[N + 1], out_lens[N], back_off[N], back_cap[N];
+    uint64_t in_total = 0, slot_total = 0, packed_cap;
+    void *d_in = NULL, *d_slots = NULL, *d_packed = NULL, *d_offs = NULL, *d_slots2 = NULL, *d_back = NULL;
+    zh_plan *cp = NULL, *up = NULL;
+    static unsigned char flat[N * 70000], rt2[N * 70000];
+    void *one[N];
+    size_t one_len[N];
+    for (i = 0; i < N; i++) {
+      src_off[i] = in_total;
+      src_len[i] = lens[i];
+      memcpy(flat + in_total, text[i], lens[i]);
+      in_total += lens[i];
+      dst_off[i] = slot_total;
+      dst_cap[i] = zh_compress_bound(lens[i], ZH_DF_GZIP);
+      slot_total += (dst_cap[i] + 255u) & ~(uint64_t)255u;
+      back_off[i] = src_off[i];
+      back_cap[i] = lens[i];
+    }
+    packed_cap = slot_total;
+    if ((rc = zh_device_malloc(ctx, in_total + 16, &d_in)) != ZH_OK) return fail("zh_device_malloc", rc);
+    if ((rc = zh_device_malloc(ctx, slot_total, &d_slots)) != ZH_OK) return fail("zh_device_malloc", rc);
+    if ((rc = zh_device_malloc(ctx, packed_cap, &d_packed)) != ZH_OK) return fail("zh_device_malloc", rc);
+    if ((rc = zh_device_malloc(ctx, sizeof offs, &d_offs)) != ZH_OK) return fail("zh_device_malloc", rc);
+    if ((rc = zh_device_malloc(ctx, slot_total, &d_slots2)) != ZH_OK) return fail("zh_device_malloc", rc);
+    if ((rc = zh_device_malloc(ctx, in_total + 16, &d_back)) != ZH_OK) return fail("zh_device_malloc", rc);
+    if ((rc = zh_device_upload(ctx, d_in, flat, in_total)) != ZH_OK) return fail("zh_device_upload", rc);
+    if ((rc = zh_plan_compress(ctx, N, src_off, src_len, dst_off, dst_cap, 1, ZH_DF_GZIP, &cp)) != ZH_OK)
+      return fail("zh_plan_compress", rc);
+    if ((rc = zh_plan_run(cp, d_in, d_slots)) != ZH_OK) return fail("zh_plan_run", rc);
+    if ((rc = zh_plan_pack(cp, d_slots, d_packed, packed_cap, (uint64_t *)d_offs)) != ZH_OK) return fail("zh_plan_pack", rc);
+    if ((rc = zh_plan_results(cp, out_lens, st)) != ZH_OK) return fail("zh_plan_results", rc);
+    if ((rc = zh_device_download(ctx, offs, d_offs, sizeof offs)) != ZH_OK) return fail("zh_device_download", rc);
+    rc = zh_compress_batch(ctx, srcs, lens, N, 1, ZH_DF_GZIP, one, one_len, st);
+    if (rc != ZH_OK) return fail("zh_compress_batch (reference for pack)", rc);
+    if (offs[0] != 0) return fail("pack: offsets[0]", -1);
+    for (i = 0; i < N; i++) {
+      static unsigned char got[2 * 70000 + 8192];
+      if (offs[i + 1] - offs[i] != out_lens[i] || out_lens[i] != one_len[i]) return fail("pack: offsets", -1);
+      if ((rc = zh_device_download(ctx, got, (unsigned char *)d_packed + offs[i], one_len[i])) != ZH_OK)
+        return fail("zh_device_download", rc);
+      if (memcmp(got, one[i], one_len[i]) != 0) return fail("pack: stream differs from zh_compress_batch's", -1);
+      zh_free(one[i]);
+    }
+    /* the slots' sizes are all the uncompress plan knows: the lengths arrive with the streams */
+    if ((rc = zh_plan_uncompress(ctx, N, dst_off, dst_cap, back_off, back_cap, ZH_DF_GZIP, &up)) != ZH_OK)
+      return fail("zh_plan_uncompress", rc);
+    if ((rc = zh_plan_unpack(up, d_packed, (const uint64_t *)d_offs, d_slots2)) != ZH_OK) return fail("zh_plan_unpack", rc);
+    if ((rc = zh_plan_run(up, d_slots2, d_back)) != ZH_OK) return fail("zh_plan_run (uncompress)", rc);
+    if ((rc = zh_plan_results(up, out_lens, st)) != ZH_OK) return fail("zh_plan_results (uncompress)", rc);
+    if ((rc = zh_device_download(ctx, rt2, d_back, in_total)) != ZH_OK) return fail("zh_device_download", rc);
+    for (i = 0; i < N; i++)
+      if (st[i] != ZH_OK || out_lens[i] != lens[i] || memcmp(rt2 + src_off[i], text[i], lens[i]) != 0)
+        return fail("pack / unpack round trip differs", st[i]);
+    if (zh_plan_unpack(cp, d_packed, (const uint64_t *)d_offs, d_slots2) != ZH_ERR_ARGUMENT)
+      return fail("unpack into a compress plan must be refused", -1);
+    zh_plan_destroy(cp);
+    zh_plan_destroy(up);
+    zh_device_free(ctx, d_in);
+    zh_device_free(ctx, d_slots);
+    zh_device_free(ctx, d_packed);
+    zh_device_free(ctx, d_offs);
+    zh_device_free(ctx, d_slots2);
+    zh_device_free(ctx, d_back);
+  }
   zh_destroy(ctx);
   printf("c_consumer ok\n");
   return 0;

@@ -733,6 +733,86 @@ def check_plan_slots_with_gaps(eng, upload, download, alloc):
         plan.run(d_src, d_dst + 1)
 
 
+def check_plan_pack(eng, upload, download, alloc):
+    """zh_plan_pack / zh_plan_unpack (include/zippy_hip.h; zippy.nim:11-18: whole buffers are all that travels): a
+    compress plan's results back to back with n + 1 device offsets == the oracle's streams concatenated (a failed
+    buffer counts 0 bytes); the packed streams scattered into an uncompress plan's slots (another layout, odd offsets)
+    decode to the inputs; a packed buffer that is too small is not overrun; a stream longer than its slot is cut to
+    the slot and fails by itself."""
+    import struct
+    import pytest
+    from zippy_amd.common import ZippyError
+    srcs = [synth.corpus_file("alice29.txt")[:70000], b"", synth.corpus_file("html")[:33001], b"x" * 70001,
+            synth.corpus_file("kppkn.gtb")[:150003], b"q"]
+    n = len(srcs)
+    src_off, pos = [], 0
+    for s in srcs:
+        src_off.append(pos)
+        pos += len(s)
+    d_src, keep_src = upload(b"".join(srcs) + b"\0" * 16)
+    caps = [len(s) + len(s) // 8 + 2048 for s in srcs]
+    caps[3] = 40  # too small: this buffer fails (ZH_ERR_DST_TOO_SMALL) and packs as 0 bytes
+    dst_off, pos = [], 3
+    for i, c in enumerate(caps):
+        dst_off.append(pos)
+        pos += c + (101, 1000, 3, 513, 77, 9)[i]
+    d_dst, keep_dst = alloc(pos + 64, 0xAB)
+    cplan = eng.plan_compress(src_off, [len(s) for s in srcs], dst_off, caps, 1, oracle.dfGzip)
+    cplan.run(d_src, d_dst)
+    want = [oracle.compress(s, 1, oracle.dfGzip, fname_len=0) for s in srcs]
+    want[3] = b""
+    total = sum(len(w) for w in want)
+    d_pack, keep_pack = alloc(total + 64, 0xCD)
+    d_offs, keep_offs = alloc(8 * (n + 1), 0xEE)
+    cplan.pack(d_dst, d_pack, total + 64, d_offs)   # (no results() in between: the lengths are the device's)
+    lens, sts = cplan.results()
+    assert [st == 0 for st in sts] == [True, True, True, False, True, True]
+    offs = list(struct.unpack("<%dQ" % (n + 1), download(keep_offs)))
+    assert offs == [sum(len(w) for w in want[:i]) for i in range(n + 1)]
+    packed = download(keep_pack)
+    assert packed[:total] == b"".join(want)
+    assert packed[total:] == b"\xcd" * 64, "bytes behind the packed streams changed"
+    # too small a packed buffer: the offsets say so, nothing behind the capacity is written
+    small = total - 1000
+    d_pack2, keep_pack2 = alloc(total + 64, 0xCD)
+    cplan.pack(d_dst, d_pack2, small, d_offs)
+    cplan.results()
+    assert struct.unpack("<%dQ" % (n + 1), download(keep_offs))[n] == total > small
+    p2 = download(keep_pack2)
+    assert p2[:small] == b"".join(want)[:small] and p2[small:] == b"\xcd" * (total + 64 - small)
+    # ... and back: into an uncompress plan's source slots (sizes and places of their own), then decoded
+    ucaps = [len(w) + (5, 0, 300, 64, 1, 17)[i] for i, w in enumerate(want)]
+    ucaps[4] = len(want[4]) - 10  # a slot smaller than its stream: cut, and the stream fails alone
+    usrc_off, pos = [], 5
+    for c in ucaps:
+        usrc_off.append(pos)
+        pos += c + 13
+    d_usrc, keep_usrc = alloc(pos + 64, 0x11)
+    out_caps = [max(len(s), 1) for s in srcs]
+    out_off, pos = [], 0
+    for c in out_caps:
+        out_off.append(pos)
+        pos += c + 7
+    d_out, keep_out = alloc(pos + 64, 0x22)
+    uplan = eng.plan_uncompress(usrc_off, ucaps, out_off, out_caps, oracle.dfGzip)
+    uplan.unpack(d_pack, d_offs, d_usrc)
+    uplan.run(d_usrc, d_out)
+    ulens, usts = uplan.results()
+    got = download(keep_out)
+    for i, s in enumerate(srcs):
+        if i in (3, 4):  # the empty stream of the failed buffer; the cut stream
+            assert usts[i] != 0
+        else:
+            assert usts[i] == 0 and got[out_off[i]:out_off[i] + ulens[i]] == s, i
+    staged = download(keep_usrc)
+    for i, w in enumerate(want):
+        k = min(len(w), ucaps[i])
+        assert staged[usrc_off[i]:usrc_off[i] + k] == w[:k]
+        assert staged[usrc_off[i] + k:usrc_off[i] + k + 13] == b"\x11" * 13, "bytes outside a source slot changed"
+    with pytest.raises(ZippyError):
+        cplan.unpack(d_pack, d_offs, d_usrc)  # (a compress plan has no streams to be handed)
+
+
 def split_inflate_edge_streams():
     """Streams that exercise the corners of the parallel token decode (csrc/zh_inflate_split.hip):
     periodic data (wrong starts never fall in step: the all-starts pass), hundreds of tiny blocks

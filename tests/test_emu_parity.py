@@ -246,6 +246,17 @@ def test_emu_plan_slots_with_gaps(eng):
     pc.check_plan_slots_with_gaps(eng, upload, lambda keep: keep.raw, alloc)
 
 
+def test_emu_plan_pack(eng):
+    import ctypes
+    def upload(b):
+        buf = ctypes.create_string_buffer(b, len(b))
+        return ctypes.addressof(buf), buf
+    def alloc(n, fill):
+        buf = ctypes.create_string_buffer(bytes([fill]) * n, n)
+        return ctypes.addressof(buf), buf
+    pc.check_plan_pack(eng, upload, lambda keep: keep.raw, alloc)
+
+
 def test_emu_split_inflate_edges(eng, inflate_mode):
     pc.check_split_inflate_edges(eng)
 

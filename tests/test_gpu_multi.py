@@ -43,6 +43,34 @@ back, my_lens = sharding.scatter_variable(data, all_lens, n, root=0, device="cud
 assert torch.equal(back, packed) and my_lens.tolist() == lens.tolist()
 home = sharding.gather_fixed(mine, n, size, root=0)
 assert torch.equal(home, batch)
+# device-resident plans: slots -> streams back to back (zh_plan_pack), over the group, -> slots (zh_plan_unpack)
+from zippy_amd import api
+from zippy_amd._binding import Engine
+eng = Engine(api.LIB_PATH, device=0, stream=torch.cuda.current_stream().cuda_stream)
+eng.set_gzip_fname_len(0)
+text = (b"whole buffers are all that ever travels " * 200)[:size]
+src = torch.frombuffer(bytearray(text * n), dtype=torch.uint8).cuda()
+cap = size + size // 8 + 2048
+slot = (cap + 255) & ~255
+offs_in, offs_slot = [i * size for i in range(n)], [i * slot for i in range(n)]
+slots = torch.zeros(n * slot, dtype=torch.uint8, device="cuda")
+cplan = eng.plan_compress(offs_in, [size] * n, offs_slot, [cap] * n, 1, api.dfGzip)
+cplan.run(src.data_ptr(), slots.data_ptr())
+packed, plens = sharding.pack_plan(cplan, slots, n)
+clens, csts = cplan.results()
+assert all(x == 0 for x in csts) and plens.tolist() == clens and packed.numel() == sum(clens)
+for i in range(n):
+    o = sum(clens[:i])
+    assert torch.equal(packed[o:o + clens[i]], slots[i * slot:i * slot + clens[i]])
+data, all_lens = sharding.gather_variable(packed, plens, root=0)
+mine_c, mine_lens = sharding.scatter_variable(data, all_lens, n, root=0, device="cuda")
+slots2 = torch.full((n * slot,), 0x5a, dtype=torch.uint8, device="cuda")
+back = torch.zeros(n * size, dtype=torch.uint8, device="cuda")
+uplan = eng.plan_uncompress(offs_slot, [cap] * n, offs_in, [size] * n, api.dfGzip)
+keep = sharding.unpack_into_plan(uplan, mine_c, mine_lens, slots2)
+uplan.run(slots2.data_ptr(), back.data_ptr())
+ulens, usts = uplan.results()
+assert all(x == 0 for x in usts) and ulens == [size] * n and torch.equal(back, src)
 dist.barrier()
 dist.destroy_process_group()
 print("sharding nccl ok")

@@ -378,6 +378,17 @@ def test_gpu_plan_slots_with_gaps(eng):
     pc.check_plan_slots_with_gaps(eng, upload, lambda t: t.cpu().numpy().tobytes(), alloc)
 
 
+def test_gpu_plan_pack(eng):
+    import torch
+    def upload(b):
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+        return t.data_ptr(), t
+    def alloc(n, fill):
+        t = torch.full((n,), fill, dtype=torch.uint8, device="cuda")
+        return t.data_ptr(), t
+    pc.check_plan_pack(eng, upload, lambda t: t.cpu().numpy().tobytes(), alloc)
+
+
 def test_gpu_split_inflate_edges(eng, inflate_mode):
     pc.check_split_inflate_edges(eng)
 

@@ -73,6 +73,41 @@ def _worker(rank, world, port, n_buffers, buf_bytes, result_path):
     whole = sharding.gather_fixed(local, n_buffers, buf_bytes, root=0)
     if rank == 0:
         ok &= whole.numpy().tobytes() == batch.numpy().tobytes()
+    # the same trip with device-resident plans (here: host memory under the emulator): the shard compressed into
+    # worst-case slots, the streams packed back to back by zh_plan_pack (no per-buffer copy), home with
+    # gather_variable, out again with scatter_variable, into the uncompress plan's slots by zh_plan_unpack
+    k = hi - lo
+    if k:
+        cap = buf_bytes + buf_bytes // 8 + 2048
+        slot = (cap + 255) & ~255
+        offs_in, offs_slot = [i * buf_bytes for i in range(k)], [i * slot for i in range(k)]
+        d_src = mine.clone()
+        d_slots = torch.zeros(k * slot, dtype=torch.uint8)
+        cplan = eng.plan_compress(offs_in, [buf_bytes] * k, offs_slot, [cap] * k, 1, oracle.dfGzip)
+        cplan.run(d_src.data_ptr(), d_slots.data_ptr())
+        packed, plens = sharding.pack_plan(cplan, d_slots, k)
+        assert plens.tolist() == [len(o) for o in outs] and packed.numpy().tobytes() == b"".join(outs)
+    else:
+        packed, plens = torch.zeros(1, dtype=torch.uint8)[:0], torch.zeros(0, dtype=torch.int64)
+    data3, all_lens3 = sharding.gather_variable(packed if k else torch.zeros(1, dtype=torch.uint8), plens, root=0)
+    if rank == 0:
+        ok &= data3.numpy().tobytes() == data.numpy().tobytes() and all_lens3.tolist() == all_lens.tolist()
+    mine_c3, mine_lens3 = sharding.scatter_variable(data3, all_lens3 if rank == 0 else None, n_buffers, root=0)
+    if k:
+        d_slots2 = torch.full((k * slot,), 0x5a, dtype=torch.uint8)
+        d_back = torch.zeros(k * buf_bytes, dtype=torch.uint8)
+        uplan = eng.plan_uncompress(offs_slot, [cap] * k, offs_in, [buf_bytes] * k, oracle.dfGzip)
+        keep = sharding.unpack_into_plan(uplan, mine_c3, mine_lens3, d_slots2)
+        uplan.run(d_slots2.data_ptr(), d_back.data_ptr())
+        ulens, usts = uplan.results()
+        assert all(x == 0 for x in usts) and ulens == [buf_bytes] * k
+        assert torch.equal(d_back, mine)
+        local3 = d_back
+    else:
+        local3 = torch.zeros(1, dtype=torch.uint8)
+    whole3 = sharding.gather_fixed(local3, n_buffers, buf_bytes, root=0)
+    if rank == 0:
+        ok &= whole3.numpy().tobytes() == batch.numpy().tobytes()
         with open(result_path, "w") as fh:
             fh.write("ok" if ok else "mismatch")
     dist.barrier()

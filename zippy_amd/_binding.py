@@ -54,6 +54,10 @@ _SIGS = {
     "zh_crc32": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_uint32)]),
     "zh_adler32": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_uint32)]),
     "zh_free": (None, [_c.c_void_p]),
+    "zh_device_malloc": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_void_p)]),
+    "zh_device_free": (None, [_c.c_void_p, _c.c_void_p]),
+    "zh_device_upload": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t]),
+    "zh_device_download": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t]),
     "zh_plan_compress": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_uint64),
                                     _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64),
                                     _c.POINTER(_c.c_uint64), _c.c_int, _c.c_int,
@@ -66,6 +70,8 @@ _SIGS = {
     "zh_plan_device_lens": (_c.c_void_p, [_c.c_void_p]),
     "zh_plan_device_statuses": (_c.c_void_p, [_c.c_void_p]),
     "zh_plan_set_src_lens_device": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "zh_plan_pack": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_uint64, _c.c_void_p]),
+    "zh_plan_unpack": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "zh_plan_destroy": (None, [_c.c_void_p]),
     "zh_plan_set_profiling": (None, [_c.c_void_p, _c.c_int]),
     "zh_plan_kernel_times": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_char_p),
@@ -172,6 +178,14 @@ class Plan:
 
     def set_src_lens_device(self, d_lens):
         self.engine._check(self.engine.lib.zh_plan_set_src_lens_device(self._h, d_lens))
+
+    def pack(self, d_slots, d_packed, packed_cap, d_offsets):
+        """The plan's results back to back at d_packed, n + 1 device uint64 offsets at d_offsets (zh_plan_pack)."""
+        self.engine._check(self.engine.lib.zh_plan_pack(self._h, d_slots, d_packed, packed_cap, d_offsets))
+
+    def unpack(self, d_packed, d_offsets, d_slots):
+        """Streams back to back -> an uncompress plan's source slots and device-side lengths (zh_plan_unpack)."""
+        self.engine._check(self.engine.lib.zh_plan_unpack(self._h, d_packed, d_offsets, d_slots))
 
     def set_profiling(self, on=True):
         self.engine.lib.zh_plan_set_profiling(self._h, 1 if on else 0)

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libzippy_hip.so")
-SOURCES = ["zh_context.hip", "zh_plan_compress.hip", "zh_plan_uncompress.hip", "zh_plan_run.hip", "zh_host_batch.hip", "zh_host_calls.hip", "zh_checksum.hip", "zh_inflate.hip", "zh_inflate_split.hip", "zh_inflate_seg.hip", "zh_l1_match.hip", "zh_l1p_match.hip",
+SOURCES = ["zh_context.hip", "zh_plan_compress.hip", "zh_plan_uncompress.hip", "zh_plan_run.hip", "zh_plan_pack.hip", "zh_host_batch.hip", "zh_host_calls.hip", "zh_checksum.hip", "zh_inflate.hip", "zh_inflate_split.hip", "zh_inflate_seg.hip", "zh_l1_match.hip", "zh_l1p_match.hip",
            "zh_chain_match.hip", "zh_huffman.hip", "zh_emit.hip", "zh_zip.hip", "zh_tar.hip"]
 HEADERS = ["zh_common.h", "zh_host.h", "zh_tables.h", "zh_kprof.h", "zh_inflate_tables.h", os.path.join("..", "..", "include", "zippy_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

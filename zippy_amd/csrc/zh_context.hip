@@ -182,6 +182,37 @@ extern "C" void zh_set_gzip_fname_len(zh_ctx* ctx, int k) {
   if (ctx) ctx->fname_len = k > 25 ? 25 : k;
 }
 extern "C" void zh_free(void* p) { free(p); }
+
+// Device memory for callers that have no HIP binding of their own (a Nim / cgo / C shim that uses the plans):
+// blocks from the context's cache, copies on the context's stream and waited for.
+extern "C" int zh_device_malloc(zh_ctx* ctx, size_t bytes, void** d_out) {
+  if (!ctx || !d_out) return ZH_ERR_ARGUMENT;
+  *d_out = nullptr;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+  ZH_HIP(ctx, ctx_malloc(ctx, d_out, bytes ? bytes : 1));
+  return ZH_OK;
+}
+extern "C" void zh_device_free(zh_ctx* ctx, void* d) {
+  if (!ctx || !d) return;
+  (void)hipStreamSynchronize(ctx->stream);  // (kernels of the context may still be reading it)
+  ctx_free(ctx, d);
+}
+extern "C" int zh_device_upload(zh_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+  if (!ctx || (bytes && (!d_dst || !src))) return ZH_ERR_ARGUMENT;
+  if (!bytes) return ZH_OK;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+  ZH_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZH_OK;
+}
+extern "C" int zh_device_download(zh_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !d_src))) return ZH_ERR_ARGUMENT;
+  if (!bytes) return ZH_OK;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+  ZH_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZH_OK;
+}
 extern "C" void zh_set_host_pipeline(zh_ctx* ctx, size_t min_batch_bytes, size_t group_bytes) {
   if (!ctx) return;
   ctx->pipe_min = min_batch_bytes;

@@ -206,6 +206,8 @@ struct zh_plan {
   uint64_t* out_len = nullptr;
   int32_t* status = nullptr;
   const uint64_t* src_len_dev = nullptr;
+  uint64_t src_max_len = 0;         // uncompress plans: the longest source slot (zh_plan_unpack's grid)
+  uint64_t* unpack_lens = nullptr;  // ... and the device-side lengths zh_plan_unpack leaves (allocated by its first call)
   // block index (zh_plan_block_index): host copies of the geometry
   std::vector<ZhBufDesc> h_bufs;
   std::vector<ZhBlockDesc> h_blocks;

@@ -80,7 +80,6 @@ constexpr uint32_t kRunUp = ZH_RUNUP;
 static_assert(kRunUp <= ZH_SUBBITS, "a run-up stays inside the subchunk before");
 constexpr uint32_t kMinTurns = 3;     // speculative turns before the all-starts pass may take over
 constexpr uint32_t kSlowGain = 12;    // ... when a turn added fewer final threads than this
-constexpr uint32_t kMapGroup = 64;    // subchunks mapped per all-starts pass
 constexpr uint32_t kStartSpan = 48;   // a token is at most 48 bits: a subchunk's true start is one of 48
 constexpr uint32_t kMapTerm = 0xffu;  // all-starts map: "ends the block (or fails) in this subchunk"
 
@@ -107,7 +106,7 @@ struct RunResult {
 // block the segment's search found, stops at the first block boundary at or behind the next found
 // start, and reports where that was, how many bytes its tokens make and whether the stream ended.
 template <uint32_t kSplitThreads, bool kSeg>
-__global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void zh_inflate_tokens_kernel(const uint8_t* __restrict__ d_src,
+__global__ __launch_bounds__(kSplitThreads, kSplitThreads <= 256 ? 4 : 1) void zh_inflate_tokens_kernel(const uint8_t* __restrict__ d_src,
                                                                 ZhInflateArgs a,
                                                                 uint32_t* __restrict__ tok_pool,
                                                                 const uint64_t* __restrict__ tok_off,
@@ -116,6 +115,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
   constexpr uint32_t kSuperBits = kSplitThreads * kSubBits;
   constexpr uint32_t kStageWords = (kSplitThreads + 1u) * kSubStride;
   constexpr uint32_t kWaves = kSplitThreads / 64u;
+  constexpr uint32_t kMapGroup = kSplitThreads >= 256u ? 64u : 16u;  // subchunks mapped per all-starts pass
   __shared__ uint32_t s_lit[(1u << kLitBits) + kLitSub];
   __shared__ uint32_t s_dst[(1u << kDistBits) + kDistSub];  // also hosts the 7-bit code-length table
   __shared__ uint32_t s_in[kStageWords];
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
   bool sub_first = false, seg_landed = false;
   // A rerun (phases 4 / 5 = 0 / 1 once more, zh_seg_repair_kernel): only the streams under repair.
   const bool rerun = kSeg && phase >= 4;
+  const int route = kSeg ? 0 : phase;  // (batches: 9 / 8, see below; 1: every stream)
   phase &= 3;
   if (rerun && !g.repair[bid]) return;
   if (kSeg && phase != 0) {
@@ -177,6 +178,17 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? 4 : 1) void z
     if (off + 4 > end) v &= (1u << (8 * (uint32_t)(end - off))) - 1u;
     return v;
   };
+  // Batches take two forms of this kernel (zh_launch_inflate_tokens): a superchunk's worth of lanes is busy only while
+  // the block lasts, and a stream of short blocks -- system zlib's are ~ 15 KiB of codes each -- ends most
+  // superchunks of 256 subchunks early; 128 fill twice as well (zlib-6 members 12.7 -> 10.7 ms), at ~ 7 % more
+  // on long blocks (barriers and scans over half the lanes).  What a stream is made of is not known before it is
+  // decoded; whether its first block is its last is: bit 0 of the body.  route 1: streams of ONE block (this
+  // library's own up to 4 MiB of input), 2: the others.
+  if (!kSeg && route >= 8) {
+    const uint64_t b0 = (uint64_t)mis + a.body_pos[sid];
+    const bool one_block = ((load_dword(b0 & ~(uint64_t)3) >> (8u * (uint32_t)(b0 & 3u))) & 1u) != 0u;
+    if (one_block != (route == 9)) return;
+  }
   uint32_t* const tok = tok_pool + (kSeg ? g.eff_tok_off[sid] : tok_off[sid]);
   const uint64_t cap = kSeg ? g.eff_tok_cap[sid] : tok_cap[sid];  // records this stream may write (the end record included)
   __shared__ uint32_t s_wbytes[kWaves];
@@ -1139,7 +1151,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
     uint32_t far_off[kB];  // where a byte copied from before the round comes from: bytes behind (op - 32768)
     uint32_t far_mask = 0, near_mask = 0;
     const uint64_t op_s = (uint64_t)zh_bcast((uint32_t)op) | ((uint64_t)zh_bcast((uint32_t)(op >> 32)) << 32);
-    const Sym* const far_base = reinterpret_cast<const Sym*>(reinterpret_cast<uintptr_t>(dst) + (op_s - 32768u) * sizeof(Sym));
+    const Sym* const far_base = dst + ((int64_t)op_s - 32768);  // (pointer arithmetic: the loads stay global_load, a base for the wave + an offset a lane)
 #pragma unroll
     for (uint32_t j = 0; j < kB; j++) {
       const uint32_t pb = kB * tid + j;       // byte of the round
@@ -1295,8 +1307,10 @@ extern "C" void zh_launch_inflate_tokens(hipStream_t stream, const uint8_t* d_sr
   if (!a.nbufs) return;
   if (zh_tokens_width(a.nbufs) == 1024u)
     hipLaunchKernelGGL((zh_inflate_tokens_kernel<1024, false>), dim3(a.nbufs), dim3(1024), 0, stream, d_src, a, tok_pool, tok_off, tok_cap, ZhSegArgs{}, 1);
-  else
-    hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, false>), dim3(a.nbufs), dim3(256), 0, stream, d_src, a, tok_pool, tok_off, tok_cap, ZhSegArgs{}, 1);
+  else {  // (phase 9: the streams of one block, 8: the others -- see the kernel)
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, false>), dim3(a.nbufs), dim3(256), 0, stream, d_src, a, tok_pool, tok_off, tok_cap, ZhSegArgs{}, 9);
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<128, false>), dim3(a.nbufs), dim3(128), 0, stream, d_src, a, tok_pool, tok_off, tok_cap, ZhSegArgs{}, 8);
+  }
 }
 // phase 0: sub-starts for the segments inside long blocks
 // (before zh_seg_decide_kernel); phase 1: the tokens; 4 / 5: the same once more for the streams under repair

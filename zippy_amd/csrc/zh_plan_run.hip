@@ -49,6 +49,7 @@ extern "C" void zh_plan_destroy(zh_plan* p) {
   if (p->sg_sym) ctx_free(p->ctx, p->sg_sym);
   if (p->sg_windows) ctx_free(p->ctx, p->sg_windows);
   if (p->sg_winsym) ctx_free(p->ctx, p->sg_winsym);
+  if (p->unpack_lens) ctx_free(p->ctx, p->unpack_lens);
   for (auto e : p->k_events) (void)hipEventDestroy(e);
   delete p;
 }

@@ -195,6 +195,10 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
   p->is_compress = false;
   p->n = n;
   p->fmt = data_format;
+  for (const ZhBufDesc& b : bufs) {
+    p->src_max_len = std::max<uint64_t>(p->src_max_len, b.src_len);
+    p->dst_max_cap = std::max<uint64_t>(p->dst_max_cap, b.dst_cap);
+  }
   const size_t np = pieces.size();
   Arena ar;
   const size_t o_bufs = ar.reserve(n * sizeof(ZhBufDesc)), o_pieces = ar.reserve(np * sizeof(ZhPieceDesc));

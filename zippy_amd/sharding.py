@@ -133,3 +133,26 @@ def scatter_variable(batch_bytes, lens, n_buffers, root=0, group=None, device=No
         for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, mine, root, group)]):
             w.wait()
     return mine, lens[lo:hi]
+
+
+def pack_plan(plan, slots, n_buffers):
+    """The results of a device-resident plan (zippy_amd Plan; `slots`: the uint8 tensor its run wrote into) packed back
+    to back on the device -- zh_plan_pack: two launches on the engine's stream, no per-buffer copy, the lengths are
+    the ones the run left on the device -> (bytes, lens) as gather_variable takes them.  One host read: the total."""
+    packed = torch.empty(max(1, slots.numel()), dtype=torch.uint8, device=slots.device)
+    offs = torch.zeros(n_buffers + 1, dtype=torch.int64, device=slots.device)
+    plan.pack(slots.data_ptr(), packed.data_ptr(), packed.numel(), offs.data_ptr())
+    if slots.is_cuda:
+        torch.cuda.current_stream(slots.device).synchronize()
+    total = int(offs[n_buffers].item())
+    assert total <= packed.numel()
+    return packed[:total], offs[1:] - offs[:-1]
+
+
+def unpack_into_plan(plan, packed, lens, slots):
+    """Inverse: streams back to back (as scatter_variable delivers them) into an uncompress plan's source slots, the
+    lengths with them (zh_plan_unpack)."""
+    offs = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=slots.device)
+    offs[1:] = torch.cumsum(lens.to(slots.device), 0)
+    plan.unpack(packed.data_ptr(), offs.data_ptr(), slots.data_ptr())
+    return offs  # (kept alive by the caller until the plan has run)
