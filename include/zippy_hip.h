@@ -405,8 +405,10 @@ int zh_debug_tokens(zh_ctx *ctx, const void *src, size_t len, int level, uint16_
 /* Debug hook: ONE prefix code from a histogram of num_freq <= 288 symbols (deflate.nim:13-151 huffmanCodes:
  * min_codes as the reference's minCodes, limit <= 15 bits).  contract 0: the replay of the reference (its heap
  * order, its length limiting) -- the tests hold it against the oracle symbol for symbol; 1: contract mode's
- * builder (zh_set_l1_parse(ctx, 1)) -- an optimal code with other tie-breaks.  codes (bit-reversed, as they
- * go into the stream) and lens hold num_freq + 2 entries; *num_codes is the reference's numCodes. */
+ * builder (zh_set_l1_parse(ctx, 1)) -- other tie-breaks; optimal unless the length limit binds (then repaired the
+ * way zlib / miniz do: valid, not always the minimum).  codes (bit-reversed, as they
+ * go into the stream) and lens hold num_freq + 2 entries; *num_codes is the reference's numCodes (min_codes <=
+ * num_freq, as in every call of the reference's: anything else is ZH_ERR_ARGUMENT). */
 int zh_debug_huffman(zh_ctx *ctx, const uint32_t *freq, int num_freq, int min_codes, int limit, int contract,
                      uint16_t *codes, uint8_t *lens, int *num_codes);
 /* Large streams are decoded by many workgroups each (segment-wise) when the chain of their segments holds, by one

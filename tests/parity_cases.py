@@ -733,6 +733,26 @@ def check_plan_slots_with_gaps(eng, upload, download, alloc):
         plan.run(d_src, d_dst + 1)
 
 
+def check_plan_reruns(eng, upload, download, alloc, n, size):
+    """A compress plan run three times (zh_l1_match.hip: from the second run on the BestSpeed matcher's waves take the
+    fragments longest first, by what they cost the run before -- more fragments than waves here, so the order is a
+    real one): every run's streams are the oracle's, byte for byte."""
+    bufs = [b.tobytes() for b in synth.gen_batch("mix", n, size)]
+    d_src, keep_src = upload(b"".join(bufs) + b"\0" * 16)
+    cap = size + size // 8 + 2048
+    slot = (cap + 255) & ~255
+    d_dst, keep_dst = alloc(n * slot, 0)
+    plan = eng.plan_compress([i * size for i in range(n)], [size] * n, [i * slot for i in range(n)], [cap] * n, 1, oracle.dfGzip)
+    want = [oracle.compress(b, 1, oracle.dfGzip, fname_len=0) for b in bufs]
+    for run in range(3):
+        plan.run(d_src, d_dst)
+        lens, sts = plan.results()
+        assert all(st == 0 for st in sts), run
+        got = download(keep_dst)
+        for i, w in enumerate(want):
+            assert lens[i] == len(w) and got[i * slot:i * slot + lens[i]] == w, (run, i)
+
+
 def check_plan_pack(eng, upload, download, alloc):
     """zh_plan_pack / zh_plan_unpack (include/zippy_hip.h; zippy.nim:11-18: whole buffers are all that travels): a
     compress plan's results back to back with n + 1 device offsets == the oracle's streams concatenated (a failed

@@ -67,21 +67,62 @@ def test_emu_chain_levels_across_windows(eng):
     pc.check_tokens(eng, stale, -1)
 
 
-def test_emu_chain_cross_check_kernels():
-    """The in-order link kernels and the every-position search (ZH_CHAIN_PREV=serial, ZH_CHAIN_SEARCH=dense:
-    switches read once a process) give the oracle's bytes, too."""
+def test_emu_cross_check_kernels():
+    """The test build of the library (-DZH_XCHECK: tests/hipemu/libzippy_hip_emu_xcheck.so here, `python -m
+    zippy_amd.build --variant xcheck -DZH_XCHECK` on a GPU box) carries what the product library does not ship: the
+    in-order link kernels on request, the every-position search, the one-wave parse (ZH_CHAIN_PREV=serial,
+    ZH_CHAIN_SEARCH=dense, ZH_CHAIN_SELECT=serial), the BestSpeed matcher with its table in LDS (ZH_L1_TABLE=lds) and
+    the thread-per-candidate block-start check (ZH_SEG_CHECK=serial; switches read once a process).  Each gives the
+    oracle's bytes, too."""
     import os
     import subprocess
     import sys
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import emu, oracle, parity_cases as pc\n"
-            "from test_emu_parity import _chain_inputs\n"
-            "pc.check_compress_identical(emu.engine(), [_chain_inputs()[0]], levels=(-1,), formats=(oracle.dfDeflate,))\n"
-            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-    for env in ({"ZH_CHAIN_PREV": "serial"}, {"ZH_CHAIN_SEARCH": "dense"}, {"ZH_CHAIN_SELECT": "serial"}):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
-                           timeout=900)
+    here, root = os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    chain = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+             "import emu, oracle, parity_cases as pc\n"
+             "from test_emu_parity import _chain_inputs\n"
+             "pc.check_compress_identical(emu.engine(), [_chain_inputs()[0]], levels=(-1,), formats=(oracle.dfDeflate,))\n"
+             % (here, root))
+    l1 = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+          "import emu, oracle, parity_cases as pc, synth\n"
+          "pc.check_compress_identical(emu.engine(), [synth.corpus_file('alice29.txt')[:100000], synth.corpus_file('html')[:70000]],"
+          " levels=(1,), formats=(oracle.dfGzip,))\n" % (here, root))
+    seg = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+           "import emu, zlib, synth\n"
+           "eng = emu.engine()\n"
+           "data = synth.gen_batch('mix', 1, 700000)[0].tobytes()\n"
+           "z = zlib.compress(data, 6)\n"
+           "outs, sts = eng.uncompress_batch([z])\n"
+           "assert sts == [0] and outs[0] == data\n"
+           "cut, held = eng.segment_stats()\n"
+           "assert cut >= 1 and held == cut, (cut, held)\n" % (here, root))
+    base = dict(os.environ, ZH_EMU_VARIANT="xcheck", ZH_EMU_DEFINES="-DZH_XCHECK")
+    for code, env in ((chain, {"ZH_CHAIN_PREV": "serial"}), (chain, {"ZH_CHAIN_SEARCH": "dense"}),
+                      (chain, {"ZH_CHAIN_SELECT": "serial"}), (l1, {"ZH_L1_TABLE": "lds"}),
+                      (seg, {"ZH_SEG_CHECK": "serial", "ZH_SEG_MIN": "65536", "ZH_SEG_BYTES": "8192", "ZH_SEG_SETUP": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(base, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (env, r.stderr[-2000:])
+
+
+def test_product_library_ships_one_implementation():
+    """nm -D of the product library (and of the emulator build of the same sources) lists none of the cross-check
+    kernels; the -DZH_XCHECK build does."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = ("zh_chain_search_kernel", "zh_chain_select_kernel")
+    def syms(path):
+        return subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    import build_emu
+    emu_syms = syms(build_emu.build())
+    assert not any(n in emu_syms for n in names)
+    prod = os.path.join(root, "zippy_amd", "libzippy_hip.so")
+    if os.path.exists(prod):
+        out = syms(prod)
+        assert "zh_plan_run" in out and not any(n in out for n in names), "a cross-check kernel in the product library"
+    xc = os.path.join(root, "tests", "hipemu", "libzippy_hip_emu_xcheck.so")
+    if os.path.exists(xc):
+        assert all(n in syms(xc) for n in names)
 
 
 def test_emu_lds_order_probe(eng):
@@ -244,6 +285,17 @@ def test_emu_plan_slots_with_gaps(eng):
         buf = ctypes.create_string_buffer(bytes([fill]) * n, n)
         return ctypes.addressof(buf), buf
     pc.check_plan_slots_with_gaps(eng, upload, lambda keep: keep.raw, alloc)
+
+
+def test_emu_plan_reruns_longest_first(eng):
+    import ctypes
+    def upload(b):
+        buf = ctypes.create_string_buffer(b, len(b))
+        return ctypes.addressof(buf), buf
+    def alloc(n, fill):
+        buf = ctypes.create_string_buffer(bytes([fill]) * n, n)
+        return ctypes.addressof(buf), buf
+    pc.check_plan_reruns(eng, upload, lambda keep: keep.raw, alloc, 9, 300000)  # (90 fragments on the emulator's 64 waves)
 
 
 def test_emu_plan_pack(eng):

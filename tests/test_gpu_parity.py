@@ -39,6 +39,48 @@ def test_gpu_lds_order_probe(eng):
     assert eng.chain_links_parallel(), eng.lib.zh_last_error(eng._h)
 
 
+def test_gpu_cross_check_kernels():
+    """The test build (-DZH_XCHECK, libzippy_hip_xcheck.so: built by __graft_entry__.build()) with each cross-check
+    switched on in a child process: the in-order links, the every-position search, the one-wave parse, the BestSpeed
+    matcher with its table in LDS, the thread-per-candidate block-start check -- the oracle's bytes every time; and
+    the product library exports none of those kernels."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from zippy_amd import build
+    lib = build.build(variant="xcheck", defines=["-DZH_XCHECK"])
+    chain = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+             "import torch; torch.cuda.init()\n"
+             "import oracle, synth, parity_cases as pc\n"
+             "from zippy_amd import api\n"
+             "eng = api.engine(); eng.set_gzip_fname_len(0)\n"
+             "bufs = [b.tobytes() for b in synth.gen_batch('mix', 6, 1 << 20)]\n"
+             "pc.check_compress_identical(eng, bufs, levels=(-1,), formats=(oracle.dfGzip,))\n"
+             % (os.path.join(root, "tests"), root))
+    l1 = chain.replace("levels=(-1,)", "levels=(1,)")
+    seg = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+           "import torch; torch.cuda.init()\n"
+           "import zlib, synth\n"
+           "from zippy_amd import api\n"
+           "eng = api.engine()\n"
+           "data = synth.gen_batch('mix', 1, 24 << 20)[0].tobytes()\n"
+           "outs, sts = eng.uncompress_batch([zlib.compress(data, 6)])\n"
+           "assert sts == [0] and outs[0] == data\n"
+           "cut, held = eng.segment_stats()\n"
+           "assert cut == 1 and held == 1, (cut, held)\n" % (os.path.join(root, "tests"), root))
+    for code, env in ((chain, {"ZH_CHAIN_PREV": "serial"}), (chain, {"ZH_CHAIN_SEARCH": "dense"}),
+                      (chain, {"ZH_CHAIN_SELECT": "serial"}), (l1, {"ZH_L1_TABLE": "lds"}), (seg, {"ZH_SEG_CHECK": "serial"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZIPPY_HIP_LIB=lib, **env), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, (env, r.stdout[-1000:], r.stderr[-3000:])
+    def syms(path):
+        return subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    names = ("zh_chain_search_kernel", "zh_chain_select_kernel")
+    assert all(n in syms(lib) for n in names)
+    assert not any(n in syms(build.build()) for n in names), "a cross-check kernel in the product library"
+
+
 def test_gpu_damaged_headers(eng, inflate_mode):
     """Every bit of three dynamic headers flipped in turn (2 160 raw deflate streams): the wave-parallel header
     reader, its fall-back to the serial one and the workgroup-built tables against the oracle."""
@@ -376,6 +418,17 @@ def test_gpu_plan_slots_with_gaps(eng):
         t = torch.full((n,), fill, dtype=torch.uint8, device="cuda")
         return t.data_ptr(), t
     pc.check_plan_slots_with_gaps(eng, upload, lambda t: t.cpu().numpy().tobytes(), alloc)
+
+
+def test_gpu_plan_reruns_longest_first(eng):
+    import torch
+    def upload(b):
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+        return t.data_ptr(), t
+    def alloc(n, fill):
+        t = torch.full((n,), fill, dtype=torch.uint8, device="cuda")
+        return t.data_ptr(), t
+    pc.check_plan_reruns(eng, upload, lambda t: t.cpu().numpy().tobytes(), alloc, 200, 1 << 20)  # (6400 fragments, 5120 waves)
 
 
 def test_gpu_plan_pack(eng):

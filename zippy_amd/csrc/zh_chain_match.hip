@@ -442,7 +442,8 @@ __device__ __forceinline__ uint32_t zh_chain_search_one(const uint8_t* __restric
 // best[] entries: bit 31 = "worked out" (length in bits 0-15, offset in bits 16-30)
 constexpr uint32_t kBestKnown = 0x80000000u;
 
-// ---- 2a. every position (ZH_CHAIN_SEARCH=dense: cross-check and measurement) ----
+#ifdef ZH_XCHECK
+// ---- 2a. every position (the test build's ZH_CHAIN_SEARCH=dense: cross-check) ----
 __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __restrict__ d_src,
                                                               ZhCompressArgs a, int good, int nice,
                                                               int max_chain,
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __r
   best[(size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE + pos] =
       kBestKnown | zh_chain_search_one(d_src + bd.src_off, pw, pos, (uint32_t)bd.len, good, nice, max_chain);
 }
+#endif  // ZH_XCHECK
 
 // ---- 2b. the positions a greedy walk comes by ----
 // The parse (kernel 3) only ever asks for the positions it visits -- about a third of them -- and
@@ -650,7 +652,9 @@ __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8
   }
 }
 
-// ---- 3. the greedy parse (lz77.nim:73-130) over the per-position results ----
+#ifdef ZH_XCHECK
+// ---- 3. the greedy parse (lz77.nim:73-130) over the per-position results, a wave a block (the test build's
+// ZH_CHAIN_SELECT=serial: cross-check) ----
 __global__ __launch_bounds__(64) void zh_chain_select_kernel(ZhCompressArgs a,
                                                              const uint32_t* __restrict__ best) {
   const unsigned lane = zh_lane();
@@ -701,6 +705,7 @@ __global__ __launch_bounds__(64) void zh_chain_select_kernel(ZhCompressArgs a,
   }
   close_frags_until(bd.nfrag);
 }
+#endif  // ZH_XCHECK
 
 // ---- 3b. the same greedy parse, parallel inside a block ----
 // The per-position results are static, so the parse is a walk p -> p + (len ? len : 1) over fixed
@@ -1007,24 +1012,14 @@ extern "C" int zh_chain_lds_order_ok(int device, hipStream_t stream) {
   }
   return v == 1;
 }
-// ZH_CHAIN_PREV=serial: the in-order kernels 1 / 1b (a wave a block) instead of 1c: cross-check and measurement;
-// also what a device gets that failed the probe above
-static bool chain_prev_serial() {
-  static const bool on = [] {
-    const char* e = getenv("ZH_CHAIN_PREV");
-    return e && strcmp(e, "serial") == 0;
-  }();
-  if (on) return true;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-  return g_lds_order[dev].load() != 1;  // (never asked: no context was made on this device -- be safe)
-}
-extern "C" int zh_chain_prev_is_serial(void) { return chain_prev_serial() ? 1 : 0; }
+// `links_serial` (zh_ctx::chain_links_serial): the in-order kernels 1 / 1b (a wave a block) instead of 1c -- what a device
+// gets that failed the probe above (the decision is the context's, made once at zh_create for ITS device; the test
+// build -DZH_XCHECK also takes it from ZH_CHAIN_PREV=serial, as a cross-check).
 // `lists`: 4 bytes a position of scratch (the plan lends best[], which the walks clear before they use it)
 extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
-                                     uint32_t* head_scratch, uint64_t* prevw, uint32_t* lists) {
+                                     uint32_t* head_scratch, uint64_t* prevw, uint32_t* lists, int links_serial) {
   if (!a.nblocks) return;
-  if (!chain_prev_serial()) {
+  if (!links_serial) {
     // (head_scratch holds at least 256 KiB a block: kClsStride words)
     const uint32_t ngrid = a.nfrags * (kUnitsPerFrag / kClsWaves);
     hipLaunchKernelGGL(zh_chain_class_kernel<false>, dim3(ngrid), dim3(64 * kClsWaves), 0, stream, d_src, a, head_scratch, lists);
@@ -1046,8 +1041,10 @@ extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, Z
   hipLaunchKernelGGL(zh_chain_prev_ldst_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a,
                      reinterpret_cast<uint16_t*>(head_scratch), prevw, a.first_block);
 }
-// ZH_CHAIN_SEARCH=dense: the best match of EVERY position (kernel 2a) instead of the walks of kernel
-// 2b; ZH_CHAIN_SELECT=serial (one wave per block, needs the dense search): cross-checks and measurement
+// The cross-checks of the test build (-DZH_XCHECK; the product library has neither the switches nor the kernels):
+// ZH_CHAIN_SEARCH=dense: the best match of EVERY position (kernel 2a) instead of the walks of kernel 2b;
+// ZH_CHAIN_SELECT=serial (one wave per block, needs the dense search).
+#ifdef ZH_XCHECK
 static bool chain_select_serial() {
   static const bool on = [] {
     const char* e = getenv("ZH_CHAIN_SELECT");
@@ -1062,21 +1059,28 @@ static bool chain_search_dense() {
   }();
   return on || chain_select_serial();
 }
+#else
+static constexpr bool chain_select_serial() { return false; }
+static constexpr bool chain_search_dense() { return false; }
+#endif
 extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
                                        int good, int nice, int max_chain, const uint64_t* prevw,
-                                       uint32_t* best) {
+                                       uint32_t* best, int links_serial) {
   // a launch takes at most 2^30 positions (a grid of 2^32 threads or more is refused), so batches
   // of 1 GiB and more go in slices
   constexpr uint32_t kSlice = 32768;  // fragments per launch
   for (uint32_t f0 = 0; f0 < a.nfrags; f0 += kSlice) {
     const uint32_t nf = a.nfrags - f0 < kSlice ? a.nfrags - f0 : kSlice;
+#ifdef ZH_XCHECK
     if (chain_search_dense()) {
       hipLaunchKernelGGL(zh_chain_search_kernel, dim3(nf * (ZH_FRAG_SIZE / 256u)), dim3(256), 0, stream,
                          d_src, a, good, nice, max_chain, prevw, best, a.first_frag + f0);
-    } else {
+    } else
+#endif
+    {
       // (nothing is worked out yet -- the walks of one launch may look at the next launch's entries --: the
       // class-sorted links have left best[] cleared; after the in-order kernels it still holds the last run's)
-      if (f0 == 0 && chain_prev_serial()) (void)hipMemsetAsync(best, 0, (size_t)a.nfrags * ZH_FRAG_SIZE * 4u, stream);
+      if (f0 == 0 && links_serial) (void)hipMemsetAsync(best, 0, (size_t)a.nfrags * ZH_FRAG_SIZE * 4u, stream);
       constexpr uint32_t kChunk = 32;
       const uint32_t ng = nf * (ZH_FRAG_SIZE / kChunk / kWalkThreads);
       hipLaunchKernelGGL(zh_chain_walk_kernel<kChunk>, dim3((ng + 7u) & ~7u), dim3(kWalkThreads), 0, stream, d_src, a, good,
@@ -1087,10 +1091,13 @@ extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src,
 extern "C" void zh_launch_chain_select(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a, int good,
                                        int nice, int max_chain, const uint64_t* prevw, uint32_t* best) {
   if (!a.nblocks) return;
-  if (chain_select_serial())
+#ifdef ZH_XCHECK
+  if (chain_select_serial()) {
     hipLaunchKernelGGL(zh_chain_select_kernel, dim3(a.nblocks), dim3(64), 0, stream, a, best);
-  else
-    hipLaunchKernelGGL(zh_chain_select_par_kernel, dim3(a.nblocks), dim3(256), 0, stream, d_src, a, good, nice,
+    return;
+  }
+#endif
+  hipLaunchKernelGGL(zh_chain_select_par_kernel, dim3(a.nblocks), dim3(256), 0, stream, d_src, a, good, nice,
                        max_chain, prevw, best);
 }
 extern "C" void zh_launch_frag_stats(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a) {

@@ -142,7 +142,7 @@ struct ZhSegArgs {
   const uint32_t* find_seg;     // [nfind]
   const uint32_t* find_batch;   // [nfind] (bit 31: the stream's last block may start in this batch: BFINAL = 1 counts too)
   uint32_t* cand_n;             // [nfind] positions of the batch that passed the cheap tests ...
-  uint32_t* cand_off;           // [nfind][64] ... as offsets into the batch
+  uint32_t* cand_off;           // [nfind][kSegFindSlots] ... as offsets into the batch
   uint32_t* go;                 // [nstreams] enough segments of the stream have a start: decode it segment-wise
   uint64_t* eff_tok_off;        // [nsegs] token region of a segment that keeps its decoder (zh_seg_decide_kernel:
   uint64_t* eff_tok_cap;        //   its own, or those of its whole group of segments)
@@ -154,6 +154,8 @@ struct ZhSegArgs {
   uint64_t* start_bit;          // [nsegs] first bit of the segment's first block, or kSegNone
   uint64_t* start2_bit;         // [nsegs] the next position of the segment that reads like a block's start (the probe of
                                 //   zh_inflate_tokens_kernel falls back on it), or kSegNone
+  uint64_t* held_start;         // [nsegs] a found start that zh_seg_decide_kernel's grouping set aside (a group keeps its first
+                                //   start's decoder): a repair round gets it back (kSegNone: none)
   uint64_t* end_bit;            // [nsegs] the block boundary the tokens kernel stopped at
   uint32_t* final_block;        // [nsegs] ... which was the end of the stream
   int32_t* seg_status;          // [nsegs] tokens kernel, then writer
@@ -259,6 +261,16 @@ __device__ __forceinline__ uint32_t zh_wave_scan_max(uint32_t v) {
   v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
   v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
   return v;
+#endif
+}
+// the shader clock (scheduling hints only: nothing that comes out depends on it; the emulator's is a sequence of
+// uneven steps, so that its "costs" make a real permutation)
+__device__ __forceinline__ uint64_t zh_clock() {
+#ifdef ZH_EMU
+  static uint64_t t = 0;  // (a sequence of uneven steps)
+  return t += 1000u + (uint32_t)((t * 2654435761ull) >> 9) % 3000000u;
+#else
+  return __builtin_readcyclecounter();
 #endif
 }
 __device__ __forceinline__ uint64_t zh_lanemask_lt() { return (1ull << zh_lane()) - 1ull; }

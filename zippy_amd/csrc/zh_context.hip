@@ -154,15 +154,20 @@ extern "C" int zh_create(int device, void* stream, zh_ctx** out) {
   }
   // the chain levels' parallel link kernels rest on the order in which the LDS unit serves the lanes of an
   // atomic: the device is asked once (zh_chain_match.hip); one that answers otherwise runs the in-order kernels
-  if (!zh_chain_lds_order_ok(device, c->stream))
+  if (!zh_chain_lds_order_ok(device, c->stream)) {
+    c->chain_links_serial = true;
     c->last_error = "this device does not serve the lanes of an LDS atomic in ascending order (or could not be asked): "
-                    "levels -1, 2..9 build their chain links with the in-order kernels (ZH_CHAIN_PREV=serial)";
+                    "levels -1, 2..9 build their chain links with the in-order kernels";
+  }
+#ifdef ZH_XCHECK  // (the test build: the in-order kernels as a cross-check of the class-sorted ones)
+  if (const char* e = getenv("ZH_CHAIN_PREV"))
+    if (strcmp(e, "serial") == 0) c->chain_links_serial = true;
+#endif
   *out = c;
   return ZH_OK;
 }
 extern "C" int zh_chain_links_parallel(zh_ctx* ctx) {
-  if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return 0;
-  return zh_chain_prev_is_serial() ? 0 : 1;
+  return ctx && !ctx->chain_links_serial ? 1 : 0;
 }
 
 extern "C" void zh_destroy(zh_ctx* ctx) {
@@ -173,6 +178,9 @@ extern "C" void zh_destroy(zh_ctx* ctx) {
   }
   for (auto& b : ctx->dev_blocks) (void)hipFree(b.p);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+  if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
+  if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -50,22 +50,23 @@ void zh_launch_seg_tokens(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, ui
 void zh_launch_seg_decide(hipStream_t, ZhInflateArgs a, ZhSegArgs g, int rerun);
 void zh_launch_seg_chain(hipStream_t, ZhInflateArgs a, ZhSegArgs g, int rerun);
 void zh_launch_seg_repair(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
+void zh_launch_seg_stats(hipStream_t, ZhSegArgs g, uint64_t* stats);
 void zh_launch_seg_write(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, const uint32_t* tok_pool, ZhSegArgs g);
 void zh_launch_seg_windows(hipStream_t, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_seg_finish(hipStream_t, uint8_t* d_dst, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_l1_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int huffman_only,
-                        uint16_t* table_pool, uint32_t* next_frag);
+                        uint16_t* table_pool, uint32_t* next_frag, uint32_t* cost, uint32_t* order, uint32_t* hist,
+                        int use_order);
 uint32_t zh_l1_table_slots(void);
 void zh_launch_l1p_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint16_t* link_pool,
                          uint32_t* next_frag);
 uint32_t zh_l1p_slots(void);
 void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint32_t* head_scratch,
-                          uint64_t* prevw, uint32_t* lists);
+                          uint64_t* prevw, uint32_t* lists, int links_serial);
 uint32_t zh_chain_prev_slice(void);
 int zh_chain_lds_order_ok(int device, hipStream_t stream);
-int zh_chain_prev_is_serial(void);
 void zh_launch_chain_search(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
-                            int max_chain, const uint64_t* prevw, uint32_t* best);
+                            int max_chain, const uint64_t* prevw, uint32_t* best, int links_serial);
 void zh_launch_chain_select(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
                             int max_chain, const uint64_t* prevw, uint32_t* best);
 void zh_launch_frag_stats(hipStream_t, const uint8_t* d_src, ZhCompressArgs a);
@@ -89,8 +90,11 @@ struct zh_ctx {
   int fname_len = -1;
   int inflate_mode = -1;  // -1: ZH_INFLATE or the default (split), 0 split, 1 serial
   int l1_parse = -1;      // -1: ZH_L1_PARSE or the default (exact), 0 exact (the reference's parse), 1 parallel
+  // chain levels: THIS device failed zh_create's probe of the LDS atomic lane order (zh_chain_match.hip): its links
+  // come from the in-order kernels
+  bool chain_links_serial = false;
   std::string last_error;
-  uint64_t seg_cut = 0, seg_held = 0;  // zh_debug_segment_stats
+  uint64_t* d_seg_stats = nullptr;  // zh_debug_segment_stats: two device counters (streams cut into segments / whose chain held)
   const void* cktabs = nullptr;
   std::mt19937 rng{std::random_device{}()};
   // host-buffer calls: two pinned staging chunks between the caller's pageable memory and HBM
@@ -99,6 +103,10 @@ struct zh_ctx {
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   bool pin_busy[2] = {false, false};
   hipStream_t copy_stream = nullptr;  // transfers of a pipelined batch, next to `stream`'s kernels
+  // a compress run's checksum kernels beside its code builder (zh_plan_run.hip): forked off `stream` behind the match
+  // finder, joined in front of the layout; the events are the context's (runs of one context follow each other)
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
   // zh_*_batch_into: the caller's output buffers and their sizes for the call in progress
   // (into_base: the dsts array the batch functions were handed, to find a buffer's index again)
   void* const* into_ptrs = nullptr;
@@ -186,6 +194,9 @@ struct zh_plan {
   size_t head_bytes = 0;             // best match per position (zh_chain_match.hip)
   uint16_t* l1_tables = nullptr;  // BestSpeed: pool of per-wave hash tables (zh_l1_match.hip)
   uint32_t* l1_counter = nullptr; // ... and the counter its waves draw fragments from
+  // longest first (zh_l1_match.hip): a fragment's cycles in the last run, the order made of them, scratch; l1_runs: runs so far
+  uint32_t *l1_cost = nullptr, *l1_order = nullptr, *l1_hist = nullptr;
+  uint32_t l1_runs = 0;
   uint64_t* chain_prev = nullptr;
   uint32_t* chain_best = nullptr;
   // best[] is cleared when the plan is made and handed back cleared by every run's link kernels; a run that
@@ -225,7 +236,9 @@ struct zh_plan {
   // large streams decoded segment-wise (zh_inflate_seg.hip); the symbol and window buffers come
   // with the token pool
   bool segmented = false;
-  bool seg_ran = false;  // the segment kernels of a run whose results have not been read yet
+  // test aids read when the plan is made (not on the run path): ZH_SEG_FAKE_START (a stream bit, ~0: none), ZH_TRACE_SEG
+  uint64_t sg_fake_start = ~0ull;
+  bool sg_trace = false;
   int sg_repair_rounds = 1;  // zh_seg_repair_kernel: twice where there is a lot to go wrong (plan_segments)
   ZhSegArgs sg{};
   uint8_t* sg_arena = nullptr;
@@ -238,6 +251,9 @@ struct zh_plan {
   std::vector<const char*> k_names;
   std::vector<hipEvent_t> k_events;
   std::vector<float> k_ms;
+  // kernels on the context's second stream (the checksum of a compress run): start / between / end
+  hipEvent_t k_aux[3] = {nullptr, nullptr, nullptr};
+  bool k_aux_used = false;
 };
 
 template <class T>

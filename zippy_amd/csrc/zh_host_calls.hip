@@ -183,8 +183,10 @@ extern "C" int zh_adler32(zh_ctx* ctx, const void* src, size_t len, uint32_t* ou
 // (byte-identical mode), 1: the wave-parallel optimal builder of contract mode.  codes / lens: num_freq + 2 entries.
 extern "C" int zh_debug_huffman(zh_ctx* ctx, const uint32_t* freq, int num_freq, int min_codes, int limit, int contract,
                                 uint16_t* codes, uint8_t* lens, int* num_codes) {
-  if (!ctx || !freq || !codes || !lens || !num_codes || num_freq < 1 || num_freq > 288 || min_codes < 1 || min_codes > 287 ||
-      limit < 1 || limit > 15)
+  // (min_codes <= num_freq: numCodes = max(highest, minCodes) + 1 then fits the num_freq + 2 entries the caller holds;
+  // the reference's own calls are 286 / 257, 30 / 2, 19 / 19, deflate.nim:285-290,355)
+  if (!ctx || !freq || !codes || !lens || !num_codes || num_freq < 1 || num_freq > 288 || min_codes < 1 ||
+      min_codes > num_freq || limit < 1 || limit > 15)
     return ZH_ERR_ARGUMENT;
   ZH_HIP(ctx, hipSetDevice(ctx->device));
   DevBuf d;
@@ -198,7 +200,7 @@ extern "C" int zh_debug_huffman(zh_ctx* ctx, const uint32_t* freq, int num_freq,
   int n = 0;
   ZH_HIP(ctx, hipMemcpyAsync(&n, d.p + o_n, 4, hipMemcpyDeviceToHost, s));
   ZH_HIP(ctx, hipStreamSynchronize(s));
-  if (n < 0 || n > 288) return ZH_ERR_COMPRESS_INTERNAL;
+  if (n < 0 || n > num_freq + 2) return ZH_ERR_COMPRESS_INTERNAL;
   ZH_HIP(ctx, hipMemcpyAsync(codes, d.p + o_codes, (size_t)n * 2, hipMemcpyDeviceToHost, s));
   ZH_HIP(ctx, hipMemcpyAsync(lens, d.p + o_lens, (size_t)n, hipMemcpyDeviceToHost, s));
   ZH_HIP(ctx, hipStreamSynchronize(s));
@@ -225,7 +227,7 @@ extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int lev
   hipStream_t s = ctx->stream;
   const ZhCompressArgs& a = p->ca;
   if (level == 1 || level == -2) {
-    zh_launch_l1_match(s, d_src.p, a, level == -2, p->l1_tables, p->l1_counter);
+    zh_launch_l1_match(s, d_src.p, a, level == -2, p->l1_tables, p->l1_counter, nullptr, nullptr, nullptr, 0);
   } else {
     const int* cfg = kChainConfig[level == -1 ? 6 : level];
     for (const auto& r : p->chain_ranges) {
@@ -234,8 +236,8 @@ extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int lev
       ar.nblocks = r.nb;
       ar.first_frag = r.f0;
       ar.nfrags = r.nf;
-      zh_launch_chain_prev(s, d_src.p, ar, p->head_scratch, p->chain_prev, p->chain_best);
-      zh_launch_chain_search(s, d_src.p, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+      zh_launch_chain_prev(s, d_src.p, ar, p->head_scratch, p->chain_prev, p->chain_best, p->ctx->chain_links_serial ? 1 : 0);
+      zh_launch_chain_search(s, d_src.p, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best, p->ctx->chain_links_serial ? 1 : 0);
       zh_launch_chain_select(s, d_src.p, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
     }
   }

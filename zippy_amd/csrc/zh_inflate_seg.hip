@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kFindThreads) void zh_seg_find_kernel(const uint8_t
   // the survivors go to this workgroup's slots of the queue (one position in 4 500 of random bits:
   // fifteen a batch)
   const uint32_t nc = s_ncand < kFindSlots ? s_ncand : kFindSlots;
-  if (tid < nc) g.cand_off[(size_t)blockIdx.x * kFindSlots + tid] = s_cand[tid];
+  for (uint32_t k = tid; k < nc; k += kFindThreads) g.cand_off[(size_t)blockIdx.x * kFindSlots + k] = s_cand[k];
   if (tid == 0) g.cand_n[blockIdx.x] = s_ncand;  // (all of them: who reads the queue clamps; ZH_TRACE_SEG counts the overflows)
   KPROF_FLUSH(56, 8);
 }
@@ -457,7 +457,8 @@ __global__ __launch_bounds__(64) void zh_seg_check_kernel(const uint8_t* __restr
   const uint32_t bid = g.parent[sid];
   const ZhBufDesc bd = a.bufs[bid];
   const uint64_t len = a.src_len_dev ? a.src_len_dev[bid] : bd.src_len;
-  if (serial) {  // a thread per candidate
+#ifdef ZH_XCHECK
+  if (serial) {  // a thread per candidate (the test build's cross-check)
     for (uint32_t c = lane; c < nc; c += 64u) {
       const uint64_t p = base + g.cand_off[(size_t)w * kFindSlots + c];
       if (p >= *(volatile uint64_t*)&g.start2_bit[sid]) continue;  // (two lower positions have passed already)
@@ -465,6 +466,7 @@ __global__ __launch_bounds__(64) void zh_seg_check_kernel(const uint8_t* __restr
     }
     return;
   }
+#endif
   KPROF_DECL(8);  // cycles: 0 set-up, 1 candidates; counts: 3 candidates, 4 passed, 5 waves
   KPROF_COUNT(5, 1);
   KPROF_MARK(0);
@@ -507,6 +509,7 @@ __global__ __launch_bounds__(64) void zh_seg_decide_kernel(ZhInflateArgs a, ZhSe
       sub = 1;
     }
     g.is_sub[k] = sub;
+    if (!rerun) g.held_start[k] = kSegNone;
     found += sk != kSegNone;
   }
   found = zh_wave_sum(found);
@@ -523,7 +526,8 @@ __global__ __launch_bounds__(64) void zh_seg_decide_kernel(ZhInflateArgs a, ZhSe
     bool taken = false;
     for (uint32_t k = k0; k < k1; k++) {
       if (g.start_bit[k] == kSegNone) continue;
-      if (taken) {
+      if (taken) {  // (set aside, not forgotten: should the group's first start be none, a repair round asks this one)
+        if (!g.is_sub[k]) g.held_start[k] = g.start_bit[k];
         g.start_bit[k] = kSegNone;
         continue;
       }
@@ -569,18 +573,28 @@ __global__ __launch_bounds__(64) void zh_seg_repair_kernel(ZhInflateArgs a, ZhSe
   const unsigned lane = zh_lane();
   const uint32_t first = g.first_seg[bid], last = g.first_seg[bid + 1u];
   const bool broken = last > first && a.status[bid] == ZH_OK && g.go[bid] != 0u && g.stream_ok[bid] == 0u;
+  auto failed = [&](uint32_t k) -> bool {  // a found start whose decoder gave itself away
+    return g.start_bit[k] != kSegNone && !g.is_sub[k] && g.seg_status[k] != ZH_OK && g.seg_status[k] != ZH_ERR_DST_TOO_SMALL;
+  };
   uint32_t dropped = 0;
-  for (uint32_t k = first + 1u + lane; broken && k < last; k += 64u) {  // (the stream's first block is where it is)
-    if (g.start_bit[k] == kSegNone) continue;
-    if (g.is_sub[k]) {
+  for (uint32_t k = first + 1u + lane; broken && k < last; k += 64u) dropped += failed(k) ? 1u : 0u;  // (the stream's first block is where it is)
+  dropped = zh_wave_sum(dropped);
+  // nothing to take out: nothing is touched (the stream goes to the ordinary kernels as it stands)
+  for (uint32_t k = first + 1u + lane; dropped && k < last; k += 64u) {
+    if (g.start_bit[k] == kSegNone) {
+      // a found start the grouping had set aside: the group's first one may be what is taken out now, and the
+      // decision of the round to come sees every found start again
+      if (g.held_start[k] != kSegNone) {
+        g.start_bit[k] = g.held_start[k];
+        g.held_start[k] = kSegNone;
+      }
+    } else if (g.is_sub[k]) {
       g.start_bit[k] = kSegNone;
-    } else if (g.seg_status[k] != ZH_OK && g.seg_status[k] != ZH_ERR_DST_TOO_SMALL) {
+    } else if (failed(k)) {
       g.start_bit[k] = g.start2_bit[k];
       g.start2_bit[k] = kSegNone;
-      dropped++;
     }
   }
-  dropped = zh_wave_sum(dropped);
   if (lane == 0) g.repair[bid] = dropped ? 1u : 0u;
 }
 
@@ -882,10 +896,14 @@ extern "C" void zh_launch_seg_find(hipStream_t stream, const uint8_t* d_src, ZhI
 }
 extern "C" void zh_launch_seg_check(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g) {
   if (!g.nsegs || !g.nfind) return;
+#ifdef ZH_XCHECK  // (the test build: a thread instead of a wave per candidate, ZH_SEG_CHECK=serial)
   static const int serial = [] {
     const char* e = getenv("ZH_SEG_CHECK");
     return e && strcmp(e, "serial") == 0 ? 1 : 0;
   }();
+#else
+  const int serial = 0;
+#endif
   hipLaunchKernelGGL(zh_seg_check_kernel, dim3(g.nfind), dim3(64), 0, stream, d_src, a, g, serial);
 }
 // ZH_SEG_FAKE_START=<bit> (tests): bits that read like a block header and are none happen in any long stream's
@@ -915,6 +933,19 @@ extern "C" void zh_launch_seg_decide(hipStream_t stream, ZhInflateArgs a, ZhSegA
 extern "C" void zh_launch_seg_chain(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g, int rerun) {
   if (!g.nstreams) return;
   hipLaunchKernelGGL(zh_seg_chain_kernel, dim3(g.nstreams), dim3(64), 0, stream, a, g, rerun);
+}
+// zh_debug_segment_stats: streams that were cut into segments / whose chain held, counted where the answer is
+// (two device counters of the context; nothing of it on the host side of a run or of a result read)
+__global__ __launch_bounds__(64) void zh_seg_stats_kernel(ZhSegArgs g, unsigned long long* stats) {
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= g.nstreams || g.first_seg[i + 1u] <= g.first_seg[i]) return;
+  atomicAdd(&stats[0], 1ull);
+  if (g.stream_ok[i]) atomicAdd(&stats[1], 1ull);
+}
+extern "C" void zh_launch_seg_stats(hipStream_t stream, ZhSegArgs g, uint64_t* stats) {
+  if (!g.nstreams || !stats) return;
+  hipLaunchKernelGGL(zh_seg_stats_kernel, dim3((g.nstreams + 63u) / 64u), dim3(64), 0, stream, g,
+                     reinterpret_cast<unsigned long long*>(stats));
 }
 extern "C" void zh_launch_seg_repair(hipStream_t stream, ZhInflateArgs a, ZhSegArgs g) {
   if (!g.nstreams) return;

@@ -43,7 +43,9 @@ template <bool kLdsTable>
 __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restrict__ d_src,
                                                          ZhCompressArgs a, int huffman_only,
                                                          uint16_t* __restrict__ table_pool,
-                                                         uint32_t* __restrict__ next_frag) {
+                                                         uint32_t* __restrict__ next_frag,
+                                                         const uint32_t* __restrict__ order,
+                                                         uint32_t* __restrict__ cost) {
   __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
   // parse: 4096 byte-wide counters (4 per dword) of the probes per table slot in one step,
   // all zero between steps; afterwards the first 4 KiB are the coverage bitmap (bit p set:
@@ -62,7 +64,12 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   uint16_t* const s_table = kLdsTable ? s_table_lds : table_pool + (size_t)blockIdx.x * 16384u;
   // fragments are handed out first come, first served (`next_frag` starts at gridDim.x): they cost
   // very different amounts of time, and a fixed share per wave leaves the last ones running alone
-  for (uint32_t f = blockIdx.x; f < a.nfrags;) {
+  // ... and longest first from a plan's second run on: `order` (null: as numbered) is the fragments by what they cost
+  // the run before (`cost`: this run's, for the next; zh_launch_l1_match) -- the expensive ones no longer start
+  // last and run alone.  Which wave takes which fragment when decides nothing of what comes out.
+  for (uint32_t ticket = blockIdx.x; ticket < a.nfrags;) {
+  const uint32_t f = order ? order[ticket] : ticket;
+  const uint64_t t_start = zh_clock();
   KPROF_DECL(16);  // cycles: 0 stage-in, 1 vector part, 2 fast walk, 3 slow walk, 4 inserts, 5 stats; counts: 6..12
   const ZhFragDesc fd = a.frags[f];
   const uint32_t n = fd.len;
@@ -542,10 +549,51 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   zh_wave_sync();
   {
     uint32_t nf = 0;
-    if (lane == 0) nf = atomicAdd(next_frag, 1u);
-    f = zh_bcast(nf);
+    if (lane == 0) {
+      if (cost) {
+        const uint64_t dt = zh_clock() - t_start;
+        cost[f] = dt < 0xffffffffull ? (uint32_t)dt : 0xffffffffu;
+      }
+      nf = atomicAdd(next_frag, 1u);
+    }
+    ticket = zh_bcast(nf);
   }
   }  // next fragment of this wave
+}
+
+// ---- longest first: the fragments by the cycles they took the run before, in 64 classes (four an octave), the
+// dearest class first; inside a class as they come (three small launches in front of the matcher) ----
+namespace {
+constexpr uint32_t kCostClasses = 64;
+__device__ __forceinline__ uint32_t cost_class(uint32_t c) {  // 2^10 .. 2^26 cycles, a quarter octave a class
+  if (c < 1024u) return 0u;
+  const uint32_t lg = 31u - (uint32_t)__clz((int)c);
+  const uint32_t k = (lg - 10u) * 4u + ((c >> (lg - 2u)) & 3u);
+  return k < kCostClasses ? k : kCostClasses - 1u;
+}
+}  // namespace
+__global__ __launch_bounds__(256) void zh_l1_cost_hist_kernel(const uint32_t* __restrict__ cost, uint32_t n,
+                                                              uint32_t* __restrict__ hist) {
+  __shared__ uint32_t s_h[kCostClasses];
+  if (threadIdx.x < kCostClasses) s_h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) atomicAdd(&s_h[cost_class(cost[i])], 1u);
+  __syncthreads();
+  if (threadIdx.x < kCostClasses && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+// hist[k] (counts) -> hist[64 + k]: the first place of class k, the dearest class at place 0
+__global__ __launch_bounds__(64) void zh_l1_cost_scan_kernel(uint32_t* __restrict__ hist) {
+  const unsigned lane = zh_lane();
+  const uint32_t mine = hist[kCostClasses - 1u - lane];  // (lane 0: the dearest class)
+  const uint32_t incl = zh_wave_scan(mine);
+  hist[kCostClasses + (kCostClasses - 1u - lane)] = incl - mine;
+}
+__global__ __launch_bounds__(256) void zh_l1_cost_scatter_kernel(const uint32_t* __restrict__ cost, uint32_t n,
+                                                                 uint32_t* __restrict__ hist,
+                                                                 uint32_t* __restrict__ order) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) order[atomicAdd(&hist[kCostClasses + cost_class(cost[i])], 1u)] = i;
 }
 
 // waves that share the table pool: 20 per CU on 256 CUs, LDS 7.4 KiB each (ZH_L1_SLOTS: tuning override)
@@ -560,20 +608,36 @@ extern "C" uint32_t zh_l1_table_slots(void) {
 
 __global__ void zh_l1_set_counter_kernel(uint32_t* next_frag, uint32_t v) { *next_frag = v; }
 
+// `cost` / `order` / `hist` (each may be null): this run's cycles a fragment; the fragments longest first by LAST run's
+// (built here when `use_order`: the plan has run before); 128 words of scratch for that
 extern "C" void zh_launch_l1_match(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
-                                   int huffman_only, uint16_t* table_pool, uint32_t* next_frag) {
+                                   int huffman_only, uint16_t* table_pool, uint32_t* next_frag, uint32_t* cost,
+                                   uint32_t* order, uint32_t* hist, int use_order) {
   if (!a.nfrags) return;
+#ifdef ZH_XCHECK  // the test / measurement build only: the same kernel with its table in LDS (ZH_L1_TABLE=lds)
   static const bool lds = [] {
     const char* e = getenv("ZH_L1_TABLE");
     return e && strcmp(e, "lds") == 0;
   }();
-  const uint32_t slots = lds ? 1024u : zh_l1_table_slots();  // (39.4 KiB of LDS: four waves per CU)
-  const uint32_t grid = a.nfrags < slots ? a.nfrags : slots;
-  hipLaunchKernelGGL(zh_l1_set_counter_kernel, dim3(1), dim3(1), 0, stream, next_frag, grid);
-  if (lds)
+  if (lds) {
+    const uint32_t grid = a.nfrags < 1024u ? a.nfrags : 1024u;  // (39.4 KiB of LDS: four waves per CU)
+    hipLaunchKernelGGL(zh_l1_set_counter_kernel, dim3(1), dim3(1), 0, stream, next_frag, grid);
     hipLaunchKernelGGL(zh_l1_match_kernel<true>, dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
-                       table_pool, next_frag);
-  else
-    hipLaunchKernelGGL(zh_l1_match_kernel<false>, dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
-                       table_pool, next_frag);
+                       table_pool, next_frag, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    return;
+  }
+#endif
+  const uint32_t slots = zh_l1_table_slots();
+  const uint32_t grid = a.nfrags < slots ? a.nfrags : slots;
+  const bool sorted = use_order && cost && order && hist && a.nfrags > grid;  // (one round of the machine: nothing to order)
+  if (sorted) {
+    (void)hipMemsetAsync(hist, 0, 2u * kCostClasses * sizeof(uint32_t), stream);
+    const uint32_t g = (a.nfrags + 255u) / 256u;
+    hipLaunchKernelGGL(zh_l1_cost_hist_kernel, dim3(g), dim3(256), 0, stream, cost, a.nfrags, hist);
+    hipLaunchKernelGGL(zh_l1_cost_scan_kernel, dim3(1), dim3(64), 0, stream, hist);
+    hipLaunchKernelGGL(zh_l1_cost_scatter_kernel, dim3(g), dim3(256), 0, stream, cost, a.nfrags, hist, order);
+  }
+  hipLaunchKernelGGL(zh_l1_set_counter_kernel, dim3(1), dim3(1), 0, stream, next_frag, grid);
+  hipLaunchKernelGGL(zh_l1_match_kernel<false>, dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,
+                     table_pool, next_frag, sorted ? order : (const uint32_t*)nullptr, cost);
 }

@@ -134,6 +134,8 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
                                                           std::min<size_t>(nf, zh_l1p_slots()) * 131072)
                                                : 0);
   const size_t o_l1ctr = ar.reserve(256);
+  const bool l1 = level == 1 || level == -2;
+  const size_t o_l1cost = ar.reserve(l1 ? nf * 4 : 4), o_l1order = ar.reserve(l1 ? nf * 4 : 4), o_l1hist = ar.reserve(512);
   const size_t o_cprev = ar.reserve(chain ? range_frags * (size_t)ZH_FRAG_SIZE * 8 : 0);
   const size_t o_cbest = ar.reserve(chain ? range_frags * (size_t)ZH_FRAG_SIZE * 4 : 0);
   ar.reserve(256);
@@ -207,6 +209,11 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   p->head_scratch = carve<uint32_t>(base, o_head);
   p->l1_tables = carve<uint16_t>(base, o_l1tab);
   p->l1_counter = carve<uint32_t>(base, o_l1ctr);
+  if (l1) {
+    p->l1_cost = carve<uint32_t>(base, o_l1cost);
+    p->l1_order = carve<uint32_t>(base, o_l1order);
+    p->l1_hist = carve<uint32_t>(base, o_l1hist);
+  }
   p->chain_prev = carve<uint64_t>(base, o_cprev);
   p->chain_best = carve<uint32_t>(base, o_cbest);
   p->h_bufs.swap(bufs);

@@ -35,6 +35,16 @@ extern "C" int zh_plan_kernel_times(zh_plan* p, const char** names, float* ms, i
     ms[cnt] = t;
     cnt++;
   }
+  if (p->k_aux_used) {  // the checksum kernels of a compress run, timed on the second stream (beside "zh_huffman_kernel")
+    static const char* const aux_names[2] = {"zh_checksum_pieces_kernel", "zh_checksum_combine_kernel"};
+    for (int k = 0; k < 2 && cnt < max_entries; k++) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, p->k_aux[k], p->k_aux[k + 1]) != hipSuccess) break;
+      names[cnt] = aux_names[k];
+      ms[cnt] = t;
+      cnt++;
+    }
+  }
   return cnt;
 }
 
@@ -51,6 +61,8 @@ extern "C" void zh_plan_destroy(zh_plan* p) {
   if (p->sg_winsym) ctx_free(p->ctx, p->sg_winsym);
   if (p->unpack_lens) ctx_free(p->ctx, p->unpack_lens);
   for (auto e : p->k_events) (void)hipEventDestroy(e);
+  for (auto e : p->k_aux)
+    if (e) (void)hipEventDestroy(e);
   delete p;
 }
 
@@ -64,6 +76,33 @@ bool inflate_split_enabled(const zh_ctx* ctx) {
     return !(e && strcmp(e, "serial") == 0);
   }();
   return ctx->inflate_mode < 0 ? on : ctx->inflate_mode == 0;
+}
+// The context's second stream and its two events, made when first asked for; ZH_CHECKSUM_ASIDE=0 keeps a compress run's
+// checksum kernels in line on the context's stream (measurement).  Anything that fails leaves them in line as well.
+static bool checksum_aside(zh_ctx* ctx) {
+  static const bool on = [] {
+    const char* e = getenv("ZH_CHECKSUM_ASIDE");
+    return !(e && strcmp(e, "0") == 0);
+  }();
+  if (!on) return false;
+  if (!ctx->aux_stream) {
+    if (hipStreamCreate(&ctx->aux_stream) != hipSuccess) {
+      ctx->aux_stream = nullptr;
+      (void)hipGetLastError();
+      return false;
+    }
+  }
+  if (!ctx->aux_fork && hipEventCreate(&ctx->aux_fork) != hipSuccess) ctx->aux_fork = nullptr;
+  if (!ctx->aux_join && hipEventCreate(&ctx->aux_join) != hipSuccess) ctx->aux_join = nullptr;
+  return ctx->aux_fork && ctx->aux_join;
+}
+// ZH_L1_ORDER=0: fragments as numbered in every run (measurement: what a plan's first run costs)
+static bool l1_longest_first() {
+  static const bool on = [] {
+    const char* e = getenv("ZH_L1_ORDER");
+    return !(e && strcmp(e, "0") == 0);
+  }();
+  return on;
 }
 // BestSpeed parse: 0 the reference's (snappy.nim:12-136, byte-identical streams), 1 the parallel
 // parse of zh_l1p_match.hip (valid streams of about the same size, not the reference's bytes)
@@ -247,7 +286,10 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       zh_launch_l1p_match(s, d_src, a, p->l1_tables, p->l1_counter);
     } else if (p->level == 1 || p->level == -2) {
       prof_mark(p, "zh_l1_match_kernel");
-      zh_launch_l1_match(s, d_src, a, p->level == -2, p->l1_tables, p->l1_counter);
+      // (from the second run on the fragments are handed out longest first, by what they cost the run before)
+      zh_launch_l1_match(s, d_src, a, p->level == -2, p->l1_tables, p->l1_counter, p->l1_cost, p->l1_order, p->l1_hist,
+                         p->l1_runs > 0 && l1_longest_first());
+      p->l1_runs++;
     } else if (p->level != 0) {
       const int* cfg = kChainConfig[p->level == -1 ? 6 : p->level];
       if (p->chain_best_dirty)
@@ -260,10 +302,10 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
         ar.first_frag = r.f0;
         ar.nfrags = r.nf;
         prof_mark(p, "zh_chain_prev_kernel");
-        zh_launch_chain_prev(s, d_src, ar, p->head_scratch, p->chain_prev, p->chain_best);
+        zh_launch_chain_prev(s, d_src, ar, p->head_scratch, p->chain_prev, p->chain_best, p->ctx->chain_links_serial ? 1 : 0);
         ZH_HIP(ctx, hipGetLastError());
         prof_mark(p, "zh_chain_walk_kernel");
-        zh_launch_chain_search(s, d_src, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+        zh_launch_chain_search(s, d_src, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best, p->ctx->chain_links_serial ? 1 : 0);
         prof_mark(p, "zh_chain_select_kernel");
         zh_launch_chain_select(s, d_src, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
         ZH_HIP(ctx, hipGetLastError());
@@ -272,18 +314,48 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       prof_mark(p, "zh_frag_stats_kernel");
       zh_launch_frag_stats(s, d_src, a);
     }
+    // The checksum of the source and the blocks' code builder need nothing from each other and wait for different
+    // things -- the one for the LDS (its table look-ups) on every CU, the other, a lane a block, for its own chain of
+    // dependent instructions --: side by side, the checksum on the context's second stream, forked behind the match
+    // finder (beside THAT it only costs) and joined in front of the layout, which writes the trailer.
+    p->k_aux_used = false;
     if (want_crc || want_adler) {
-      prof_mark(p, "zh_checksum_pieces_kernel");
-      zh_launch_checksum_pieces(s, ctx->cktabs, d_src, p->d_pieces, p->npieces, nullptr, want_crc,
+      hipStream_t cs = s;
+      const bool aside = checksum_aside(ctx);
+      if (aside) {
+        cs = ctx->aux_stream;
+        ZH_HIP(ctx, hipEventRecord(ctx->aux_fork, s));
+        ZH_HIP(ctx, hipStreamWaitEvent(cs, ctx->aux_fork, 0));
+        if (p->profiling) {
+          for (hipEvent_t& e : p->k_aux)
+            if (!e && hipEventCreate(&e) != hipSuccess) p->profiling = false;
+          if (p->profiling) {
+            ZH_HIP(ctx, hipEventRecord(p->k_aux[0], cs));
+            p->k_aux_used = true;
+          }
+        }
+      } else {
+        prof_mark(p, "zh_checksum_pieces_kernel");
+      }
+      zh_launch_checksum_pieces(cs, ctx->cktabs, d_src, p->d_pieces, p->npieces, nullptr, want_crc,
                                 want_adler, p->piece_crc, p->piece_adler, p->piece_len);
-      prof_mark(p, "zh_checksum_combine_kernel");
-      zh_launch_checksum_combine(s, p->d_bufs, (uint32_t)p->n, p->piece_crc, p->piece_adler,
+      if (!aside) prof_mark(p, "zh_checksum_combine_kernel");
+      else if (p->k_aux_used) ZH_HIP(ctx, hipEventRecord(p->k_aux[1], cs));
+      zh_launch_checksum_combine(cs, p->d_bufs, (uint32_t)p->n, p->piece_crc, p->piece_adler,
                                  p->piece_len, want_crc, want_adler, p->buf_crc, p->buf_adler);
+      if (aside) {
+        if (p->k_aux_used) ZH_HIP(ctx, hipEventRecord(p->k_aux[2], cs));
+        ZH_HIP(ctx, hipEventRecord(ctx->aux_join, cs));
+      }
+      prof_mark(p, "zh_huffman_kernel");
+      zh_launch_huffman(s, a, p->level == 1 && l1_parallel(ctx) ? 1 : 0);
+      if (aside) ZH_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_join, 0));
+    } else {
+      prof_mark(p, "zh_huffman_kernel");
+      // (contract mode -- zh_set_l1_parse(ctx, 1), BestSpeed only -- also builds the block's codes without the
+      // replay of the reference's heap: optimal codes, other tie-breaks)
+      zh_launch_huffman(s, a, p->level == 1 && l1_parallel(ctx) ? 1 : 0);
     }
-    prof_mark(p, "zh_huffman_kernel");
-    // (contract mode -- zh_set_l1_parse(ctx, 1), BestSpeed only -- also builds the block's codes without the
-    // replay of the reference's heap: optimal codes, other tie-breaks)
-    zh_launch_huffman(s, a, p->level == 1 && l1_parallel(ctx) ? 1 : 0);
     prof_mark(p, "zh_layout_kernel");
     zh_launch_layout(s, d_dst, a, p->buf_crc, p->buf_adler);
     prof_mark(p, "zh_emit_kernel");
@@ -304,7 +376,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       zh_launch_seg_find(s, d_src, a, p->sg);
       prof_mark(p, "zh_seg_check_kernel");
       zh_launch_seg_check(s, d_src, a, p->sg);
-      if (const char* e = getenv("ZH_SEG_FAKE_START")) zh_launch_seg_fake_start(s, p->sg, strtoull(e, nullptr, 10));
+      if (p->sg_fake_start != ~0ull) zh_launch_seg_fake_start(s, p->sg, p->sg_fake_start);
       prof_mark(p, "zh_seg_substart_kernel");
       zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 0);
       zh_launch_seg_decide(s, a, p->sg, 0);
@@ -321,8 +393,15 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
         zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 5);
         zh_launch_seg_chain(s, a, p->sg, 1);
       }
-      p->seg_ran = true;
-      if (getenv("ZH_TRACE_SEG")) seg_trace(p, s);
+      if (!ctx->d_seg_stats) {
+        void* q = nullptr;
+        if (ctx_malloc(ctx, &q, 16) == hipSuccess) {
+          ctx->d_seg_stats = static_cast<uint64_t*>(q);
+          ZH_HIP(ctx, hipMemsetAsync(q, 0, 16, s));
+        }
+      }
+      zh_launch_seg_stats(s, p->sg, ctx->d_seg_stats);
+      if (p->sg_trace) seg_trace(p, s);
       if (!a.count_only) {
         prof_mark(p, "zh_seg_write_kernel");
         zh_launch_seg_write(s, d_src, a, p->tok_pool, p->sg);
@@ -388,24 +467,18 @@ extern "C" int zh_plan_results(zh_plan* p, uint64_t* out_lens, int32_t* statuses
   if (out_lens) ZH_HIP(ctx, hipMemcpyAsync(out_lens, p->out_len, p->n * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (statuses) ZH_HIP(ctx, hipMemcpyAsync(statuses, p->status, p->n * 4, hipMemcpyDeviceToHost, ctx->stream));
   ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (!p->is_compress && p->segmented && p->seg_ran) {  // zh_debug_segment_stats
-    p->seg_ran = false;
-    const ZhSegArgs& g = p->sg;
-    std::vector<uint32_t> first(g.nstreams + 1), ok(g.nstreams);
-    ZH_HIP(ctx, hipMemcpy(first.data(), g.first_seg, first.size() * 4, hipMemcpyDeviceToHost));
-    ZH_HIP(ctx, hipMemcpy(ok.data(), g.stream_ok, ok.size() * 4, hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < g.nstreams; i++)
-      if (first[i + 1] > first[i]) {
-        ctx->seg_cut++;
-        ctx->seg_held += ok[i] != 0;
-      }
-  }
   return ZH_OK;
 }
 extern "C" int zh_debug_segment_stats(zh_ctx* ctx, uint64_t* cut, uint64_t* held) {
   if (!ctx) return ZH_ERR_ARGUMENT;
-  if (cut) *cut = ctx->seg_cut;
-  if (held) *held = ctx->seg_held;
+  uint64_t h[2] = {0, 0};
+  if (ctx->d_seg_stats) {
+    ZH_HIP(ctx, hipSetDevice(ctx->device));
+    ZH_HIP(ctx, hipMemcpyAsync(h, ctx->d_seg_stats, 16, hipMemcpyDeviceToHost, ctx->stream));
+    ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (cut) *cut = h[0];
+  if (held) *held = h[1];
   return ZH_OK;
 }
 extern "C" int zh_plan_request_crc32(zh_plan* p, int on) {

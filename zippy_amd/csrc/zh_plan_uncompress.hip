@@ -28,6 +28,9 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   zh_ctx* ctx = p->ctx;
   const size_t n = bufs.size();
   if (!c.on || !n || n > c.max_streams) return;
+  // test aids, read here and not on the run path: a found start that is none planted at a stream bit, the chain's story
+  if (const char* e = getenv("ZH_SEG_FAKE_START")) p->sg_fake_start = strtoull(e, nullptr, 10);
+  p->sg_trace = getenv("ZH_TRACE_SEG") != nullptr;
   // the large streams of the batch are cut into segments, the others have none (and take the
   // ordinary kernels, like every stream whose chain of segments does not hold)
   auto large = [&](const ZhBufDesc& b) {
@@ -91,7 +94,7 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
                o_wlen = ar.reserve(ns * 8), o_valid = ar.reserve(ns * 4), o_prev = ar.reserve(ns * 4),
                o_ostart = ar.reserve(ns * 8), o_sok = ar.reserve(n * 4), o_order = ar.reserve(ns * 4),
                o_nchain = ar.reserve(n * 4), o_repair = ar.reserve(n * 4), o_ordinal = ar.reserve(ns * 4), o_go = ar.reserve(n * 4), o_etoff = ar.reserve(ns * 8), o_etcap = ar.reserve(ns * 8), o_substart = ar.reserve(ns * 8), o_subhdr = ar.reserve(ns * 8),
-               o_issub = ar.reserve(ns * 4);
+               o_issub = ar.reserve(ns * 4), o_held = ar.reserve(ns * 8);
   const size_t nfind = find_seg.size();
   const size_t o_fseg = ar.reserve(nfind * 4), o_fbatch = ar.reserve(nfind * 4), o_cn = ar.reserve(nfind * 4),
                o_coff = ar.reserve(nfind * (size_t)kSegFindSlots * 4);
@@ -154,6 +157,7 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   g.sub_start = carve<uint64_t>(base, o_substart);
   g.sub_hdr = carve<uint64_t>(base, o_subhdr);
   g.is_sub = carve<uint32_t>(base, o_issub);
+  g.held_start = carve<uint64_t>(base, o_held);
   g.nfind = (uint32_t)nfind;
   g.find_seg = carve<uint32_t>(base, o_fseg);
   g.find_batch = carve<uint32_t>(base, o_fbatch);
