@@ -149,18 +149,28 @@ def cpu_baseline(bufs, level, cores, reps=8):
         return out
 
     one = leg(bufs[:max(1, min(len(bufs), (8 << 20) // max(1, len(bufs[0]))))], 1)
-    # every logical CPU, and -- where there are enough of them to be SMT siblings and for memory bandwidth to
-    # matter -- half, a quarter, an eighth as many: the best of them is the baseline
-    legs = {cores: leg(bufs, cores)}
-    t = cores // 2
-    while t >= 32 and len(legs) < 4:  # (256 logical CPUs: 256, 128, 64, 32 threads)
-        legs[t] = leg(bufs, t)
-        t //= 2
+    # What the lease allows, not what the box shows: a cgroup CPU quota (cpu.max) caps the CPU time of ALL threads
+    # together -- 256 logical CPUs behind a quota of 16 run 16 threads' worth -- so the thread counts tried are the
+    # quota and twice it (threads that wait for memory leave quota to their siblings).  Without a quota: every CPU
+    # the process may run on, and -- where there are enough of them to be SMT siblings and for memory bandwidth to
+    # matter -- half, a quarter, an eighth as many.  The best of them is the baseline.
+    host = host_cpu_info()
+    quota = host.get("cgroup_cpu_quota_cpus")
+    if quota and quota < cores:
+        q = max(1, int(math.ceil(quota)))
+        legs = {t: leg(bufs, t) for t in sorted({q, min(cores, 2 * q)})}
+    else:
+        legs = {cores: leg(bufs, cores)}
+        t = cores // 2
+        while t >= 32 and len(legs) < 4:  # (256 logical CPUs: 256, 128, 64, 32 threads)
+            legs[t] = leg(bufs, t)
+            t //= 2
     best = max(legs, key=lambda t: legs[t]["oracle"]["both_GiBps_at_avg"])
     many = legs[best]
     one_v = one["oracle"]["both_GiBps_at_avg"]
     return {
-        "host": host_cpu_info(),
+        "host": host,
+        "cpu_time_limit": ("cgroup quota: %.4g CPUs of %d logical" % (quota, cores)) if quota and quota < cores else None,
         # the harness's scaling, thread count by thread count: x one thread (compress, uncompress, both)
         "speedup_over_1_thread": {str(t): [round(v["oracle"]["compress"]["GiBps_at_avg"] / one["oracle"]["compress"]["GiBps_at_avg"], 1),
                                            round(v["oracle"]["uncompress"]["GiBps_at_avg"] / one["oracle"]["uncompress"]["GiBps_at_avg"], 1),
@@ -863,9 +873,11 @@ def main():
                 out["configs"]["c4_share"]["cpu_baseline_level_-1"] = cpu_level_leg(
                     [host[i].tobytes() for i in range(min(n, max(32, out["cpu_baseline"]["cores"])))], -1,
                     out["cpu_baseline"]["cores"])
-                g = out["configs"]["c4_share"]
-                g["cpu_baseline_level_-1"]["gpu_ratio_vs_cpu_ratio"] = round(
-                    g["ratio"] / g["cpu_baseline_level_-1"]["ratio"], 5)
+                # (the device's streams ARE the oracle's at this level -- parity_sample above --, so "ratio vs CPU
+                # zippy" is 1 stream for stream; the entry's own ratio is over all of the share's buffers, this one
+                # over the sample's)
+                out["configs"]["c4_share"]["cpu_baseline_level_-1"]["device_vs_cpu_size"] = (
+                    "identical streams" if out["configs"]["c4_share"].get("parity_sample", {}).get("identical") else None)
         out["host_gen_s"] = round(t_gen, 1)
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -5,6 +5,7 @@ under the CPU emulator).  `eng` is a zippy_amd._binding.Engine; the oracle
 import hashlib
 import os
 import random
+import struct
 import zlib
 
 import numpy as np
@@ -735,7 +736,7 @@ def check_plan_slots_with_gaps(eng, upload, download, alloc):
 
 def check_plan_reruns(eng, upload, download, alloc, n, size):
     """A compress plan run three times (zh_l1_match.hip: from the second run on the BestSpeed matcher's waves take the
-    fragments longest first, by what they cost the run before -- more fragments than waves here, so the order is a
+    cheapest fragments -- by what they cost the run before -- last; more fragments than waves here, so the order is a
     real one): every run's streams are the oracle's, byte for byte."""
     bufs = [b.tobytes() for b in synth.gen_batch("mix", n, size)]
     d_src, keep_src = upload(b"".join(bufs) + b"\0" * 16)
@@ -917,6 +918,66 @@ def check_split_inflate_edges(eng):
         fmt = oracle.dfZlib if (blob[0] & 0x0f) == 8 and (blob[0] * 256 + blob[1]) % 31 == 0 else oracle.dfDeflate
         got, st = eng.uncompress_batch([blob], fmt)
         assert st == [0] and got[0] == want, (len(blob), fmt, st)
+
+
+def stored_chain_streams(nblocks=70):
+    """Streams of stored blocks (inflate.nim:252-266), the kind incompressible data makes -- one of 65 535 bytes after
+    the other (deflate.nim:186-199) --, for the chain reader of the tokens kernel (64 headers at once) and the
+    writer's grouped copy: whole chains of more than 64 blocks, a short last block, an empty one, chains broken by a
+    compressed block, by a short block in the middle, and damaged ones (a length that does not match its complement
+    in the middle of a chain, a chain that runs past the input).  -> [(raw deflate, plain or None)]"""
+    rnd = random.Random(4711)
+    noise = rnd.randbytes(nblocks * 65535 + 12345)
+
+    def stored(data, final, size=65535):
+        out = []
+        chunks = [data[o:o + size] for o in range(0, len(data), size)] or [b""]
+        for k, c in enumerate(chunks):
+            out.append(bytes([1 if final and k == len(chunks) - 1 else 0]) + struct.pack("<HH", len(c), len(c) ^ 0xffff) + c)
+        return b"".join(out)
+    text = synth.corpus_file("alice29.txt")[:50000]
+    dyn = zlib.compressobj(6, zlib.DEFLATED, -15)
+    dyn_block = dyn.compress(text) + dyn.flush(zlib.Z_FULL_FLUSH)  # (ends byte-aligned with an empty stored block, not final)
+    out = []
+    out.append((stored(noise, True), noise))                                        # the oracle's own shape at level 0
+    out.append((oracle.compress(noise, 0, oracle.dfDeflate), noise))
+    out.append((oracle.compress(noise[:200000], 1, oracle.dfDeflate), noise[:200000]))  # incompressible at level 1: stored
+    out.append((stored(noise[:65535 * 64], True), noise[:65535 * 64]))              # exactly 64 full blocks, the last final
+    out.append((stored(noise[:65535 * 65], False) + stored(b"", True), noise[:65535 * 65]))  # an empty final block behind the chain
+    out.append((stored(noise[:65535 * 3], False) + dyn_block + stored(noise[:65535 * 70 + 5], True),
+                noise[:65535 * 3] + text + noise[:65535 * 70 + 5]))
+    out.append((stored(noise[:65535 * 5], False) + stored(noise[:1000], False, 1000) + stored(noise[:65535 * 66], True),
+                noise[:65535 * 5] + noise[:1000] + noise[:65535 * 66]))
+    out.append((stored(noise[:300000], True, 30000), noise[:300000]))               # no full block at all
+    good = stored(noise[:65535 * 40], True)
+    bad = bytearray(good)
+    bad[17 * 65540 + 3] ^= 0x40                                                     # block 17: NLEN no longer the complement
+    out.append((bytes(bad), None))
+    out.append((good[:-30000], None))                                               # the last block runs past the input
+    bad = bytearray(good)
+    bad[9 * 65540] |= 0x06                                                          # block 9: BTYPE 3
+    out.append((bytes(bad), None))
+    return out
+
+
+def check_stored_chains(eng, nblocks=70):
+    """The streams above through the device decoder: bytes where they are sound (and through zlib, the referee), the
+    oracle's accept / reject decision where they are not; and with an output slot that is too small the status a
+    caller grows its buffer on, not another."""
+    cases = stored_chain_streams(nblocks)
+    outs, sts = eng.uncompress_batch([c[0] for c in cases], oracle.dfDeflate)
+    for (blob, want), got, st in zip(cases, outs, sts):
+        try:
+            ref = oracle.uncompress(blob, oracle.dfDeflate)
+        except oracle.ZippyError:
+            ref = None
+        assert ref == want, "the oracle disagrees with the test's expectation"
+        assert (st == 0) == (want is not None), (len(blob), st)
+        if want is not None:
+            assert got == want and zlib.decompress(blob, -15) == want
+    one = [cases[0][0]]  # (a batch of one: the wide kernels)
+    got, st = eng.uncompress_batch(one, oracle.dfDeflate)
+    assert st == [0] and got[0] == cases[0][1]
 
 
 def segmented_streams(scale):

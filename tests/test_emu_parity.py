@@ -287,7 +287,7 @@ def test_emu_plan_slots_with_gaps(eng):
     pc.check_plan_slots_with_gaps(eng, upload, lambda keep: keep.raw, alloc)
 
 
-def test_emu_plan_reruns_longest_first(eng):
+def test_emu_plan_reruns_cheapest_last(eng):
     import ctypes
     def upload(b):
         buf = ctypes.create_string_buffer(b, len(b))
@@ -307,6 +307,10 @@ def test_emu_plan_pack(eng):
         buf = ctypes.create_string_buffer(bytes([fill]) * n, n)
         return ctypes.addressof(buf), buf
     pc.check_plan_pack(eng, upload, lambda keep: keep.raw, alloc)
+
+
+def test_emu_stored_chains(eng, inflate_mode):
+    pc.check_stored_chains(eng)
 
 
 def test_emu_split_inflate_edges(eng, inflate_mode):

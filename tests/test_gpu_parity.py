@@ -420,7 +420,7 @@ def test_gpu_plan_slots_with_gaps(eng):
     pc.check_plan_slots_with_gaps(eng, upload, lambda t: t.cpu().numpy().tobytes(), alloc)
 
 
-def test_gpu_plan_reruns_longest_first(eng):
+def test_gpu_plan_reruns_cheapest_last(eng):
     import torch
     def upload(b):
         t = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
@@ -440,6 +440,10 @@ def test_gpu_plan_pack(eng):
         t = torch.full((n,), fill, dtype=torch.uint8, device="cuda")
         return t.data_ptr(), t
     pc.check_plan_pack(eng, upload, lambda t: t.cpu().numpy().tobytes(), alloc)
+
+
+def test_gpu_stored_chains(eng, inflate_mode):
+    pc.check_stored_chains(eng, 200)
 
 
 def test_gpu_split_inflate_edges(eng, inflate_mode):
@@ -473,3 +477,9 @@ def test_gpu_one_gib_stream_decodes_segment_wise():
     res = gpu_big_buffer.run(1024, level=1, with_oracle=False, with_zlib=False)
     assert res["trailer_ok"] and res["decoded_segment_wise"], res
     assert max(res["uncompress_s"][1:]) < 0.5, res  # (20 ms on an MI355X; one workgroup takes 2 s)
+    # the kinds that have no block starts to find: 1 GiB of random bytes is 16 K stored blocks, which one workgroup takes
+    # 64 headers and eight blocks' bytes at a time (193 ms with a header and a block a round); literals only (level -2)
+    rand = gpu_big_buffer.run(1024, level=1, with_oracle=False, with_zlib=False, kind="rand")
+    assert rand["trailer_ok"] and min(rand["uncompress_s"]) < 0.1, rand
+    lits = gpu_big_buffer.run(1024, level=-2, with_oracle=False, with_zlib=False)
+    assert lits["trailer_ok"] and min(lits["uncompress_s"]) < 0.2, lits

@@ -47,6 +47,9 @@
 #ifndef ZH_SUBBITS
 #define ZH_SUBBITS 512
 #endif
+#ifndef ZH_TOK_OCC
+#define ZH_TOK_OCC 5  // workgroups a CU of the tokens kernel's 256-thread form (4: 8.03 ms, 5: 7.26 ms for 4096 x 1 MiB of own streams)
+#endif
 #ifndef ZH_SERIAL_HEADER
 #define ZH_SERIAL_HEADER 0  // 1: the code lengths of every dynamic header by the serial reader (cross-check, measurement)
 #endif
@@ -106,7 +109,7 @@ struct RunResult {
 // block the segment's search found, stops at the first block boundary at or behind the next found
 // start, and reports where that was, how many bytes its tokens make and whether the stream ended.
 template <uint32_t kSplitThreads, bool kSeg>
-__global__ __launch_bounds__(kSplitThreads, kSplitThreads <= 256 ? 4 : 1) void zh_inflate_tokens_kernel(const uint8_t* __restrict__ d_src,
+__global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : kSplitThreads < 256 ? 4 : 1) void zh_inflate_tokens_kernel(const uint8_t* __restrict__ d_src,
                                                                 ZhInflateArgs a,
                                                                 uint32_t* __restrict__ tok_pool,
                                                                 const uint64_t* __restrict__ tok_off,
@@ -115,7 +118,8 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads <= 256 ? 4 : 1) void z
   constexpr uint32_t kSuperBits = kSplitThreads * kSubBits;
   constexpr uint32_t kStageWords = (kSplitThreads + 1u) * kSubStride;
   constexpr uint32_t kWaves = kSplitThreads / 64u;
-  constexpr uint32_t kMapGroup = kSplitThreads >= 256u ? 64u : 16u;  // subchunks mapped per all-starts pass
+  // subchunks mapped per all-starts pass (the map is what decides how many workgroups a CU's LDS holds)
+  constexpr uint32_t kMapGroup = kSplitThreads == 256u && ZH_TOK_OCC > 4 ? 48u : kSplitThreads >= 256u ? 64u : 16u;
   __shared__ uint32_t s_lit[(1u << kLitBits) + kLitSub];
   __shared__ uint32_t s_dst[(1u << kDistBits) + kDistSub];  // also hosts the 7-bit code-length table
   __shared__ uint32_t s_in[kStageWords];
@@ -691,6 +695,70 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads <= 256 ? 4 : 1) void z
         out_bytes += len;
       }
       pos = (byte_pos + len) * 8;
+      // Stored blocks come in chains -- incompressible data is one of 65 535 bytes after the other, 16 K of them a
+      // GiB (deflate.nim:186-199), each a header read with the whole workgroup waiting at three barriers --, and
+      // behind a stored block the next header is byte-aligned: wave 0 reads 64 of them at once, lane k where the
+      // k-th would be if all before it were full, and keeps the lanes up to the first that is not a full block of a
+      // chain that goes on (anything that is not a clean stored block is left to the header reader above, which
+      // knows the reference's error for it).  One record a block, as before.  (Not in segment mode: a decoder
+      // there has to stop at the found starts it lands on.)
+      if (!kSeg && len == ZH_STORED_MAX && !final_block) {
+        for (;;) {
+          if (tid < 64u) {
+            const uint64_t o = (pos >> 3) + (uint64_t)lane * (ZH_STORED_MAX + 5u);  // (from asrc)
+            const uint32_t w0 = load_dword(o & ~(uint64_t)3), w1 = load_dword((o & ~(uint64_t)3) + 4u),
+                           w2 = load_dword((o & ~(uint64_t)3) + 8u);
+            const uint32_t sh = (uint32_t)(o & 3u) * 8u;
+            const uint64_t five = (((uint64_t)zh_alignbit(w2, w1, sh) << 32) | zh_alignbit(w1, w0, sh)) & 0xffffffffffull;
+            const uint32_t h = (uint32_t)five & 0xffu, blen = (uint32_t)(five >> 8) & 0xffffu, nlen = (uint32_t)(five >> 24) & 0xffffu;
+            const bool ok = o + 5u <= end && ((h >> 1) & 3u) == 0u && blen + nlen == 65535u && o + 5u + blen <= end;
+            const bool full = ok && blen == ZH_STORED_MAX && !(h & 1u);
+            const uint64_t fulls = __ballot(full);
+            const uint32_t m = ~fulls ? (uint32_t)__builtin_ctzll(~fulls) : 64u;  // lanes 0 .. m - 1: full blocks of the chain
+            const bool tail_ok = m < 64u && ((__ballot(ok) >> m) & 1ull);         // lane m: a last, shorter or final one
+            uint32_t cnt = m + (tail_ok ? 1u : 0u);
+            // records: the blocks that still fit the region (the check a block had: ntok + 3 + 1 <= cap), none for an
+            // empty block
+            const uint32_t tail_len = (uint32_t)__shfl((int)blen, (int)(m < 64u ? m : 0u), 64);
+            const uint32_t nrec = cnt - (tail_ok && tail_len == 0u ? 1u : 0u);
+            const uint64_t room = cap > ntok + 4u ? (cap - ntok - 4u) / 3u + 1u : (cap == ntok + 4u ? 1u : 0u);
+            const bool over = nrec > room;
+            const uint32_t nfit = over ? (uint32_t)room : nrec;
+            if (lane < nfit) {
+              const uint64_t off = o + 5u - mis;
+              tok[ntok + 3u * lane] = kRecSpecial | kRecStored | (blen << 16);
+              tok[ntok + 3u * lane + 1u] = (uint32_t)off;
+              tok[ntok + 3u * lane + 2u] = (uint32_t)(off >> 32);
+            }
+            if (over) cnt = nfit;  // (the stream ends here: ZH_ERR_DST_TOO_SMALL)
+            if (lane == 0) {
+              const uint32_t lastl = cnt ? cnt - 1u : 0u;
+              s_c_stored_len = cnt;                                       // blocks taken
+              s_c_term = over ? 1u : 0u;
+              s_c_endrel = nfit;                                          // records written
+            }
+            if (cnt && lane == cnt - 1u) {
+              s_c_pos = (o + 5u + blen) * 8u;                             // behind the last block taken
+              s_c_final = h & 1u;
+            }
+          }
+          __syncthreads();
+          const uint32_t took = s_c_stored_len, nrec = s_c_endrel;
+          const bool over = s_c_term != 0u;
+          if (took) {
+            pos = s_c_pos;
+            if (s_c_final) final_block = true;
+          }
+          ntok += 3u * nrec;
+          __syncthreads();  // (the control words are read: the next round, or the header reader, may write them)
+          if (over) {
+            st = ZH_ERR_DST_TOO_SMALL;
+            break;
+          }
+          if (took < 64u || final_block) break;  // (a block that is not a full one of the chain: the ordinary way)
+        }
+        if (st != ZH_OK) break;
+      }
       continue;
     }
 
@@ -1084,16 +1152,100 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
       const uint32_t q0 = s_tok[(uint32_t)ti & (kWrRing - 1u)];
       if (q0 & kRecSpecial) {
         if ((q0 & (3u << 11)) == kRecStored) {  // inflate.nim:252-266: raw bytes
-          const uint32_t length = q0 >> 16;
-          const uint64_t off = (uint64_t)s_tok[(uint32_t)(ti + 1u) & (kWrRing - 1u)] |
-                               ((uint64_t)s_tok[(uint32_t)(ti + 2u) & (kWrRing - 1u)] << 32);
-          if (op + length > cap) {
-            st = ZH_ERR_DST_TOO_SMALL;
-            break;
+          if (kSeg) {
+            const uint32_t length = q0 >> 16;
+            const uint64_t off = (uint64_t)s_tok[(uint32_t)(ti + 1u) & (kWrRing - 1u)] |
+                                 ((uint64_t)s_tok[(uint32_t)(ti + 2u) & (kWrRing - 1u)] << 32);
+            if (op + length > cap) {
+              st = ZH_ERR_DST_TOO_SMALL;
+              break;
+            }
+            for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = (Sym)src[off + i];
+            op += length;
+            ti += 3;
+          } else {
+            // Stored blocks come in chains (incompressible data: 16 K of them a GiB): up to eight records at a time,
+            // their bytes sixteen at a time with eight loads of a thread in flight before the first store -- not a
+            // round of this loop, with its scans and barriers, a block, and not a byte a thread and trip.
+            struct __attribute__((packed)) V16 { uint32_t w[4]; };
+            constexpr uint32_t kGroup = 8, kFly = 8;
+            bool bad = false;
+            for (;;) {
+              // (every array below is indexed by unrolled constants only: registers, not scratch)
+              uint64_t goff[kGroup], gpre[kGroup];   // a record's source offset; the group's bytes before it
+              uint32_t glen[kGroup], gch[kGroup + 1], ng = 0;  // its length; the group's whole pieces before it
+              uint64_t gtotal = 0;
+              bool open = true;
+              gch[0] = 0;
+#pragma unroll
+              for (uint32_t k = 0; k < kGroup; k++) {
+                goff[k] = 0;
+                gpre[k] = gtotal;
+                glen[k] = 0;
+                gch[k + 1] = gch[k];
+                if (open && ti + 3u * (k + 1u) <= hi) {
+                  const uint32_t q = s_tok[(uint32_t)(ti + 3u * k) & (kWrRing - 1u)];
+                  const uint32_t length = q >> 16;
+                  if ((q & (kRecSpecial | (3u << 11))) != (kRecSpecial | kRecStored)) {
+                    open = false;
+                  } else if (op + gtotal + length > cap) {
+                    bad = k == 0;  // (the first of a group: this is where the stream ends)
+                    open = false;
+                  } else {
+                    glen[k] = length;
+                    goff[k] = (uint64_t)s_tok[(uint32_t)(ti + 3u * k + 1u) & (kWrRing - 1u)] |
+                              ((uint64_t)s_tok[(uint32_t)(ti + 3u * k + 2u) & (kWrRing - 1u)] << 32);
+                    gch[k + 1] = gch[k] + (length >> 4);
+                    gtotal += length;
+                    ng = k + 1u;
+                  }
+                } else {
+                  open = false;
+                }
+              }
+              if (!ng) break;
+              // whole 16-byte pieces, numbered through the group; the bytes behind a record's last whole piece one by one
+              for (uint32_t base = 0; base < gch[kGroup]; base += kWrThreads * kFly) {
+                V16 v[kFly];
+                uint64_t at[kFly];
+#pragma unroll
+                for (uint32_t u = 0; u < kFly; u++) {
+                  const uint32_t e = base + u * kWrThreads + tid;
+                  uint32_t rch = 0;
+                  uint64_t roff = goff[0], rpre = 0;
+#pragma unroll
+                  for (uint32_t k = 1; k < kGroup; k++)
+                    if (k < ng && e >= gch[k]) {
+                      rch = gch[k];
+                      roff = goff[k];
+                      rpre = gpre[k];
+                    }
+                  const bool live = e < gch[kGroup];
+                  at[u] = live ? op + rpre + (uint64_t)(e - rch) * 16u : ~0ull;
+                  v[u] = *reinterpret_cast<const V16*>(src + (live ? roff + (uint64_t)(e - rch) * 16u : goff[0]));
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kFly; u++)
+                  if (at[u] != ~0ull) *reinterpret_cast<V16*>(dst + at[u]) = v[u];
+              }
+#pragma unroll
+              for (uint32_t k = 0; k < kGroup; k++) {
+                const uint32_t done = glen[k] & ~15u;
+                if (k < ng && tid < (glen[k] & 15u)) dst[op + gpre[k] + done + tid] = src[goff[k] + done + tid];
+              }
+              op += gtotal;
+              ti += 3u * ng;
+              if (hi < ti + kWrRecs + 128u) {
+                commit_ahead();
+                fetch_ahead();
+              }
+              __syncthreads();
+            }
+            if (bad) {
+              st = ZH_ERR_DST_TOO_SMALL;
+              break;
+            }
           }
-          for (uint32_t i = tid; i < length; i += kWrThreads) dst[op + i] = (Sym)src[off + i];
-          op += length;
-          ti += 3;
           output_visible();
           continue;
         }

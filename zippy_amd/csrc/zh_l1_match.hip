@@ -64,9 +64,10 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   uint16_t* const s_table = kLdsTable ? s_table_lds : table_pool + (size_t)blockIdx.x * 16384u;
   // fragments are handed out first come, first served (`next_frag` starts at gridDim.x): they cost
   // very different amounts of time, and a fixed share per wave leaves the last ones running alone
-  // ... and longest first from a plan's second run on: `order` (null: as numbered) is the fragments by what they cost
-  // the run before (`cost`: this run's, for the next; zh_launch_l1_match) -- the expensive ones no longer start
-  // last and run alone.  Which wave takes which fragment when decides nothing of what comes out.
+  // ... and from a plan's second run on the cheapest ones last: `order` (null: as numbered) is the fragments as numbered
+  // but for the cheapest two rounds' worth, which go to the end -- by what they cost the run before (`cost`: this
+  // run's, for the next; zh_launch_l1_match) --, so that what is still running when waves fall idle is short.  Which
+  // wave takes which fragment when decides nothing of what comes out.
   for (uint32_t ticket = blockIdx.x; ticket < a.nfrags;) {
   const uint32_t f = order ? order[ticket] : ticket;
   const uint64_t t_start = zh_clock();
@@ -561,8 +562,13 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   }  // next fragment of this wave
 }
 
-// ---- longest first: the fragments by the cycles they took the run before, in 64 classes (four an octave), the
-// dearest class first; inside a class as they come (three small launches in front of the matcher) ----
+// ---- the cheap ones last: from a plan's second run on the fragments are handed out as numbered -- the mix of kinds
+// the batch came with keeps the fabric evenly loaded: all of them sorted by cost, dearest first, measured 2.7 %
+// SLOWER on 4096 x 1 MiB (the dear ones are the ones with the most table traffic, and they would all run together)
+// -- EXCEPT that the cheapest ~ 2 rounds' worth go to the end, so that what runs last, with waves already idle,
+// is short.  Costs: the cycles a fragment took the run before, in 64 classes (four an octave); the cheapest classes
+// that together hold at most `tail` fragments form the tail; both parts keep their order (a stable partition: flags,
+// a two-level scan, a scatter -- four small launches in front of the matcher). ----
 namespace {
 constexpr uint32_t kCostClasses = 64;
 __device__ __forceinline__ uint32_t cost_class(uint32_t c) {  // 2^10 .. 2^26 cycles, a quarter octave a class
@@ -572,6 +578,7 @@ __device__ __forceinline__ uint32_t cost_class(uint32_t c) {  // 2^10 .. 2^26 cy
   return k < kCostClasses ? k : kCostClasses - 1u;
 }
 }  // namespace
+// hist[0 .. 64): fragments a class
 __global__ __launch_bounds__(256) void zh_l1_cost_hist_kernel(const uint32_t* __restrict__ cost, uint32_t n,
                                                               uint32_t* __restrict__ hist) {
   __shared__ uint32_t s_h[kCostClasses];
@@ -582,18 +589,72 @@ __global__ __launch_bounds__(256) void zh_l1_cost_hist_kernel(const uint32_t* __
   __syncthreads();
   if (threadIdx.x < kCostClasses && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
 }
-// hist[k] (counts) -> hist[64 + k]: the first place of class k, the dearest class at place 0
-__global__ __launch_bounds__(64) void zh_l1_cost_scan_kernel(uint32_t* __restrict__ hist) {
+// few rounds: ALL fragments by class, the dearest class first (inside a class as they come): hist[k] -> hist[64 + k], the
+// first place of class k; then the scatter
+__global__ __launch_bounds__(64) void zh_l1_cost_places_kernel(uint32_t* __restrict__ hist) {
   const unsigned lane = zh_lane();
   const uint32_t mine = hist[kCostClasses - 1u - lane];  // (lane 0: the dearest class)
   const uint32_t incl = zh_wave_scan(mine);
   hist[kCostClasses + (kCostClasses - 1u - lane)] = incl - mine;
 }
-__global__ __launch_bounds__(256) void zh_l1_cost_scatter_kernel(const uint32_t* __restrict__ cost, uint32_t n,
-                                                                 uint32_t* __restrict__ hist,
-                                                                 uint32_t* __restrict__ order) {
+__global__ __launch_bounds__(256) void zh_l1_cost_sort_kernel(const uint32_t* __restrict__ cost, uint32_t n,
+                                                              uint32_t* __restrict__ hist, uint32_t* __restrict__ order) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < n) order[atomicAdd(&hist[kCostClasses + cost_class(cost[i])], 1u)] = i;
+}
+// -> hist[64]: the highest class of the tail (classes 0 .. hist[64] hold at most `tail` fragments; 0xffffffff: none),
+// hist[65]: how many fragments that is.  Then the tail flags a block of 256 fragments, counted: blk[b].
+__global__ __launch_bounds__(64) void zh_l1_cost_cut_kernel(uint32_t* __restrict__ hist, uint32_t tail) {
+  const unsigned lane = zh_lane();
+  const uint32_t incl = zh_wave_scan(hist[lane]);
+  const uint64_t fits = __ballot(incl <= tail);  // (a prefix of the lanes: the sums grow)
+  const uint32_t k = (uint32_t)__popcll(fits);
+  if (lane == 0) hist[kCostClasses] = k ? k - 1u : 0xffffffffu;
+  if (lane == (k ? k - 1u : 0u)) hist[kCostClasses + 1u] = k ? incl : 0u;
+}
+__global__ __launch_bounds__(256) void zh_l1_cost_count_kernel(const uint32_t* __restrict__ cost, uint32_t n,
+                                                               const uint32_t* __restrict__ hist,
+                                                               uint32_t* __restrict__ blk) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x, cut = hist[kCostClasses];
+  const bool last = i < n && cut != 0xffffffffu && cost_class(cost[i]) <= cut;
+  const uint32_t c = (uint32_t)__popcll(__ballot(last));
+  __shared__ uint32_t s_c[4];
+  if (zh_lane() == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+// blk[b] -> the tail fragments before block b (one workgroup, 1024 blocks a turn)
+__global__ __launch_bounds__(1024) void zh_l1_cost_scan_kernel(uint32_t* __restrict__ blk, uint32_t nblk) {
+  __shared__ uint32_t s_w[16], s_carry;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nblk; base += 1024u) {
+    const uint32_t i = base + tid, v = i < nblk ? blk[i] : 0u;
+    const uint32_t incl = zh_wave_scan(v);
+    if (zh_lane() == 63) s_w[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = s_carry;
+    for (uint32_t w = 0; w < (tid >> 6); w++) before += s_w[w];
+    if (i < nblk) blk[i] = before + incl - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = before + incl;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void zh_l1_cost_scatter_kernel(const uint32_t* __restrict__ cost, uint32_t n,
+                                                                 const uint32_t* __restrict__ hist,
+                                                                 const uint32_t* __restrict__ blk,
+                                                                 uint32_t* __restrict__ order) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x, cut = hist[kCostClasses], ntail = hist[kCostClasses + 1u];
+  const bool last = i < n && cut != 0xffffffffu && cost_class(cost[i]) <= cut;
+  const uint64_t m = __ballot(last);
+  __shared__ uint32_t s_c[4];
+  if (zh_lane() == 0) s_c[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t before = blk[blockIdx.x] + (uint32_t)__popcll(m & zh_lanemask_lt());  // tail fragments before this one
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += s_c[w];
+  if (i < n) order[last ? (n - ntail) + before : i - before] = i;
 }
 
 // waves that share the table pool: 20 per CU on 256 CUs, LDS 7.4 KiB each (ZH_L1_SLOTS: tuning override)
@@ -608,8 +669,8 @@ extern "C" uint32_t zh_l1_table_slots(void) {
 
 __global__ void zh_l1_set_counter_kernel(uint32_t* next_frag, uint32_t v) { *next_frag = v; }
 
-// `cost` / `order` / `hist` (each may be null): this run's cycles a fragment; the fragments longest first by LAST run's
-// (built here when `use_order`: the plan has run before); 128 words of scratch for that
+// `cost` / `order` / `hist` (each may be null): this run's cycles a fragment; the order made of LAST run's (built here
+// when `use_order`: the plan has run before); 128 words + a word a 256 fragments of scratch for that
 extern "C" void zh_launch_l1_match(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
                                    int huffman_only, uint16_t* table_pool, uint32_t* next_frag, uint32_t* cost,
                                    uint32_t* order, uint32_t* hist, int use_order) {
@@ -631,11 +692,29 @@ extern "C" void zh_launch_l1_match(hipStream_t stream, const uint8_t* d_src, ZhC
   const uint32_t grid = a.nfrags < slots ? a.nfrags : slots;
   const bool sorted = use_order && cost && order && hist && a.nfrags > grid;  // (one round of the machine: nothing to order)
   if (sorted) {
-    (void)hipMemsetAsync(hist, 0, 2u * kCostClasses * sizeof(uint32_t), stream);
     const uint32_t g = (a.nfrags + 255u) / 256u;
+    static const uint32_t rounds = [] {  // (ZH_L1_TAIL_ROUNDS: measurement)
+      const char* e = getenv("ZH_L1_TAIL_ROUNDS");
+      const long v = e ? atol(e) : 0;
+      return v >= 1 && v <= 64 ? (uint32_t)v : 2u;
+    }();
+    const uint32_t tail = a.nfrags / 2u < rounds * grid ? a.nfrags / 2u : rounds * grid;  // two rounds' worth, half of all at most
+    uint32_t* blk = hist + 128;  // (hist: 128 words + a word a block of 256 fragments)
+    (void)hipMemsetAsync(hist, 0, 128u * sizeof(uint32_t), stream);
     hipLaunchKernelGGL(zh_l1_cost_hist_kernel, dim3(g), dim3(256), 0, stream, cost, a.nfrags, hist);
-    hipLaunchKernelGGL(zh_l1_cost_scan_kernel, dim3(1), dim3(64), 0, stream, hist);
-    hipLaunchKernelGGL(zh_l1_cost_scatter_kernel, dim3(g), dim3(256), 0, stream, cost, a.nfrags, hist, order);
+    if (a.nfrags < 8u * grid) {
+      // a few rounds of the machine (one GPU's share of eight: 3.2): the dearest first -- what starts last then is
+      // short (512 x 1 MiB: 9.41 -> 8.97 ms, against 9.33 with only the cheapest moved)
+      hipLaunchKernelGGL(zh_l1_cost_places_kernel, dim3(1), dim3(64), 0, stream, hist);
+      hipLaunchKernelGGL(zh_l1_cost_sort_kernel, dim3(g), dim3(256), 0, stream, cost, a.nfrags, hist, order);
+    } else {
+      // many rounds (4096 x 1 MiB: 25.6): the order the batch came in, the cheapest two rounds' worth last (65.57 ->
+      // 65.22 ms; all of them sorted: 66.4, see above)
+      hipLaunchKernelGGL(zh_l1_cost_cut_kernel, dim3(1), dim3(64), 0, stream, hist, tail);
+      hipLaunchKernelGGL(zh_l1_cost_count_kernel, dim3(g), dim3(256), 0, stream, cost, a.nfrags, hist, blk);
+      hipLaunchKernelGGL(zh_l1_cost_scan_kernel, dim3(1), dim3(1024), 0, stream, blk, g);
+      hipLaunchKernelGGL(zh_l1_cost_scatter_kernel, dim3(g), dim3(256), 0, stream, cost, a.nfrags, hist, blk, order);
+    }
   }
   hipLaunchKernelGGL(zh_l1_set_counter_kernel, dim3(1), dim3(1), 0, stream, next_frag, grid);
   hipLaunchKernelGGL(zh_l1_match_kernel<false>, dim3(grid), dim3(64), 0, stream, d_src, a, huffman_only,

@@ -135,7 +135,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
                                                : 0);
   const size_t o_l1ctr = ar.reserve(256);
   const bool l1 = level == 1 || level == -2;
-  const size_t o_l1cost = ar.reserve(l1 ? nf * 4 : 4), o_l1order = ar.reserve(l1 ? nf * 4 : 4), o_l1hist = ar.reserve(512);
+  const size_t o_l1cost = ar.reserve(l1 ? nf * 4 : 4), o_l1order = ar.reserve(l1 ? nf * 4 : 4), o_l1hist = ar.reserve(512 + (l1 ? (nf / 256 + 2) * 4 : 0));
   const size_t o_cprev = ar.reserve(chain ? range_frags * (size_t)ZH_FRAG_SIZE * 8 : 0);
   const size_t o_cbest = ar.reserve(chain ? range_frags * (size_t)ZH_FRAG_SIZE * 4 : 0);
   ar.reserve(256);

@@ -286,7 +286,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       zh_launch_l1p_match(s, d_src, a, p->l1_tables, p->l1_counter);
     } else if (p->level == 1 || p->level == -2) {
       prof_mark(p, "zh_l1_match_kernel");
-      // (from the second run on the fragments are handed out longest first, by what they cost the run before)
+      // (from the second run on the cheapest fragments -- by what they cost the run before -- are handed out last)
       zh_launch_l1_match(s, d_src, a, p->level == -2, p->l1_tables, p->l1_counter, p->l1_cost, p->l1_order, p->l1_hist,
                          p->l1_runs > 0 && l1_longest_first());
       p->l1_runs++;
