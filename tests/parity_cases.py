@@ -980,6 +980,33 @@ def check_stored_chains(eng, nblocks=70):
     assert st == [0] and got[0] == cases[0][1]
 
 
+def check_stored_chain_segmented(eng, monkeypatch, nblocks=70):
+    """A chain of full stored blocks in the MIDDLE of a stream that is decoded segment-wise (zh_inflate_seg.hip): the
+    segments inside the chain have no block start, the decoder before them reads the chain 64 headers a step and has to
+    stop where the next segment's found start is -- the compressed blocks behind the chain."""
+    monkeypatch.setenv("ZH_SEG_MIN", "65536")
+    monkeypatch.setenv("ZH_SEG_BYTES", "16384")
+    monkeypatch.setenv("ZH_SEG_SETUP", "0")
+    rnd = random.Random(99)
+    noise = rnd.randbytes(nblocks * 65535)
+    text = synth.gen_batch("text", 1, 600000, first_index=3)[0].tobytes()
+
+    def dyn(data, last):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        return c.compress(data) + (c.flush() if last else c.flush(zlib.Z_FULL_FLUSH))
+    stored = b"".join(bytes([0]) + struct.pack("<HH", 65535, 0) + noise[o:o + 65535] for o in range(0, len(noise), 65535))
+    for blob, want in ((dyn(text, False) + stored + dyn(text[::-1], True), text + noise + text[::-1]),
+                       (stored + dyn(text, True), noise + text)):
+        assert zlib.decompress(blob, -15) == want
+        before = eng.segment_stats()
+        outs, sts = eng.uncompress_batch([blob], oracle.dfDeflate)
+        assert sts == [0] and outs[0] == want
+        cut, held = eng.segment_stats()
+        assert cut - before[0] == 1, "the stream was not cut into segments"
+    for k in ("ZH_SEG_MIN", "ZH_SEG_BYTES", "ZH_SEG_SETUP"):
+        monkeypatch.delenv(k)
+
+
 def segmented_streams(scale):
     """Foreign streams for the segment-wise decoder (zh_inflate_seg.hip): many blocks each, the
     kinds of block boundaries it has to cope with.  -> [(blob, format, plain)]"""

@@ -313,6 +313,10 @@ def test_emu_stored_chains(eng, inflate_mode):
     pc.check_stored_chains(eng)
 
 
+def test_emu_stored_chain_segmented(eng, monkeypatch):
+    pc.check_stored_chain_segmented(eng, monkeypatch)
+
+
 def test_emu_split_inflate_edges(eng, inflate_mode):
     pc.check_split_inflate_edges(eng)
 

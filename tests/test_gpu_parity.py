@@ -446,6 +446,10 @@ def test_gpu_stored_chains(eng, inflate_mode):
     pc.check_stored_chains(eng, 200)
 
 
+def test_gpu_stored_chain_segmented(eng, monkeypatch):
+    pc.check_stored_chain_segmented(eng, monkeypatch, 300)
+
+
 def test_gpu_split_inflate_edges(eng, inflate_mode):
     pc.check_split_inflate_edges(eng)
 

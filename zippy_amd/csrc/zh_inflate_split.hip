@@ -700,10 +700,18 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
       // behind a stored block the next header is byte-aligned: wave 0 reads 64 of them at once, lane k where the
       // k-th would be if all before it were full, and keeps the lanes up to the first that is not a full block of a
       // chain that goes on (anything that is not a clean stored block is left to the header reader above, which
-      // knows the reference's error for it).  One record a block, as before.  (Not in segment mode: a decoder
-      // there has to stop at the found starts it lands on.)
-      if (!kSeg && len == ZH_STORED_MAX && !final_block) {
+      // knows the reference's error for it).  One record a block, as before.  In segment mode a decoder stops at the
+      // found start it lands on: a step goes no further than the next one (a found start inside a block's bytes is a
+      // wrong guess and is run past with the block).
+      if (len == ZH_STORED_MAX && !final_block) {
         for (;;) {
+          uint64_t seg_stop = ~0ull;  // (stream bit: the chain takes no block that starts at or behind it)
+          if (kSeg) {
+            const uint64_t rel = pos - (uint64_t)mis * 8;
+            next_start(rel);
+            if (seg_target == rel && !g.is_sub[seg_tj]) break;  // (the loop above hands over to that segment's decoder)
+            if (seg_tj < seg_last && seg_target != kSegNone && seg_target > rel) seg_stop = seg_target;
+          }
           if (tid < 64u) {
             const uint64_t o = (pos >> 3) + (uint64_t)lane * (ZH_STORED_MAX + 5u);  // (from asrc)
             const uint32_t w0 = load_dword(o & ~(uint64_t)3), w1 = load_dword((o & ~(uint64_t)3) + 4u),
@@ -711,7 +719,8 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
             const uint32_t sh = (uint32_t)(o & 3u) * 8u;
             const uint64_t five = (((uint64_t)zh_alignbit(w2, w1, sh) << 32) | zh_alignbit(w1, w0, sh)) & 0xffffffffffull;
             const uint32_t h = (uint32_t)five & 0xffu, blen = (uint32_t)(five >> 8) & 0xffffu, nlen = (uint32_t)(five >> 24) & 0xffffu;
-            const bool ok = o + 5u <= end && ((h >> 1) & 3u) == 0u && blen + nlen == 65535u && o + 5u + blen <= end;
+            const bool ok = o + 5u <= end && ((h >> 1) & 3u) == 0u && blen + nlen == 65535u && o + 5u + blen <= end &&
+                            (!kSeg || (o - mis) * 8u < seg_stop);
             const bool full = ok && blen == ZH_STORED_MAX && !(h & 1u);
             const uint64_t fulls = __ballot(full);
             const uint32_t m = ~fulls ? (uint32_t)__builtin_ctzll(~fulls) : 64u;  // lanes 0 .. m - 1: full blocks of the chain
@@ -741,8 +750,13 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
               s_c_pos = (o + 5u + blen) * 8u;                             // behind the last block taken
               s_c_final = h & 1u;
             }
+            if (kSeg) {  // the bytes the records make (blocks 0 .. nfit - 1; an empty last one adds nothing)
+              const uint32_t made = zh_wave_sum(lane < nfit ? blen : 0u);
+              if (lane == 0) s_wbytes[0] = made;
+            }
           }
           __syncthreads();
+          if (kSeg) out_bytes += s_wbytes[0];
           const uint32_t took = s_c_stored_len, nrec = s_c_endrel;
           const bool over = s_c_term != 0u;
           if (took) {
@@ -1001,7 +1015,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
 // workgroup is writing at the same time -- 0x8000 | its index in that window.  Copies of symbols are
 // copies whatever the symbol is; zh_seg_windows_kernel / zh_seg_finish_kernel turn them into bytes.
 template <uint32_t kWrThreads, bool kSeg, uint32_t kB>
-__global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThreads == 512 ? 2 : 1) void zh_inflate_write_kernel(const uint8_t* __restrict__ d_src,
+__global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThreads == 512 ? 4 : 1) void zh_inflate_write_kernel(const uint8_t* __restrict__ d_src,
                                                                uint8_t* __restrict__ d_dst, ZhInflateArgs a,
                                                                const uint32_t* __restrict__ tok_pool,
                                                                const uint64_t* __restrict__ tok_off,
@@ -1164,11 +1178,14 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
             op += length;
             ti += 3;
           } else {
-            // Stored blocks come in chains (incompressible data: 16 K of them a GiB): up to eight records at a time,
-            // their bytes sixteen at a time with eight loads of a thread in flight before the first store -- not a
+            // Stored blocks come in chains (incompressible data: 16 K of them a GiB): up to four records at a time,
+            // their bytes sixteen at a time with four or eight loads of a thread in flight before the first store -- not a
             // round of this loop, with its scans and barriers, a block, and not a byte a thread and trip.
             struct __attribute__((packed)) V16 { uint32_t w[4]; };
-            constexpr uint32_t kGroup = 8, kFly = 8;
+            // (kept small: what this path holds in registers must not cost the rounds above theirs -- with eight records
+            // and eight loads the 256-thread form spilt inside its round, 12.2 -> 13.7 ms on the bench batch, and the
+            // 512-thread form lost a workgroup a CU)
+            constexpr uint32_t kGroup = 4, kFly = kWrThreads >= 1024u ? 8u : 4u;
             bool bad = false;
             for (;;) {
               // (every array below is indexed by unrolled constants only: registers, not scratch)
