@@ -207,7 +207,7 @@ def cpu_level_leg(sample, level, threads, reps=3):
                 len(sample), len(sample[0]), level, reps)}
 
 
-def hbm_traffic(workload="headline"):
+def hbm_traffic(workload="headline", field="hbm_bytes_per_launch"):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
     (tools/prof/pmc_passes.sh -> tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE runs of the command
     behind every workload -- the headline step and BASELINE configs 2-5 --, units and gfx950 corrections as the
@@ -218,7 +218,7 @@ def hbm_traffic(workload="headline"):
         with open(path) as fh:
             t = json.load(fh)
         if t.get("source_sha") == source_sha():
-            return {k: v["hbm_bytes_per_launch"] for k, v in t["workloads"][workload]["kernels"].items()}
+            return {k: v[field] for k, v in t["workloads"][workload]["kernels"].items()}
     except (OSError, KeyError, ValueError):
         pass
     return {}
@@ -312,6 +312,9 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
              "frac": round(own.get(dom, nbytes + comp_bytes) / (kms[dom] * 1e-3) / HBM_PEAK, 6),
              # measured HBM bytes a launch of that kernel (profiles/hbm_traffic.json, this workload's own PMC passes)
              "traffic": (hbm_traffic(pmc_key).get(dom) or 0) * nl or None if pmc_key and full_size else None,
+             # (the same as FETCH_SIZE + WRITE_SIZE report it: a 128-byte request tallied at 64)
+             "traffic_raw": (hbm_traffic(pmc_key, "hbm_bytes_per_launch_uncorrected").get(dom) or 0) * nl or None
+             if pmc_key and full_size else None,
              "kernels_ms": {k: round(v, 4) for k, v in sorted(kms.items(), key=lambda kv: -kv[1]) if k != "end"}}
         if tc and tu:
             e["compress_GiBps"] = round(nbytes / GIB / (tc * 1e-3), 3)
@@ -778,6 +781,8 @@ def main():
         N, C = n * size, comp_total
         own = own_bytes(N, C)
         traffic = hbm_traffic("headline") if (n, size, args.level) == (4096, 1 << 20, 1) and args.foreign is None else {}
+        traffic_raw = (hbm_traffic("headline", "hbm_bytes_per_launch_uncorrected")
+                       if (n, size, args.level) == (4096, 1 << 20, 1) and args.foreign is None else {})
 
         def roof(nbytes, ms, name=None, nl=None):
             """nbytes / ms: of all launches of the kernel in a step together; reported a launch (`nl` of them), like the
@@ -787,6 +792,7 @@ def main():
             r = {"bound": "hbm", "achieved": round(a / 1e9, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                  "frac": round(a / HBM_PEAK, 6), "frac_of_copy_peak": round(a / HBM_COPY_PEAK, 6),
                  "traffic": traffic.get(name) if name else None,
+                 "traffic_raw": traffic_raw.get(name) if name else None,
                  "algorithmic_bytes_per_launch": nbytes // nl, "avg_launch_ms": round(ms / nl, 4), "launches_per_step": nl}
             if name:
                 r["kernel"] = name
@@ -828,6 +834,10 @@ def main():
             "roofline_kernels": {k: roof(b * (launches.get(k, 1) if k.startswith("zh_checksum") else 1), avg[k], k)
                                  for k, b in own.items() if k in avg},
             "source_sha": source_sha(),
+            "traffic_note": "bytes a launch across the L2's memory side (Infinity Cache hits included: not all of it reaches HBM), "
+                            "read requests counted by size (gfx950: 128-byte requests almost only, whatever a lane asked for) + "
+                            "WRITE_SIZE; traffic_raw: FETCH_SIZE + WRITE_SIZE as rocprofv3 reports them (profiles/hbm_traffic.json, "
+                            "tools/pmc_traffic.py)",
             "parity_sample": parity_sample,
         }
         if do_c:

@@ -11,12 +11,18 @@ export TMPDIR=/tmp
 # the PMC passes first: profiles/hbm_traffic.json has to be there (with these sources' hash) for the bench lines to quote it
 bash tools/prof/pmc_passes.sh > $O/${T}_pmc.log 2>&1   # -> gpurun_out/hbm_traffic.json: the headline and configs 2-5, a pair of PMC passes each
 mkdir -p profiles && cp $O/hbm_traffic.json profiles/hbm_traffic.json
+# scheduler / L2 counters per kernel (SQ_*, TCC_*: valu busy, lane utilisation, waits, L2 hit rate, requests by size)
+bash tools/prof/pmc_sq.sh ${T} 1024 > $O/${T}_pmc_sq.log 2>&1
 timeout 1200 python -m pytest tests -m gpu -q > $O/${T}_pytest_gpu.log 2>&1
 timeout 900 python bench.py --steps 10 --warmup 2 2>$O/${T}_bench.err | tail -1 > $O/${T}_bench.json
 timeout 600 python bench.py --level -1 --compress-only --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_c4.json
 timeout 300 python bench.py --buffers 512 --level -1 --compress-only --steps 5 --warmup 1 --no-cpu-baseline --no-configs --no-parallel-parse 2>/dev/null | tail -1 > $O/${T}_c4share.json
 # one GPU's share of the batch when eight GPUs split it (strong scaling, 512 x 1 MiB)
 timeout 300 python bench.py --buffers 512 --steps 10 --warmup 2 --no-cpu-baseline --no-configs 2>/dev/null | tail -1 > $O/${T}_share512.json
+# the same two steps with the fragments as numbered in every run (ZH_L1_ORDER=0): what a plan's FIRST run costs, before
+# the matcher knows what its fragments cost (the lines above are steady state: the plans have run before)
+ZH_L1_ORDER=0 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-parallel-parse --no-parity-sample 2>/dev/null | tail -1 > $O/${T}_bench_first_run_order.json
+ZH_L1_ORDER=0 timeout 300 python bench.py --buffers 512 --steps 10 --warmup 2 --no-cpu-baseline --no-configs --no-parallel-parse --no-parity-sample 2>/dev/null | tail -1 > $O/${T}_share512_first_run_order.json
 timeout 300 python tools/bench_host_api.py --reps 2 2>/dev/null | tail -1 > $O/${T}_host_api.json
 timeout 300 python tools/bench_host_api.py --reps 2 --buffers 4096 2>/dev/null | tail -1 > $O/${T}_host_api_4096.json
 timeout 300 python tools/bench_single_call.py 2>/dev/null | tail -1 > $O/${T}_single_call.json

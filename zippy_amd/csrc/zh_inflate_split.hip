@@ -1179,13 +1179,13 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
             ti += 3;
           } else {
             // Stored blocks come in chains (incompressible data: 16 K of them a GiB): up to four records at a time,
-            // their bytes sixteen at a time with four or eight loads of a thread in flight before the first store -- not a
+            // their bytes sixteen at a time with four (one stream a workgroup: sixteen) loads of a thread in flight before the first store -- not a
             // round of this loop, with its scans and barriers, a block, and not a byte a thread and trip.
             struct __attribute__((packed)) V16 { uint32_t w[4]; };
             // (kept small: what this path holds in registers must not cost the rounds above theirs -- with eight records
             // and eight loads the 256-thread form spilt inside its round, 12.2 -> 13.7 ms on the bench batch, and the
             // 512-thread form lost a workgroup a CU)
-            constexpr uint32_t kGroup = 4, kFly = kWrThreads >= 1024u ? 8u : 4u;
+            constexpr uint32_t kGroup = 4, kFly = kWrThreads >= 1024u ? 16u : 4u;
             bool bad = false;
             for (;;) {
               // (every array below is indexed by unrolled constants only: registers, not scratch)
@@ -1222,28 +1222,29 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
               }
               if (!ng) break;
               // whole 16-byte pieces, numbered through the group; the bytes behind a record's last whole piece one by one
+              // piece e of the group -> where it comes from (`to` false) or goes (true); ~0: none
+              auto piece = [&](uint32_t e, bool to) -> uint64_t {
+                uint32_t rch = 0;
+                uint64_t roff = goff[0], rpre = 0;
+#pragma unroll
+                for (uint32_t k = 1; k < kGroup; k++)
+                  if (k < ng && e >= gch[k]) {
+                    rch = gch[k];
+                    roff = goff[k];
+                    rpre = gpre[k];
+                  }
+                if (e >= gch[kGroup]) return to ? ~0ull : goff[0];
+                return (to ? op + rpre : roff) + (uint64_t)(e - rch) * 16u;
+              };
               for (uint32_t base = 0; base < gch[kGroup]; base += kWrThreads * kFly) {
                 V16 v[kFly];
-                uint64_t at[kFly];
+#pragma unroll
+                for (uint32_t u = 0; u < kFly; u++) v[u] = *reinterpret_cast<const V16*>(src + piece(base + u * kWrThreads + tid, false));
 #pragma unroll
                 for (uint32_t u = 0; u < kFly; u++) {
-                  const uint32_t e = base + u * kWrThreads + tid;
-                  uint32_t rch = 0;
-                  uint64_t roff = goff[0], rpre = 0;
-#pragma unroll
-                  for (uint32_t k = 1; k < kGroup; k++)
-                    if (k < ng && e >= gch[k]) {
-                      rch = gch[k];
-                      roff = goff[k];
-                      rpre = gpre[k];
-                    }
-                  const bool live = e < gch[kGroup];
-                  at[u] = live ? op + rpre + (uint64_t)(e - rch) * 16u : ~0ull;
-                  v[u] = *reinterpret_cast<const V16*>(src + (live ? roff + (uint64_t)(e - rch) * 16u : goff[0]));
+                  const uint64_t at = piece(base + u * kWrThreads + tid, true);
+                  if (at != ~0ull) *reinterpret_cast<V16*>(dst + at) = v[u];
                 }
-#pragma unroll
-                for (uint32_t u = 0; u < kFly; u++)
-                  if (at[u] != ~0ull) *reinterpret_cast<V16*>(dst + at[u]) = v[u];
               }
 #pragma unroll
               for (uint32_t k = 0; k < kGroup; k++) {
