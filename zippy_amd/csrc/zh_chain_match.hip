@@ -30,6 +30,7 @@
 #include <cstring>
 
 #include <atomic>
+#include <type_traits>
 #include "zh_common.h"
 #include "zh_tables.h"
 
@@ -47,6 +48,22 @@ __device__ inline uint32_t load32u(const uint8_t* p) {
   __builtin_memcpy(&v, p, 4);
   return v;
 }
+// NARROW link records (round 5): 32 bits a position -- the 16-bit link and a 16-bit tag of the position's first FIVE
+// bytes -- instead of 64 (the link and six bytes).  The searches are bound by the lines their gathers pull through
+// the fabric (128 bytes a miss for one record: profiles/r05_*_pmc_sq.txt), and a line of narrow records holds 32
+// positions instead of 16.  What a tag can decide is "this candidate matches fewer than five bytes" (tags differ),
+// which is all the search needs to know of such a candidate where `good` >= 5 (levels 5-9 and -1: a match of up to
+// four bytes neither cuts `tries`, nor reaches `nice`, nor is returned, lz77.nim:104-114; it only raises a
+// longest_len that stays below every length that matters); a candidate whose tag agrees is compared byte for byte
+// against the source, as a candidate whose six bytes agree always was.  Levels 2-4 (`good` = 4: a match of exactly
+// four bytes cuts `tries`) and the in-order link kernels keep the wide records.
+__device__ __forceinline__ uint32_t zh_chain_tag(uint64_t first8) {  // (32-bit arithmetic: two multiplies, not a 64-bit one)
+  return ((uint32_t)first8 * 0x9e3779b1u + ((uint32_t)(first8 >> 32) & 0xffu) * 0x85ebca6bu) >> 16;
+}
+template <bool kNarrow>
+struct ChainRec {
+  typedef typename std::conditional<kNarrow, uint32_t, uint64_t>::type T;
+};
 }  // namespace
 
 // ---- 1. previous same-hash window position of every inserted position ----
@@ -217,6 +234,12 @@ __global__ __launch_bounds__(64) void zh_chain_prev_ldst_kernel(const uint8_t* _
 // Scratch of a block: `cls` = per unit of kUnit positions the class counts (then: where the unit's
 // positions of a class go), followed by the classes' starts and sizes; the sorted positions themselves
 // borrow the block's part of best[] (cleared afterwards, before the walks, anyway).
+#ifndef ZH_CHAIN_LINK_TURNS
+#define ZH_CHAIN_LINK_TURNS 3
+#endif
+#ifndef ZH_CHAIN_CHUNK
+#define ZH_CHAIN_CHUNK 32  // positions a walk starts at the first of
+#endif
 #ifndef ZH_CHAIN_CLASS_BITS
 #define ZH_CHAIN_CLASS_BITS 5
 #endif
@@ -305,6 +328,7 @@ __global__ __launch_bounds__(512) void zh_chain_class_scan_kernel(ZhCompressArgs
 // is ONE LDS atomic: positions grow along the list and the lanes of an LDS atomic are served in ascending order,
 // so atomicMax hands every lane what the slot held just before it -- the previous position of equal hash, be
 // it an earlier lane of the step or an earlier step -- and leaves the step's last one there.
+template <bool kNarrow>
 __global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
                                                                   const uint32_t* __restrict__ cls_scratch,
                                                                   uint32_t* __restrict__ lists,
@@ -325,7 +349,8 @@ __global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t*
   if (!n) return;
   uint32_t* list_rw = lists + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE + cls[kClsInfo + c];
   const uint32_t* list = list_rw;
-  uint64_t* pw = prevw + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
+  typedef typename ChainRec<kNarrow>::T Rec;
+  Rec* pw = reinterpret_cast<Rec*>(prevw) + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   for (uint32_t i = lane; i < kSlots; i += 64) s_head[i] = 0;
   zh_wave_sync();
   // the eight bytes at a listed position (zeros behind the block's end); every load is unconditional
@@ -369,7 +394,8 @@ __global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t*
       const uint32_t i = base0 + 64u * k + lane;
       const uint32_t link = old[k] ? (old[k] - 1u) & 32767u : 0u;
       if (i < n) {
-        pw[P[k]] = (uint64_t)link | ((w8[k] & 0xffffffffffffull) << 16);
+        if (kNarrow) pw[P[k]] = (Rec)(link | (zh_chain_tag(w8[k]) << 16));
+        else pw[P[k]] = (Rec)((uint64_t)link | ((w8[k] & 0xffffffffffffull) << 16));
         list_rw[i] = 0;  // best[] goes back the way the walks expect it: nothing worked out
       }
     }
@@ -379,17 +405,21 @@ __global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t*
 // ---- 2. best match of a position (lz77.nim:83-112) ----
 // `pos` is block-relative, `pw` the block's links (kernel 1).  Returns length | offset << 16, or 0
 // when the longest match is not longer than 4 (lz77.nim:114).
+template <bool kNarrow>
 __device__ __forceinline__ uint32_t zh_chain_search_one(const uint8_t* __restrict__ src,
-                                                        const uint64_t* __restrict__ pw, uint32_t pos,
+                                                        const typename ChainRec<kNarrow>::T* __restrict__ pw, uint32_t pos,
                                                         uint32_t block_len, int good, int nice, int max_chain) {
   if (pos + 4u >= block_len) return 0;
   const uint32_t window_pos = pos & 32767u;
   const uint32_t limit = block_len < pos + 258u ? block_len : pos + 258u;
-  uint32_t hash_pos = (uint32_t)pw[pos] & 0xffffu;
+  const uint64_t own_rec = pw[pos];
+  uint32_t hash_pos = (uint32_t)own_rec & 0xffffu;
   // the position's own first bytes: every candidate is compared against them, first through the
-  // six bytes that travel with the candidate's chain link (one gather decides most candidates)
+  // six bytes that travel with the candidate's chain link (one gather decides most candidates);
+  // narrow records: through the tag of its first five
   const bool wide = pos + 8u <= limit;
   const uint64_t own6 = wide ? load64u(src + pos) & 0xffffffffffffull : 0ull;
+  const uint32_t own_tag = (uint32_t)own_rec >> 16;
   int tries = max_chain;
   int prev_offset = 0, longest_offset = 0, longest_len = 0;
   while (tries > 0 && hash_pos != 0) {
@@ -399,12 +429,14 @@ __device__ __forceinline__ uint32_t zh_chain_search_one(const uint8_t* __restric
     if (offset <= 0 || offset < prev_offset) break;
     prev_offset = offset;
     // determineMatchLength(src, pos - offset, pos, limit), internal.nim:251-270
-    const uint64_t entry = pw[pos - (uint32_t)offset];  // chain[hashPos] | the candidate's six bytes << 16
+    const uint64_t entry = pw[pos - (uint32_t)offset];  // chain[hashPos] | the candidate's six bytes (or its tag) << 16
     const uint8_t* s1 = src + (pos - (uint32_t)offset);
     uint32_t s2 = pos;
     int match_len = 0;
     bool done = false;
-    if (wide) {
+    if (kNarrow) {
+      done = ((uint32_t)entry >> 16) != own_tag;  // fewer than five bytes: as good as none (see ChainRec)
+    } else if (wide) {
       const uint64_t x6 = (entry >> 16) ^ own6;
       if (x6 != 0) {
         match_len = (int)((uint32_t)__builtin_ctzll(x6) >> 3);
@@ -458,7 +490,7 @@ __global__ __launch_bounds__(256) void zh_chain_search_kernel(const uint8_t* __r
   const uint32_t pos = (f - bd.first_frag) * ZH_FRAG_SIZE + local;  // block-relative
   const uint64_t* pw = prevw + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   best[(size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE + pos] =
-      kBestKnown | zh_chain_search_one(d_src + bd.src_off, pw, pos, (uint32_t)bd.len, good, nice, max_chain);
+      kBestKnown | zh_chain_search_one<false>(d_src + bd.src_off, pw, pos, (uint32_t)bd.len, good, nice, max_chain);
 }
 #endif  // ZH_XCHECK
 
@@ -474,7 +506,7 @@ namespace {
 constexpr uint32_t kWalkThreads = 256u;
 }  // namespace
 // kChunk: positions a walk starts at the first of (512 x 1 MiB, this kernel in ms: 16: 40.3, 32: 36.8, 64: 40.7, 128: 47.4)
-template <uint32_t kChunk>
+template <uint32_t kChunk, bool kNarrow>
 __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
                                                             int good, int nice, int max_chain,
                                                             const uint64_t* __restrict__ prevw,
@@ -493,7 +525,8 @@ __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8
   const ZhBlockDesc bd = a.blocks[fd.block];
   const uint8_t* src = d_src + bd.src_off;
   const uint32_t block_len = (uint32_t)bd.len;
-  const uint64_t* pw = prevw + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
+  typedef typename ChainRec<kNarrow>::T Rec;
+  const Rec* pw = reinterpret_cast<const Rec*>(prevw) + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   uint32_t* bst = best + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   const uint32_t nmain = block_len > 4u ? block_len - 4u : 0u;  // lz77.nim:74-76: behind it only literals
   uint32_t pos = (f - bd.first_frag) * ZH_FRAG_SIZE + local;    // block-relative
@@ -511,7 +544,7 @@ __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8
   // lanes busy.  Here a lane that is done with a search goes on to its next position while the others
   // follow their chains; the values are zh_chain_search_one's, decision for decision.
   enum : uint32_t { kT = 0, kC = 1, kE = 2, kF = 3, kDone = 4 };
-  constexpr uint32_t kLinkTurns = 3;  // (512 x 1 MiB, this kernel: 0: 37.0 ms, 1: 34.1, 3: 33.7, 7: 34.5)
+  constexpr uint32_t kLinkTurns = ZH_CHAIN_LINK_TURNS;  // (512 x 1 MiB, this kernel: 0: 37.0 ms, 1: 34.1, 3: 33.7, 7: 34.5)
   uint32_t st = kT;
   uint32_t hash_pos = 0, nxt = 0, limit = 0, window_pos = 0;
   int tries = 0, prev_offset = 0, longest_len = 0, longest_offset = 0, offset = 0, m = 0;
@@ -550,7 +583,8 @@ __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8
       a1 = src + pos + (uint32_t)m;
       a2 = src + cand + (uint32_t)m;
     }
-    const uint64_t v1 = load64u(a1);
+    // (a narrow record is four bytes: its load must not reach behind the array; the other states' are eight)
+    const uint64_t v1 = kNarrow && st != kE ? (uint64_t)load32u(a1) : load64u(a1);
     // (past the L1: best[] entries come from other workgroups, too; eight bytes at any address)
     const uint64_t v2 = __hip_atomic_load(reinterpret_cast<const uint64_t*>(a2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- what they mean ----
@@ -564,11 +598,11 @@ __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8
           const uint32_t len = r & 0xffffu;
           pos += len ? len : 1u;
         }
-      } else {  // zh_chain_search_one(src, pw, pos, ...) starts (pos < nmain: pos + 4 < block_len)
+      } else {  // zh_chain_search_one<kNarrow>(src, pw, pos, ...) starts (pos < nmain: pos + 4 < block_len)
         window_pos = pos & 32767u;
         limit = block_len < pos + 258u ? block_len : pos + 258u;
         wide = pos + 8u <= limit;
-        own6 = wide ? v1 >> 16 : 0ull;  // (the position's own six bytes travel with its link, too)
+        own6 = kNarrow ? (v1 >> 16) & 0xffffull : wide ? v1 >> 16 : 0ull;  // (the position's own six bytes -- or its tag -- travel with its link, too)
         hash_pos = (uint32_t)v1 & 0xffffu;
         tries = max_chain;
         prev_offset = 0;
@@ -578,10 +612,10 @@ __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8
       }
     } else if (st == kC) {
       nxt = (uint32_t)v1 & 0xffffu;
-      const uint64_t x6 = (v1 >> 16) ^ own6;
+      const uint64_t x6 = ((v1 >> 16) & (kNarrow ? 0xffffull : ~0ull)) ^ own6;
       m = 0;
-      if (wide && x6 != 0) {
-        m = (int)((uint32_t)__builtin_ctzll(x6) >> 3);
+      if (kNarrow ? x6 != 0 : wide && x6 != 0) {  // (narrow: the tags differ -- fewer than five bytes, as good as none)
+        m = kNarrow ? 0 : (int)((uint32_t)__builtin_ctzll(x6) >> 3);
         decided = true;
       } else {
         st = kE;
@@ -632,8 +666,8 @@ __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8
             const uint64_t e = pw[pos - (uint32_t)offset];
             nxt = (uint32_t)e & 0xffffu;
             const uint64_t x6 = (e >> 16) ^ own6;
-            if (wide && x6 != 0) {
-              m = (int)((uint32_t)__builtin_ctzll(x6) >> 3);
+            if (kNarrow ? x6 != 0 : wide && x6 != 0) {
+              m = kNarrow ? 0 : (int)((uint32_t)__builtin_ctzll(x6) >> 3);
               if (m > longest_len) {
                 if (m >= good) tries >>= 2;
                 longest_len = m;
@@ -719,6 +753,7 @@ __global__ __launch_bounds__(64) void zh_chain_select_kernel(ZhCompressArgs a,
 // whose walks never meet (a run parsed into back-to-back maximal matches) makes the final prefix
 // grow one chunk a turn: thread 0 then simply finishes the walk through LDS alone.  Counts are
 // prefix-summed and a last walk files the matches.  Same match list as zh_chain_select_kernel.
+template <bool kNarrow>
 __global__ __launch_bounds__(256) void zh_chain_select_par_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
                                                                   int good, int nice, int max_chain,
                                                                   const uint64_t* __restrict__ prevw,
@@ -735,7 +770,8 @@ __global__ __launch_bounds__(256) void zh_chain_select_par_kernel(const uint8_t*
   const uint32_t block_len = (uint32_t)bd.len;
   uint32_t* bst = best + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   const uint8_t* src = d_src + bd.src_off;
-  const uint64_t* pw = prevw + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
+  typedef typename ChainRec<kNarrow>::T Rec;
+  const Rec* pw = reinterpret_cast<const Rec*>(prevw) + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE;
   // lz77.nim:54-56,74-76: the last four positions (and blocks of <= 4 bytes) are literals
   const uint32_t nmain = block_len > 4u ? block_len - 4u : 0u;
   uint32_t entry = 0;  // block-relative position at which the walk enters the next fragment
@@ -774,7 +810,7 @@ __global__ __launch_bounds__(256) void zh_chain_select_par_kernel(const uint8_t*
     auto len_at = [&](uint32_t p) -> uint32_t {
       uint32_t l = s_len[p];
       if (l == 255u) {
-        const uint32_t r = zh_chain_search_one(src, pw, base + p, block_len, good, nice, max_chain);
+        const uint32_t r = zh_chain_search_one<kNarrow>(src, pw, base + p, block_len, good, nice, max_chain);
         __hip_atomic_store(bst + base + p, r | kBestKnown, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         l = (r & 0xffffu) ? (r & 0xffffu) - 4u : 0u;
         s_len[p] = (uint8_t)l;
@@ -1016,31 +1052,6 @@ extern "C" int zh_chain_lds_order_ok(int device, hipStream_t stream) {
 // gets that failed the probe above (the decision is the context's, made once at zh_create for ITS device; the test
 // build -DZH_XCHECK also takes it from ZH_CHAIN_PREV=serial, as a cross-check).
 // `lists`: 4 bytes a position of scratch (the plan lends best[], which the walks clear before they use it)
-extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
-                                     uint32_t* head_scratch, uint64_t* prevw, uint32_t* lists, int links_serial) {
-  if (!a.nblocks) return;
-  if (!links_serial) {
-    // (head_scratch holds at least 256 KiB a block: kClsStride words)
-    const uint32_t ngrid = a.nfrags * (kUnitsPerFrag / kClsWaves);
-    hipLaunchKernelGGL(zh_chain_class_kernel<false>, dim3(ngrid), dim3(64 * kClsWaves), 0, stream, d_src, a, head_scratch, lists);
-    hipLaunchKernelGGL(zh_chain_class_scan_kernel, dim3(a.nblocks), dim3(512), 0, stream, a, head_scratch);
-    hipLaunchKernelGGL(zh_chain_class_kernel<true>, dim3(ngrid), dim3(64 * kClsWaves), 0, stream, d_src, a, head_scratch, lists);
-    const uint32_t ng = a.nblocks * kClasses;
-    hipLaunchKernelGGL(zh_chain_class_links_kernel, dim3((ng + 7u) & ~7u), dim3(64), 0, stream, d_src, a, head_scratch, lists,
-                       prevw, ng);
-    return;
-  }
-  const uint32_t slice = zh_chain_prev_slice();
-  if (a.nblocks <= slice) {
-    (void)hipMemsetAsync(head_scratch, 0, (size_t)a.nblocks * ZH_CHAIN_HEAD_WORDS * 4u, stream);
-    hipLaunchKernelGGL(zh_chain_prev_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a, head_scratch, prevw, a.first_block);
-    return;
-  }
-  // (all blocks at once: this form lives on the number of loads in flight)
-  (void)hipMemsetAsync(head_scratch, 0, (size_t)a.nblocks << (kHashBits + 1), stream);
-  hipLaunchKernelGGL(zh_chain_prev_ldst_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a,
-                     reinterpret_cast<uint16_t*>(head_scratch), prevw, a.first_block);
-}
 // The cross-checks of the test build (-DZH_XCHECK; the product library has neither the switches nor the kernels):
 // ZH_CHAIN_SEARCH=dense: the best match of EVERY position (kernel 2a) instead of the walks of kernel 2b;
 // ZH_CHAIN_SELECT=serial (one wave per block, needs the dense search).
@@ -1063,6 +1074,38 @@ static bool chain_search_dense() {
 static constexpr bool chain_select_serial() { return false; }
 static constexpr bool chain_search_dense() { return false; }
 #endif
+// narrow records (ChainRec): where the links come from the class kernels and the level's `good` is at least five, and
+// no cross-check of the test build asks for the every-position search (which reads wide records)
+static bool chain_narrow(int links_serial, int good) { return !links_serial && good >= 5 && !chain_search_dense(); }
+extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
+                                     uint32_t* head_scratch, uint64_t* prevw, uint32_t* lists, int links_serial, int good) {
+  if (!a.nblocks) return;
+  if (!links_serial) {
+    // (head_scratch holds at least 256 KiB a block: kClsStride words)
+    const uint32_t ngrid = a.nfrags * (kUnitsPerFrag / kClsWaves);
+    hipLaunchKernelGGL(zh_chain_class_kernel<false>, dim3(ngrid), dim3(64 * kClsWaves), 0, stream, d_src, a, head_scratch, lists);
+    hipLaunchKernelGGL(zh_chain_class_scan_kernel, dim3(a.nblocks), dim3(512), 0, stream, a, head_scratch);
+    hipLaunchKernelGGL(zh_chain_class_kernel<true>, dim3(ngrid), dim3(64 * kClsWaves), 0, stream, d_src, a, head_scratch, lists);
+    const uint32_t ng = a.nblocks * kClasses;
+    if (chain_narrow(links_serial, good))
+      hipLaunchKernelGGL(zh_chain_class_links_kernel<true>, dim3((ng + 7u) & ~7u), dim3(64), 0, stream, d_src, a, head_scratch,
+                         lists, prevw, ng);
+    else
+      hipLaunchKernelGGL(zh_chain_class_links_kernel<false>, dim3((ng + 7u) & ~7u), dim3(64), 0, stream, d_src, a, head_scratch,
+                         lists, prevw, ng);
+    return;
+  }
+  const uint32_t slice = zh_chain_prev_slice();
+  if (a.nblocks <= slice) {
+    (void)hipMemsetAsync(head_scratch, 0, (size_t)a.nblocks * ZH_CHAIN_HEAD_WORDS * 4u, stream);
+    hipLaunchKernelGGL(zh_chain_prev_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a, head_scratch, prevw, a.first_block);
+    return;
+  }
+  // (all blocks at once: this form lives on the number of loads in flight)
+  (void)hipMemsetAsync(head_scratch, 0, (size_t)a.nblocks << (kHashBits + 1), stream);
+  hipLaunchKernelGGL(zh_chain_prev_ldst_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_src, a,
+                     reinterpret_cast<uint16_t*>(head_scratch), prevw, a.first_block);
+}
 extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a,
                                        int good, int nice, int max_chain, const uint64_t* prevw,
                                        uint32_t* best, int links_serial) {
@@ -1081,15 +1124,19 @@ extern "C" void zh_launch_chain_search(hipStream_t stream, const uint8_t* d_src,
       // (nothing is worked out yet -- the walks of one launch may look at the next launch's entries --: the
       // class-sorted links have left best[] cleared; after the in-order kernels it still holds the last run's)
       if (f0 == 0 && links_serial) (void)hipMemsetAsync(best, 0, (size_t)a.nfrags * ZH_FRAG_SIZE * 4u, stream);
-      constexpr uint32_t kChunk = 32;
+      constexpr uint32_t kChunk = ZH_CHAIN_CHUNK;
       const uint32_t ng = nf * (ZH_FRAG_SIZE / kChunk / kWalkThreads);
-      hipLaunchKernelGGL(zh_chain_walk_kernel<kChunk>, dim3((ng + 7u) & ~7u), dim3(kWalkThreads), 0, stream, d_src, a, good,
-                         nice, max_chain, prevw, best, a.first_frag + f0, ng);
+      if (chain_narrow(links_serial, good))
+        hipLaunchKernelGGL((zh_chain_walk_kernel<kChunk, true>), dim3((ng + 7u) & ~7u), dim3(kWalkThreads), 0, stream, d_src, a,
+                           good, nice, max_chain, prevw, best, a.first_frag + f0, ng);
+      else
+        hipLaunchKernelGGL((zh_chain_walk_kernel<kChunk, false>), dim3((ng + 7u) & ~7u), dim3(kWalkThreads), 0, stream, d_src, a,
+                           good, nice, max_chain, prevw, best, a.first_frag + f0, ng);
     }
   }
 }
 extern "C" void zh_launch_chain_select(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a, int good,
-                                       int nice, int max_chain, const uint64_t* prevw, uint32_t* best) {
+                                       int nice, int max_chain, const uint64_t* prevw, uint32_t* best, int links_serial) {
   if (!a.nblocks) return;
 #ifdef ZH_XCHECK
   if (chain_select_serial()) {
@@ -1097,7 +1144,11 @@ extern "C" void zh_launch_chain_select(hipStream_t stream, const uint8_t* d_src,
     return;
   }
 #endif
-  hipLaunchKernelGGL(zh_chain_select_par_kernel, dim3(a.nblocks), dim3(256), 0, stream, d_src, a, good, nice,
+  if (chain_narrow(links_serial, good))
+    hipLaunchKernelGGL(zh_chain_select_par_kernel<true>, dim3(a.nblocks), dim3(256), 0, stream, d_src, a, good, nice,
+                       max_chain, prevw, best);
+  else
+    hipLaunchKernelGGL(zh_chain_select_par_kernel<false>, dim3(a.nblocks), dim3(256), 0, stream, d_src, a, good, nice,
                        max_chain, prevw, best);
 }
 extern "C" void zh_launch_frag_stats(hipStream_t stream, const uint8_t* d_src, ZhCompressArgs a) {

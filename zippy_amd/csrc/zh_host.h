@@ -62,13 +62,13 @@ void zh_launch_l1p_match(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, ui
                          uint32_t* next_frag);
 uint32_t zh_l1p_slots(void);
 void zh_launch_chain_prev(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, uint32_t* head_scratch,
-                          uint64_t* prevw, uint32_t* lists, int links_serial);
+                          uint64_t* prevw, uint32_t* lists, int links_serial, int good);
 uint32_t zh_chain_prev_slice(void);
 int zh_chain_lds_order_ok(int device, hipStream_t stream);
 void zh_launch_chain_search(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
                             int max_chain, const uint64_t* prevw, uint32_t* best, int links_serial);
 void zh_launch_chain_select(hipStream_t, const uint8_t* d_src, ZhCompressArgs a, int good, int nice,
-                            int max_chain, const uint64_t* prevw, uint32_t* best);
+                            int max_chain, const uint64_t* prevw, uint32_t* best, int links_serial);
 void zh_launch_frag_stats(hipStream_t, const uint8_t* d_src, ZhCompressArgs a);
 void zh_launch_huffman(hipStream_t, ZhCompressArgs a, int contract);
 void zh_launch_huffman_probe(hipStream_t, const uint32_t* freq, int num_freq, int min_codes, int limit, int contract,

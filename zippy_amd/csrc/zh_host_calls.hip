@@ -236,9 +236,9 @@ extern "C" int zh_debug_tokens(zh_ctx* ctx, const void* src, size_t len, int lev
       ar.nblocks = r.nb;
       ar.first_frag = r.f0;
       ar.nfrags = r.nf;
-      zh_launch_chain_prev(s, d_src.p, ar, p->head_scratch, p->chain_prev, p->chain_best, p->ctx->chain_links_serial ? 1 : 0);
+      zh_launch_chain_prev(s, d_src.p, ar, p->head_scratch, p->chain_prev, p->chain_best, p->ctx->chain_links_serial ? 1 : 0, cfg[0]);
       zh_launch_chain_search(s, d_src.p, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best, p->ctx->chain_links_serial ? 1 : 0);
-      zh_launch_chain_select(s, d_src.p, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+      zh_launch_chain_select(s, d_src.p, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best, p->ctx->chain_links_serial ? 1 : 0);
     }
   }
   const size_t nf = a.nfrags;

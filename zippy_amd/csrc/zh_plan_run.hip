@@ -302,12 +302,12 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
         ar.first_frag = r.f0;
         ar.nfrags = r.nf;
         prof_mark(p, "zh_chain_prev_kernel");
-        zh_launch_chain_prev(s, d_src, ar, p->head_scratch, p->chain_prev, p->chain_best, p->ctx->chain_links_serial ? 1 : 0);
+        zh_launch_chain_prev(s, d_src, ar, p->head_scratch, p->chain_prev, p->chain_best, p->ctx->chain_links_serial ? 1 : 0, cfg[0]);
         ZH_HIP(ctx, hipGetLastError());
         prof_mark(p, "zh_chain_walk_kernel");
         zh_launch_chain_search(s, d_src, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best, p->ctx->chain_links_serial ? 1 : 0);
         prof_mark(p, "zh_chain_select_kernel");
-        zh_launch_chain_select(s, d_src, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best);
+        zh_launch_chain_select(s, d_src, ar, cfg[0], cfg[1], cfg[2], p->chain_prev, p->chain_best, p->ctx->chain_links_serial ? 1 : 0);
         ZH_HIP(ctx, hipGetLastError());
       }
       p->chain_best_dirty = false;  // (every launch was accepted: the links kernel hands best[] back cleared)
