@@ -143,6 +143,10 @@ proc zh_plan_pack(plan: ZhPlan, dSlots, dPacked: pointer, packedCap: uint64,
 proc zh_plan_unpack(plan: ZhPlan, dPacked: pointer, dOffsets: ptr uint64,
                     dSlots: pointer): cint {.importc, cdecl, dynlib: zhLib.}
 proc zh_plan_destroy(plan: ZhPlan) {.importc, cdecl, dynlib: zhLib.}
+proc zh_device_malloc(ctx: ZhCtx, bytes: csize_t, dOut: ptr pointer): cint {.importc, cdecl, dynlib: zhLib.}
+proc zh_device_free(ctx: ZhCtx, d: pointer) {.importc, cdecl, dynlib: zhLib.}
+proc zh_device_upload(ctx: ZhCtx, dDst, src: pointer, bytes: csize_t): cint {.importc, cdecl, dynlib: zhLib.}
+proc zh_device_download(ctx: ZhCtx, dst, dSrc: pointer, bytes: csize_t): cint {.importc, cdecl, dynlib: zhLib.}
 
 # ---- the archive layer (src/zippy/ziparchives.nim) ----
 type

@@ -1,4 +1,6 @@
 export TMPDIR=/tmp
+# (round 5: ZH_L1_TABLE=lds exists only in the test build: python -m zippy_amd.build --variant xcheck -DZH_XCHECK)
+export ZIPPY_HIP_LIB=$(pwd)/zippy_amd/libzippy_hip_xcheck.so
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
 ZH_L1_TABLE=lds python bench.py --steps 3 --warmup 1 --no-cpu-baseline --compress-only 2>/dev/null | tail -1 > $O/r02_ldsmode_bench.json
 python -c "
