@@ -920,12 +920,13 @@ def check_split_inflate_edges(eng):
         assert st == [0] and got[0] == want, (len(blob), fmt, st)
 
 
-def stored_chain_streams(nblocks=70):
+def stored_chain_streams(nblocks=70, small=False):
     """Streams of stored blocks (inflate.nim:252-266), the kind incompressible data makes -- one of 65 535 bytes after
     the other (deflate.nim:186-199) --, for the chain reader of the tokens kernel (64 headers at once) and the
     writer's grouped copy: whole chains of more than 64 blocks, a short last block, an empty one, chains broken by a
     compressed block, by a short block in the middle, and damaged ones (a length that does not match its complement
-    in the middle of a chain, a chain that runs past the input).  -> [(raw deflate, plain or None)]"""
+    in the middle of a chain, a chain that runs past the input).  small: the subset the CPU emulator (a third of a
+    megabyte a second on these) runs; the GPU tests run all of them.  -> [(raw deflate, plain or None)]"""
     rnd = random.Random(4711)
     noise = rnd.randbytes(nblocks * 65535 + 12345)
 
@@ -940,16 +941,19 @@ def stored_chain_streams(nblocks=70):
     dyn_block = dyn.compress(text) + dyn.flush(zlib.Z_FULL_FLUSH)  # (ends byte-aligned with an empty stored block, not final)
     out = []
     out.append((stored(noise, True), noise))                                        # the oracle's own shape at level 0
-    out.append((oracle.compress(noise, 0, oracle.dfDeflate), noise))
+    if not small:
+        out.append((oracle.compress(noise, 0, oracle.dfDeflate), noise))
     out.append((oracle.compress(noise[:200000], 1, oracle.dfDeflate), noise[:200000]))  # incompressible at level 1: stored
-    out.append((stored(noise[:65535 * 64], True), noise[:65535 * 64]))              # exactly 64 full blocks, the last final
+    if not small:
+        out.append((stored(noise[:65535 * 64], True), noise[:65535 * 64]))          # exactly 64 full blocks, the last final
     out.append((stored(noise[:65535 * 65], False) + stored(b"", True), noise[:65535 * 65]))  # an empty final block behind the chain
-    out.append((stored(noise[:65535 * 3], False) + dyn_block + stored(noise[:65535 * 70 + 5], True),
-                noise[:65535 * 3] + text + noise[:65535 * 70 + 5]))
-    out.append((stored(noise[:65535 * 5], False) + stored(noise[:1000], False, 1000) + stored(noise[:65535 * 66], True),
-                noise[:65535 * 5] + noise[:1000] + noise[:65535 * 66]))
+    out.append((stored(noise[:65535 * 3], False) + dyn_block + stored(noise[:65535 * (nblocks - 1) + 5], True),
+                noise[:65535 * 3] + text + noise[:65535 * (nblocks - 1) + 5]))
+    if not small:
+        out.append((stored(noise[:65535 * 5], False) + stored(noise[:1000], False, 1000) + stored(noise[:65535 * 65], True),
+                    noise[:65535 * 5] + noise[:1000] + noise[:65535 * 65]))
     out.append((stored(noise[:300000], True, 30000), noise[:300000]))               # no full block at all
-    good = stored(noise[:65535 * 40], True)
+    good = stored(noise[:65535 * (20 if small else 40)], True)
     bad = bytearray(good)
     bad[17 * 65540 + 3] ^= 0x40                                                     # block 17: NLEN no longer the complement
     out.append((bytes(bad), None))
@@ -960,11 +964,11 @@ def stored_chain_streams(nblocks=70):
     return out
 
 
-def check_stored_chains(eng, nblocks=70):
+def check_stored_chains(eng, nblocks=70, small=False):
     """The streams above through the device decoder: bytes where they are sound (and through zlib, the referee), the
     oracle's accept / reject decision where they are not; and with an output slot that is too small the status a
     caller grows its buffer on, not another."""
-    cases = stored_chain_streams(nblocks)
+    cases = stored_chain_streams(nblocks, small)
     outs, sts = eng.uncompress_batch([c[0] for c in cases], oracle.dfDeflate)
     for (blob, want), got, st in zip(cases, outs, sts):
         try:
@@ -975,12 +979,12 @@ def check_stored_chains(eng, nblocks=70):
         assert (st == 0) == (want is not None), (len(blob), st)
         if want is not None:
             assert got == want and zlib.decompress(blob, -15) == want
-    one = [cases[0][0]]  # (a batch of one: the wide kernels)
+    one = [cases[1 if small else 0][0]]  # (a batch of one: the wide kernels)
     got, st = eng.uncompress_batch(one, oracle.dfDeflate)
-    assert st == [0] and got[0] == cases[0][1]
+    assert st == [0] and got[0] == cases[1 if small else 0][1]
 
 
-def check_stored_chain_segmented(eng, monkeypatch, nblocks=70):
+def check_stored_chain_segmented(eng, monkeypatch, nblocks=70, text_bytes=600000):
     """A chain of full stored blocks in the MIDDLE of a stream that is decoded segment-wise (zh_inflate_seg.hip): the
     segments inside the chain have no block start, the decoder before them reads the chain 64 headers a step and has to
     stop where the next segment's found start is -- the compressed blocks behind the chain."""
@@ -989,7 +993,7 @@ def check_stored_chain_segmented(eng, monkeypatch, nblocks=70):
     monkeypatch.setenv("ZH_SEG_SETUP", "0")
     rnd = random.Random(99)
     noise = rnd.randbytes(nblocks * 65535)
-    text = synth.gen_batch("text", 1, 600000, first_index=3)[0].tobytes()
+    text = synth.gen_batch("text", 1, text_bytes, first_index=3)[0].tobytes()
 
     def dyn(data, last):
         c = zlib.compressobj(6, zlib.DEFLATED, -15)

@@ -309,12 +309,18 @@ def test_emu_plan_pack(eng):
     pc.check_plan_pack(eng, upload, lambda keep: keep.raw, alloc)
 
 
-def test_emu_stored_chains(eng, inflate_mode):
-    pc.check_stored_chains(eng)
+def test_emu_stored_chains(eng):
+    """(the split decoder only, 66-block chains: the serial decoder reads stored blocks the way it always did, and
+    the GPU suite runs both modes at 200 blocks)"""
+    eng.set_inflate_mode(0)
+    try:
+        pc.check_stored_chains(eng, 66, small=True)
+    finally:
+        eng.set_inflate_mode(-1)
 
 
 def test_emu_stored_chain_segmented(eng, monkeypatch):
-    pc.check_stored_chain_segmented(eng, monkeypatch)
+    pc.check_stored_chain_segmented(eng, monkeypatch, 66, 200000)
 
 
 def test_emu_split_inflate_edges(eng, inflate_mode):
@@ -323,4 +329,4 @@ def test_emu_split_inflate_edges(eng, inflate_mode):
 
 def test_emu_segmented_streams(eng, monkeypatch):
     pc.check_segmented(eng, 1024, monkeypatch, 2048)
-    pc.check_segmented(eng, 1024, monkeypatch, 600)  # chains of more than two window groups
+    pc.check_segmented(eng, 512, monkeypatch, 600)  # chains of more than two window groups

@@ -107,6 +107,12 @@ def main():
         show("zh_l1_match_kernel", L1, list(slots[0:16]))
     show("zh_emit_kernel", EMIT, list(slots[32:40]))
     show("zh_huffman_kernel", HUFF, list(slots[40:48]))
+    if args.l1_parse != 1 and slots[47]:
+        names = ["used symbols", "leaves pushed", "merges (2 pops + a push each)", "depths", "limit: histogram + levels",
+                 "limit: quicksort", "limit: lengths by rank", "lengths + canonical codes"]
+        print("   the literal / length code (the replay of huffmanCodes), cycles a block:")
+        for nm, v in zip(names, slots[56:64]):
+            print("     %-32s %9d" % (nm, v // slots[47]))
     show("zh_inflate_tokens_kernel (thread 0 of each stream)", TOK, list(slots[48:56]))
     show("zh_inflate_kernel: output wave", INF_O, list(slots[16:24]))
     show("zh_inflate_kernel: decode wave", INF_D, list(slots[24:32]))

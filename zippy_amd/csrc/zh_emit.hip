@@ -3,8 +3,9 @@
 // Replaces deflate.nim:403-466 (the literal/length/distance bit packing loop)
 // and the data copy of addNoCompressionBlock (deflate.nim:200-205).  The
 // reference packs serially through BitStreamWriter.addBits; here every source
-// position of the fragment is an item (four per lane and pass, so that the loads of a
-// pass -- one source dword and the match fields per lane -- are in flight together):
+// position of the fragment is an item (kPos = 8 per lane and pass: the loads of a pass -- the lane's source
+// bytes and the match fields -- are in flight together, and what a pass costs whatever its width -- two wave
+// scans, the match coding, the bitmap reads, the loop -- is paid once per 512 positions):
 // a literal contributes its code, a
 // match start contributes code + length extra + distance code + distance extra
 // (<= 48 bits, assembled exactly as deflate.nim:417-433), bytes inside a match
@@ -19,9 +20,19 @@
 #include "zh_kprof.h"
 
 namespace {
-constexpr uint32_t kChunk = 4096;                      // positions per match-bitmap chunk (16 passes)
+#ifndef ZH_EMIT_POS
+#define ZH_EMIT_POS 8
+#endif
+constexpr uint32_t kPos = ZH_EMIT_POS;                 // positions per lane and pass (4 or 8: one bitmap word a lane)
+constexpr uint32_t kPass = 64 * kPos;                  // positions per pass
+constexpr uint32_t kPosMask = (1u << kPos) - 1u;
+constexpr uint32_t kChunk = 4096;                      // positions per match-bitmap chunk
 constexpr uint32_t kStageWords = 512;                  // 2 KiB staging window
-constexpr uint32_t kFlushBits = (kStageWords - 200) * 32;  // flush threshold: a 256-position pass adds < 6400 bits
+// flush threshold: a position adds at most 16 bits (a 15-bit literal, or 48 bits for a match of >= 3)
+constexpr uint32_t kFlushBits = (kStageWords - kPass / 2 - 16) * 32;
+constexpr uint32_t kPassMatches = kPass / 3 + 3;       // a pass starts at most kPass / 3 + 1 matches
+constexpr uint32_t kAhead = kPos / 4;                  // match fields asked for a pass ahead, per lane
+static_assert(kPos == 4 || kPos == 8, "one bitmap word and whole source dwords per lane");
 }  // namespace
 
 __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__ d_src,
@@ -33,9 +44,9 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   __shared__ uint32_t s_start[kChunk / 32];  // bit p - c0: a match starts at p
   __shared__ uint32_t s_cover[kChunk / 32];  // bit p - c0: p is inside a match (not its start)
   __shared__ uint32_t s_stage[kStageWords + 4];
-  // the pass's matches, coded once each by the first lanes (a pass of 256 positions starts at most 86)
-  __shared__ uint64_t s_mval[88];
-  __shared__ uint32_t s_mbits[88];
+  // the pass's matches, coded once each by the first lanes
+  __shared__ uint64_t s_mval[kPassMatches];
+  __shared__ uint32_t s_mbits[kPassMatches];
 
   const unsigned lane = zh_lane();
   KPROF_DECL(8);  // 0 flush + loop, 1 chunk bitmaps, 2 bitmaps/source/scan/match fields, 3 codes, 4 scan + LDS ORs, 5 last flush, 6 waves
@@ -138,26 +149,44 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   const uint32_t last_dw = (n + mis - 1u) >> 2;  // n >= 1 here
   auto dw = [&](uint32_t i) -> uint32_t { return asrc[i < last_dw ? i : last_dw]; };
 
-  // a pass ahead: the lane's source bytes and the next 64 matches' fields (clamped, unconditional loads)
+  // a pass ahead: the lane's source bytes and the next 64 * kAhead matches' fields (clamped, unconditional loads)
   const uint32_t mlast = nmatch ? nmatch - 1u : 0u;
-  auto word_at = [&](uint32_t p0) -> uint32_t {
+  uint32_t w_next[kPos / 4];
+  auto words_at = [&](uint32_t p0) {
     const uint32_t q = p0 + mis;
-    return __builtin_amdgcn_alignbyte(dw((q >> 2) + 1u), dw(q >> 2), q);
+    uint32_t d = dw(q >> 2);
+#pragma unroll
+    for (uint32_t i = 0; i < kPos / 4; i++) {
+      const uint32_t e = dw((q >> 2) + i + 1u);
+      w_next[i] = __builtin_amdgcn_alignbyte(e, d, q);
+      d = e;
+    }
   };
-  uint32_t w_next = word_at(4u * lane);
-  uint32_t pl = m_len[lane < nmatch ? lane : mlast], po = m_off[lane < nmatch ? lane : mlast];
-  for (uint32_t base = 0; base < n; base += 256) {
+  words_at(kPos * lane);
+  uint32_t pl[kAhead], po[kAhead];
+  auto fields_at = [&](uint32_t m0) {
+#pragma unroll
+    for (uint32_t i = 0; i < kAhead; i++) {
+      const uint32_t mi = m0 + 64u * i + lane < nmatch ? m0 + 64u * i + lane : mlast;
+      pl[i] = m_len[mi];
+      po[i] = m_off[mi];
+    }
+  };
+  fields_at(0);
+  for (uint32_t base = 0; base < n; base += kPass) {
     KPROF_MARK(0);
     if ((base & (kChunk - 1u)) == 0) build_chunk(base);
     KPROF_MARK(1);
-    const uint32_t p0 = base + 4u * lane;  // this lane's four positions p0 .. p0+3
+    const uint32_t p0 = base + kPos * lane;  // this lane's positions p0 .. p0 + kPos - 1
     const bool in = p0 < n;
-    const uint32_t bw = in ? (p0 & (kChunk - 1u)) >> 5 : 0u, bs = p0 & 31u;  // p0 is a multiple of 4: one bitmap word
-    const uint32_t st4 = in ? (s_start[bw] >> bs) & 15u : 0u;
-    uint32_t skip4 = in ? (s_cover[bw] >> bs) & 15u : 15u;
-    if (in && n - p0 < 4u) skip4 |= 15u << (n - p0);  // positions past the fragment
-    const uint32_t w = in ? w_next : 0u;
-    w_next = word_at(p0 + 256u);  // (dw() clamps behind the fragment's last byte)
+    const uint32_t bw = in ? (p0 & (kChunk - 1u)) >> 5 : 0u, bs = p0 & 31u;  // p0 is a multiple of kPos: one bitmap word
+    const uint32_t st4 = in ? (s_start[bw] >> bs) & kPosMask : 0u;
+    uint32_t skip4 = in ? (s_cover[bw] >> bs) & kPosMask : kPosMask;
+    if (in && n - p0 < kPos) skip4 |= (kPosMask << (n - p0)) & kPosMask;  // positions past the fragment
+    uint32_t w[kPos / 4];
+#pragma unroll
+    for (uint32_t i = 0; i < kPos / 4; i++) w[i] = in ? w_next[i] : 0u;
+    words_at(p0 + kPass);  // (dw() clamps behind the fragment's last byte)
     // index (in the pass) of this lane's first match start
     const uint32_t nst = (uint32_t)__popc(st4);
     const uint32_t incl_st = zh_wave_scan(nst);
@@ -166,8 +195,13 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
     // ---- the pass's matches: length code + extra + distance code + extra (deflate.nim:417-433), one
     // match a lane (their fields are neighbours in the match list), parked for the lanes that own the
     // positions ----
-    for (uint32_t j = lane; j < npass; j += 64) {
-      const uint32_t length = j < 64u ? pl : m_len[mbase + j], offset = j < 64u ? po : m_off[mbase + j];
+#pragma unroll
+    for (uint32_t i = 0; i < (kPassMatches + 63u) / 64u; i++) {
+      const uint32_t j = lane + 64u * i;
+      if (64u * i >= npass) break;
+      if (j >= npass) continue;
+      const uint32_t length = i < kAhead ? pl[i < kAhead ? i : 0] : m_len[mbase + j];
+      const uint32_t offset = i < kAhead ? po[i < kAhead ? i : 0] : m_off[mbase + j];
       const uint32_t li = zh_len_code(length), di = zh_dist_code(offset);
       const uint32_t lc = s_lit[257 + li], dc = s_dist[di];
       uint64_t v = lc & 0xffffu;
@@ -182,17 +216,13 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
       s_mbits[j] = nbits;
     }
     mbase += npass;
-    {
-      const uint32_t mi = mbase + lane < nmatch ? mbase + lane : mlast;
-      pl = m_len[mi];
-      po = m_off[mi];
-    }
+    fields_at(mbase);
     zh_wave_sync();
     KPROF_MARK(2);
-    uint64_t val[4];
-    uint32_t nb[4], lane_bits = 0;
+    uint64_t val[kPos];
+    uint32_t nb[kPos], lane_bits = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
+    for (uint32_t k = 0; k < kPos; k++) {
       uint64_t v = 0;
       uint32_t nbits = 0;
       if ((st4 >> k) & 1u) {
@@ -200,7 +230,7 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
         nbits = s_mbits[mj];
         mj++;
       } else if (!((skip4 >> k) & 1u)) {
-        const uint32_t lc = s_lit[(w >> (8u * k)) & 255u];
+        const uint32_t lc = s_lit[(w[k / 4] >> (8u * (k & 3u))) & 255u];
         v = lc & 0xffffu;
         nbits = lc >> 16;
       }
@@ -217,7 +247,7 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
     uint32_t bp = stage_bits + incl - lane_bits;
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
+    for (uint32_t k = 0; k < kPos; k++) {
       if (nb[k]) {
         const uint32_t wd = bp >> 5, sft = bp & 31u;
         const uint64_t lo64 = val[k] << sft;  // nbits <= 48, so only sft + nbits > 64 loses bits here
@@ -233,7 +263,7 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
 #endif
     KPROF_MARK(4);
 
-    const bool last = base + 256 >= n;
+    const bool last = base + kPass >= n;
     if (stage_bits >= kFlushBits || last) {
       zh_wave_sync();
       const uint32_t full = stage_bits >> 5;           // complete words

@@ -38,124 +38,261 @@ constexpr int kMaxSyms = 288;
 // round of the machine): children only for the internal nodes, and the quicksort stack and the depth
 // histogram of the length limiting live where the heap was.
 struct HuffWork {
-  uint64_t hkey[kMaxSyms + 2];     // the heap: node frequency << 16 | node (one LDS read per comparison)
-  uint16_t left[kMaxSyms];         // of internal node i (n <= i < 2n - 1), at [i - n]
+  uint64_t hkey[kMaxSyms + 2];     // the heap: node frequency << 32 | node
+  uint16_t left[kMaxSyms];         // left and right together: node -> parent (2n - 1 nodes)
   uint16_t right[kMaxSyms];
-  uint16_t depth[2 * kMaxSyms];
+  uint16_t depth[2 * kMaxSyms];    // node -> depth (while the heap runs: the leaves' frequencies)
   int16_t symbol[kMaxSyms];        // leaf -> symbol
   uint16_t order[kMaxSyms];        // leaves, sorted by depth when limiting
   // behind the heap phase, in hkey's bytes:
   __device__ uint16_t* stack() { return reinterpret_cast<uint16_t*>(hkey); }                         // [2 * kMaxSyms + 4]
-  __device__ int32_t* histogram() { return reinterpret_cast<int32_t*>(hkey) + (kMaxSyms + 2); }     // [kMaxSyms + 2]
+  __device__ int32_t* histogram() { return reinterpret_cast<int32_t*>(hkey) + (kMaxSyms + 2); }     // [kMaxSyms + 2] (depths up to n - 1)
 };
 static_assert((2 * kMaxSyms + 4) * 2 <= (kMaxSyms + 2) * 4 && (kMaxSyms + 2) * 8 <= sizeof(uint64_t) * (kMaxSyms + 2), "");
 
 __device__ inline uint32_t rev16(uint32_t v) { return __brev(v) >> 16; }
 
-// ---- Nim std/heapqueue (CPython heapq) on nodes, `<` on frequency only ----
-__device__ inline void heap_sift_to_root(HuffWork& w, int startpos, int pos) {
-  const uint64_t newitem = w.hkey[pos];
-  const uint64_t f = newitem >> 16;
-  while (pos > startpos) {
-    const int parentpos = (pos - 1) >> 1;
-    const uint64_t parent = w.hkey[parentpos];
-    if (f < (parent >> 16)) {
-      w.hkey[pos] = parent;
-      pos = parentpos;
-    } else {
-      break;
+// deflate.nim:136-149: canonical codes, bit-reversed, symbols of one length in symbol order (wide counters, see
+// SURVEY.md 9.5) -- by the whole wave: a symbol's code is its length's first code plus the symbols of that length
+// before it (ballots).  lens / codes in LDS.
+__device__ inline void canonical_codes(const uint8_t* lens, uint16_t* codes, int num_codes) {
+  const unsigned lane = zh_lane();
+  constexpr int kPer = (kMaxSyms + 63) / 64;  // symbols a lane: lane, lane + 64, ...
+  uint32_t l[kPer], hist[16];
+#pragma unroll
+  for (int L = 0; L < 16; L++) hist[L] = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int sidx = (int)lane + 64 * k;
+    l[k] = sidx < num_codes ? lens[sidx] : 0u;
+#pragma unroll
+    for (int L = 1; L < 16; L++) hist[L] += (uint32_t)__popcll(__ballot(l[k] == (uint32_t)L));
+  }
+  uint32_t next_code[16];
+  next_code[0] = 0;
+  hist[0] = 0;
+#pragma unroll
+  for (int L = 1; L < 16; L++) next_code[L] = (next_code[L - 1] + hist[L - 1]) << 1;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int sidx = (int)lane + 64 * k;
+    uint32_t c = 0;
+#pragma unroll
+    for (int L = 1; L < 16; L++) {
+      const uint64_t m = __ballot(l[k] == (uint32_t)L);
+      if (l[k] == (uint32_t)L) c = next_code[L] + (uint32_t)__popcll(m & zh_lanemask_lt());
+      next_code[L] += (uint32_t)__popcll(m);
     }
+    if (l[k]) codes[sidx] = (uint16_t)(rev16(c & 0xffffu) >> (16 - l[k]));
   }
-  w.hkey[pos] = newitem;
-}
-__device__ inline void heap_sink_to_bottom(HuffWork& w, int len, int pos) {
-  const int startpos = pos;
-  const uint64_t newitem = w.hkey[pos];
-  int childpos = 2 * pos + 1;
-  while (childpos < len) {
-    const int rightpos = childpos + 1;
-    uint64_t c = w.hkey[childpos];
-    if (rightpos < len) {
-      const uint64_t r = w.hkey[rightpos];
-      if (!((c >> 16) < (r >> 16))) {
-        childpos = rightpos;
-        c = r;
-      }
-    }
-    w.hkey[pos] = c;
-    pos = childpos;
-    childpos = 2 * pos + 1;
-  }
-  w.hkey[pos] = newitem;
-  heap_sift_to_root(w, startpos, pos);
-}
-__device__ inline uint64_t heap_pop(HuffWork& w, int& len) {
-  const uint64_t last = w.hkey[--len];
-  if (len > 0) {
-    const uint64_t result = w.hkey[0];
-    w.hkey[0] = last;
-    heap_sink_to_bottom(w, len, 0);
-    return result;
-  }
-  return last;
+  zh_wave_sync();
 }
 
-// deflate.nim:13-151.  Serial; call from one lane.  Returns the number of codes.
-__device__ int huffman_codes(const uint32_t* freq, int num_freq, int min_codes, int limit,
-                             uint16_t* codes, uint8_t* lens, HuffWork& w) {
-  int highest = 0, used = 0;
-  for (int s = 0; s < num_freq; s++)
-    if (freq[s] > 0) {
-      highest = s;
-      used++;
+// ---- Nim std/heapqueue (CPython heapq) on nodes, `<` on frequency only: the reference's tie-breaks ARE the heap's
+// mechanics, so the heap is replayed move for move.  A key is frequency << 32 | node (a frequency is a sum over one
+// block, <= 4 MiB of symbols: the high dword compares).  One lane replaying it is a chain of ~ 240 instructions a pop
+// at ~ 10 cycles each (measured: three heap levels an LDS trip with scalar decisions cost what a level a trip had,
+// 5200 cycles a merge, 80 % of this kernel), so the WAVE does a pop: the 62 nodes of the five levels below the hole a
+// lane each.  A lane reads its node and its right neighbour, two ballots say where the right child is the one to
+// take and which nodes are larger than the item, the scalar unit walks those bits down the smaller children (the
+// path only depends on what is in the heap), and the lanes on the path write their nodes a level up -- all at once.
+// heappop's _siftup sinks the last item to a leaf and lets it climb back while it is smaller than its parent; along
+// that path frequencies do not decrease, so it ends right above the first child that is larger than the item, with
+// everything below back in place: the descent stops there instead.  A push is the mirror: a lane an ancestor. ----
+struct HeapLane {  // a lane's node in the tree below a hole: the hole is node 0, node t's children 2t + 1 and 2t + 2
+  int shift;       // its level, 1..5
+  int offset;      // heap index = ((hole + 1) << shift) + offset
+  bool in_tree;    // lanes 1..62
+};
+__device__ inline HeapLane heap_lane() {
+  const int t = (int)zh_lane();
+  HeapLane h;
+  h.shift = 31 - __clz(t + 1);
+  h.offset = t - (1 << h.shift);
+  h.in_tree = t >= 1 && t <= 62;
+  return h;
+}
+// heappush: the item goes in at `pos` (the heap's length before) and climbs while it is smaller than its parent.
+// Lane k holds ancestor k + 1 levels up; every lane of the wave calls, pos and item are the same in all.
+__device__ inline void heap_push(HuffWork& w, int pos, uint2 item) {
+  uint2* const hk = reinterpret_cast<uint2*>(w.hkey);
+  const int k = (int)zh_lane();
+  const int up = k < 9 ? (pos + 1) >> (k + 1) : 0;  // pos < 512
+  const uint2 key = hk[up ? up - 1 : 0];
+  const uint64_t smaller = __ballot(up != 0 && item.y < key.y);
+  const int climb = __ffsll((long long)~smaller) - 1;  // (frequencies do not increase towards the root: a run of ones)
+  if (k < climb) hk[((pos + 1) >> k) - 1] = key;        // the ancestors it passes, each a level down
+  if (k == 0) hk[((pos + 1) >> climb) - 1] = item;
+}
+// heappop; every lane of the wave calls.
+__device__ inline uint2 heap_pop(HuffWork& w, int& len, const HeapLane& hl) {
+  uint2* const hk = reinterpret_cast<uint2*>(w.hkey);
+  const unsigned lane = zh_lane();
+  --len;
+  const uint2 last = hk[len];
+  if (len == 0) return last;
+  const uint2 result = hk[0];
+  const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)last.y);
+  int pos = 0;
+  while (2 * pos + 1 < len) {
+    const int at = ((pos + 1) << hl.shift) + hl.offset;
+    const bool have = hl.in_tree && at < len, have_next = hl.in_tree && at + 1 < len;
+    const uint2 key = hk[have ? at : 0], next = hk[have_next ? at + 1 : 0];
+    const uint32_t fk = have ? key.y : 0xffffffffu, fn = have_next ? next.y : 0xffffffffu;
+    // bit t, t odd (a left child): its right neighbour is the one to take (heapqueue's `not (heap[childpos] <
+    // heap[rightpos])`); bit t: node t is larger than the item (so are the nodes that are not there)
+    const uint64_t right = __ballot(!(fk < fn)), larger = __ballot(fk > f);
+    // the smaller children all the way down (no decisions: five steps of bit arithmetic), then where the item stops: the
+    // first node of the path that is larger -- node numbers grow along a path --; what lies before it moves up
+    uint64_t path = 0;
+    int t = 0;
+#pragma unroll
+    for (int step = 0; step < 5; step++) {
+      t = 2 * t + 1 + (int)((right >> (2 * t + 1)) & 1ull);
+      path |= 1ull << t;
     }
+    const uint64_t stop = path & larger;
+    const bool done = stop != 0;
+    if (done) path &= (stop & (0ull - stop)) - 1ull;
+    t = path ? 63 - __clzll((long long)path) : 0;  // the new hole
+    if ((path >> lane) & 1ull) hk[(at - 1) >> 1] = key;
+    zh_wave_sync();
+    if (t) pos = __builtin_amdgcn_readlane(at, t);
+    if (done) break;
+  }
+  if (lane == 0) hk[pos] = last;
+  return result;
+}
+
+// deflate.nim:13-151 huffmanCodes, the reference's code symbol for symbol.  Every lane of the wave: what is a chain of
+// decisions (the heap, the length limiting's quicksort) runs on lane 0, everything around it -- which symbols are
+// used, the leaves' depths (pointer doubling over the parent links), lengths and canonical codes -- on the wave.
+// freq / codes / lens in LDS.  Returns the number of codes.
+#ifdef ZH_KPROF
+#define HPROF_MARK(i)                                               \
+  do {                                                              \
+    const unsigned long long hp_now = __builtin_readcyclecounter(); \
+    hp_acc[i] += hp_now - hp_t;                                     \
+    hp_t = hp_now;                                                  \
+  } while (0)
+#else
+#define HPROF_MARK(i) ((void)0)
+#endif
+__device__ int huffman_codes(const uint32_t* freq, int num_freq, int min_codes, int limit,
+                             uint16_t* codes, uint8_t* lens, HuffWork& w, bool prof = false) {
+  const unsigned lane = zh_lane();
+#ifdef ZH_KPROF
+  // tuning builds, the literal / length code: 0 used symbols, 1 leaves pushed, 2 merges, 3 depths, 4 the limit's
+  // histogram, 5 its sort, 6 its lengths, 7 lengths and codes out (slots 56..63)
+  unsigned long long hp_acc[8] = {}, hp_t = __builtin_readcyclecounter();
+#endif
+  constexpr int kPer = (kMaxSyms + 63) / 64;
+  // while the heap runs: the used symbols' frequencies, in symbol order, where the depths will be; the nodes' parents
+  // where round 4 kept the children (left and right are neighbours)
+  uint32_t* const leaf_f = reinterpret_cast<uint32_t*>(w.depth);
+  uint16_t* const par = w.left;
+  static_assert(2 * kMaxSyms * sizeof(uint16_t) >= kMaxSyms * sizeof(uint32_t) &&
+                    offsetof(HuffWork, right) == offsetof(HuffWork, left) + kMaxSyms * sizeof(uint16_t), "");
+  uint32_t f[kPer];
+  int leaf[kPer];  // the symbol's place among the used ones
+  int highest = 0, used = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int sidx = (int)lane + 64 * k;
+    f[k] = sidx < num_freq ? freq[sidx] : 0u;
+    const uint64_t m = __ballot(f[k] != 0u);
+    leaf[k] = used + __popcll(m & zh_lanemask_lt());
+    used += __popcll(m);
+    if (m) highest = 64 * k + 63 - __clzll((long long)m);
+  }
   const int num_codes = (highest > min_codes ? highest : min_codes) + 1;
-  for (int i = 0; i < num_codes; i++) {
+  for (int i = (int)lane; i < num_codes; i += 64) {
     codes[i] = 0;
     lens[i] = 0;
   }
-  if (used == 0) {  // :34-36
-    lens[0] = 1;
-    lens[1] = 1;
-  } else if (used == 1) {  // :37-45
-    for (int i = 0; i < num_freq; i++)
-      if (freq[i] != 0) {
-        lens[i] = 1;
-        lens[i == 0 ? 1 : 0] = 1;
-        break;
+  zh_wave_sync();
+  if (used <= 1) {  // :34-45
+    if (lane == 0) {
+      if (used == 0) {
+        lens[0] = 1;
+        lens[1] = 1;
+      } else {
+        lens[highest] = 1;
+        lens[highest == 0 ? 1 : 0] = 1;
       }
+    }
   } else {
-    int n = 0, hlen = 0;
-    for (int s = 0; s < num_freq; s++)
-      if (freq[s] > 0) {  // :54-55 push the leaves, in symbol order
-        w.symbol[n] = (int16_t)s;
-        w.order[n] = (uint16_t)n;
-        w.hkey[hlen++] = ((uint64_t)freq[s] << 16) | (uint64_t)n;
-        heap_sift_to_root(w, 0, hlen - 1);
-        n++;
+    const int n = used;
+#pragma unroll
+    for (int k = 0; k < kPer; k++)
+      if (f[k]) {
+        w.symbol[leaf[k]] = (int16_t)((int)lane + 64 * k);
+        w.order[leaf[k]] = (uint16_t)leaf[k];
+        leaf_f[leaf[k]] = f[k];
       }
-    int total = n;
-    while (hlen >= 2) {  // :57-63
-      const uint64_t l = heap_pop(w, hlen);
-      const uint64_t r = heap_pop(w, hlen);
-      w.left[total - n] = (uint16_t)(l & 0xffffu);
-      w.right[total - n] = (uint16_t)(r & 0xffffu);
-      w.hkey[hlen++] = (((l >> 16) + (r >> 16)) << 16) | (uint64_t)total;
-      heap_sift_to_root(w, 0, hlen - 1);
-      total++;
+    zh_wave_sync();
+    HPROF_MARK(0);
+    {
+      const HeapLane hl = heap_lane();
+      for (int i = 0; i < n; i++) {  // :54-55 push the leaves, in symbol order
+        heap_push(w, i, make_uint2((uint32_t)i, leaf_f[i]));
+        zh_wave_sync();
+      }
+      int hlen = n, total = n;
+      HPROF_MARK(1);
+      while (hlen >= 2) {  // :57-63
+        const uint2 l = heap_pop(w, hlen, hl);
+        zh_wave_sync();
+        const uint2 r = heap_pop(w, hlen, hl);
+        zh_wave_sync();
+        if (lane == 0) {
+          par[l.x] = (uint16_t)total;
+          par[r.x] = (uint16_t)total;
+        }
+        heap_push(w, hlen++, make_uint2((uint32_t)total, l.y + r.y));
+        zh_wave_sync();
+        total++;
+      }
+      if (lane == 0) par[total - 1] = (uint16_t)(total - 1);  // the root
     }
-    // :65-75 leaf depths.  Children always have smaller indices than their parent,
-    // so one descending sweep over the internal nodes replaces the recursion.
-    w.depth[total - 1] = 0;
-    for (int i = total - 1; i >= n; i--) {
-      const uint16_t d = (uint16_t)(w.depth[i] + 1);
-      w.depth[w.left[i - n]] = d;
-      w.depth[w.right[i - n]] = d;
+    zh_wave_sync();
+    HPROF_MARK(2);
+    // :65-75 leaf depths: dep += dep[par], par = par[par] until every node hangs on the root
+    const int nodes = 2 * n - 1;
+    for (int v = (int)lane; v < nodes; v += 64) w.depth[v] = v == nodes - 1 ? 0 : 1;
+    zh_wave_sync();
+    constexpr int kNodesPer = (2 * kMaxSyms + 63) / 64;
+    for (;;) {
+      uint32_t np[kNodesPer], nd[kNodesPer], upd = 0;
+#pragma unroll
+      for (int k = 0; k < kNodesPer; k++) {
+        const int v = (int)lane + 64 * k;
+        if (v < nodes) {
+          const uint32_t p1 = par[v];
+          if (p1 != (uint32_t)(nodes - 1) && p1 != (uint32_t)v) {
+            np[k] = par[p1];
+            nd[k] = (uint32_t)w.depth[v] + w.depth[p1];
+            upd |= 1u << k;
+          }
+        }
+      }
+      zh_wave_sync();  // (every lane has read before any lane writes)
+#pragma unroll
+      for (int k = 0; k < kNodesPer; k++) {
+        const int v = (int)lane + 64 * k;
+        if ((upd >> k) & 1u) {
+          w.depth[v] = (uint16_t)nd[k];
+          par[v] = (uint16_t)np[k];
+        }
+      }
+      zh_wave_sync();
+      if (!__ballot(upd != 0u)) break;
     }
-    int longest = 0;
-    for (int i = 0; i < n; i++)
-      if (w.depth[i] > longest) longest = w.depth[i];
-    if (longest > limit) {  // :78-131
+    HPROF_MARK(3);
+    uint32_t deepest = 0;
+    for (int v = (int)lane; v < n; v += 64) deepest = w.depth[v] > deepest ? w.depth[v] : deepest;
+    const int longest = __builtin_amdgcn_readlane((int)zh_wave_scan_max(deepest), 63);
+    if (longest > limit && lane == 0) {  // :78-131 (a decision a step: one lane)
       uint16_t* const stack_ = w.stack();
       int32_t* const hist_ = w.histogram();
       for (int i = 0; i <= longest; i++) hist_[i] = 0;
@@ -174,6 +311,7 @@ __device__ int huffman_codes(const uint32_t* freq, int num_freq, int min_codes, 
         hist_[j]--;
       }
       // :103-123 quickSort(nodes by depth), explicit stack instead of recursion
+      HPROF_MARK(4);
       int sp = 0;
       stack_[sp++] = 0;
       stack_[sp++] = (uint16_t)(n - 1);
@@ -202,6 +340,7 @@ __device__ int huffman_codes(const uint32_t* freq, int num_freq, int min_codes, 
         stack_[sp++] = (uint16_t)l;
         stack_[sp++] = (uint16_t)inr;
       }
+      HPROF_MARK(5);
       int code_len = 1;
       for (int k = 0; k < n; k++) {  // :125-131
         while (hist_[code_len] == 0) code_len++;
@@ -209,20 +348,17 @@ __device__ int huffman_codes(const uint32_t* freq, int num_freq, int min_codes, 
         hist_[code_len]--;
       }
     }
-    for (int i = 0; i < n; i++) lens[w.symbol[i]] = (uint8_t)w.depth[i];
+    zh_wave_sync();
+    HPROF_MARK(6);
+    for (int i = (int)lane; i < n; i += 64) lens[w.symbol[i]] = (uint8_t)w.depth[i];
   }
-  // :136-149 canonical codes, bit-reversed (wide counters)
-  uint32_t hist[16], next_code[16];
-  for (int i = 0; i < 16; i++) hist[i] = 0;
-  for (int i = 0; i < num_codes; i++) hist[lens[i]]++;
-  hist[0] = 0;
-  next_code[0] = 0;
-  for (int i = 1; i < 16; i++) next_code[i] = (next_code[i - 1] + hist[i - 1]) << 1;
-  for (int i = 0; i < num_codes; i++)
-    if (lens[i]) {
-      codes[i] = (uint16_t)(rev16(next_code[lens[i]] & 0xffffu) >> (16 - lens[i]));
-      next_code[lens[i]]++;
-    }
+  zh_wave_sync();
+  canonical_codes(lens, codes, num_codes);
+#ifdef ZH_KPROF
+  HPROF_MARK(7);
+  if (prof && lane == 0)
+    for (int i = 0; i < 8; i++) atomicAdd(&zh_kprof_slots[56 + i], hp_acc[i]);
+#endif
   return num_codes;
 }
 
@@ -404,35 +540,7 @@ __device__ int huffman_codes_fast(const uint32_t* freq, int num_freq, int min_co
     }
   }
   zh_wave_sync();
-  // ---- canonical codes, bit-reversed (deflate.nim:136-149), symbols of one length in symbol order ----
-  uint32_t l[kPer], hist[16];
-#pragma unroll
-  for (int L = 0; L < 16; L++) hist[L] = 0;
-#pragma unroll
-  for (int k = 0; k < kPer; k++) {
-    const int sidx = (int)lane + 64 * k;
-    l[k] = sidx < num_codes ? lens[sidx] : 0u;
-#pragma unroll
-    for (int L = 1; L < 16; L++) hist[L] += (uint32_t)__popcll(__ballot(l[k] == (uint32_t)L));
-  }
-  uint32_t next_code[16];
-  next_code[0] = 0;
-  hist[0] = 0;
-#pragma unroll
-  for (int L = 1; L < 16; L++) next_code[L] = (next_code[L - 1] + hist[L - 1]) << 1;
-#pragma unroll
-  for (int k = 0; k < kPer; k++) {
-    const int sidx = (int)lane + 64 * k;
-    uint32_t c = 0;
-#pragma unroll
-    for (int L = 1; L < 16; L++) {
-      const uint64_t m = __ballot(l[k] == (uint32_t)L);
-      if (l[k] == (uint32_t)L) c = next_code[L] + (uint32_t)__popcll(m & zh_lanemask_lt());
-      next_code[L] += (uint32_t)__popcll(m);
-    }
-    if (l[k]) codes[sidx] = (uint16_t)(rev16(c & 0xffffu) >> (16 - l[k]));
-  }
-  zh_wave_sync();
+  canonical_codes(lens, codes, num_codes);
   return num_codes;
 }
 
@@ -557,11 +665,15 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
         s_n[0] = nl;
         s_n[1] = nd;
       }
-    } else if (lane == 0) {
-      s_n[0] = huffman_codes(s_freq, ZH_NUM_LITLEN, 257, 15, s_codes, s_lens, s_work);
+    } else {
+      const int nl = huffman_codes(s_freq, ZH_NUM_LITLEN, 257, 15, s_codes, s_lens, s_work, true);
       KPROF_MARK(1);
-      s_n[1] = huffman_codes(s_freq + ZH_NUM_LITLEN, ZH_NUM_DIST, 2, 15, s_codes + 288, s_lens + 288, s_work);
+      const int nd = huffman_codes(s_freq + ZH_NUM_LITLEN, ZH_NUM_DIST, 2, 15, s_codes + 288, s_lens + 288, s_work);
       KPROF_MARK(2);
+      if (lane == 0) {
+        s_n[0] = nl;
+        s_n[1] = nd;
+      }
     }
     zh_wave_sync();
     const int n_litlen = s_n[0], n_dist = s_n[1];
@@ -633,7 +745,7 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
     // ---- the code of the code lengths (deflate.nim:362) ----
     if (contract) {
       huffman_codes_fast(s_clfreq, 19, 19, 7, s_clcodes, s_cllens, fwork, s_num);
-    } else if (lane == 0) {
+    } else {
       huffman_codes(s_clfreq, 19, 19, 7, s_clcodes, s_cllens, s_work);
     }
     zh_wave_sync();
@@ -719,19 +831,39 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   if (lane < 32) a.b_distcode[(size_t)b * 32 + lane] = lane < 30 ? (s_codes[288 + lane] | ((uint32_t)s_lens[288 + lane] << 16)) : 0u;
   for (uint32_t i = lane; i < ZH_HDR_WORDS; i += 64) a.b_hdr[(size_t)b * ZH_HDR_WORDS + i] = s_hdr[i];
 
-  // ---- encoded size of every fragment under these codes ----
+  // ---- encoded size of every fragment under these codes: histogram x code lengths, four fragments' loads in
+  // flight together (one after the other was a tenth of the kernel) ----
   uint64_t total = s_hdr_bits + s_lens[256];
-  for (uint32_t k = 0; k < bd.nfrag; k++) {
-    const uint32_t f = bd.first_frag + k;
-    const uint16_t* hist = a.f_hist + (size_t)f * ZH_HIST_STRIDE;
-    uint32_t acc = 0;
-    for (uint32_t i = lane; i < ZH_NUM_LITLEN + ZH_NUM_DIST; i += 64) {
-      const uint32_t l = i < ZH_NUM_LITLEN ? s_lens[i] : s_lens[288 + (i - ZH_NUM_LITLEN)];
-      acc += (uint32_t)hist[i] * l;
+  constexpr uint32_t kSymPer = (ZH_NUM_LITLEN + ZH_NUM_DIST + 63) / 64, kFr = 4;
+  uint32_t ll[kSymPer];  // this lane's symbols' lengths
+#pragma unroll
+  for (uint32_t j = 0; j < kSymPer; j++) {
+    const uint32_t i = lane + 64u * j;
+    ll[j] = i < ZH_NUM_LITLEN ? s_lens[i] : i < ZH_NUM_LITLEN + ZH_NUM_DIST ? s_lens[288 + (i - ZH_NUM_LITLEN)] : 0u;
+  }
+  for (uint32_t k0 = 0; k0 < bd.nfrag; k0 += kFr) {
+    uint32_t hv[kFr][kSymPer], extra[kFr];
+#pragma unroll
+    for (uint32_t u = 0; u < kFr; u++) {
+      const uint32_t f = bd.first_frag + (k0 + u < bd.nfrag ? k0 + u : bd.nfrag - 1u);
+      const uint16_t* hist = a.f_hist + (size_t)f * ZH_HIST_STRIDE;
+#pragma unroll
+      for (uint32_t j = 0; j < kSymPer; j++) {
+        const uint32_t i = lane + 64u * j;
+        hv[u][j] = hist[i < ZH_NUM_LITLEN + ZH_NUM_DIST ? i : 0u];
+      }
+      extra[u] = a.f_extra_bits[f];
     }
-    acc = zh_wave_sum(acc) + a.f_extra_bits[f];
-    if (lane == 0) a.f_bits[f] = acc;
-    total += acc;
+#pragma unroll
+    for (uint32_t u = 0; u < kFr; u++) {
+      if (k0 + u >= bd.nfrag) break;
+      uint32_t acc = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < kSymPer; j++) acc += hv[u][j] * ll[j];
+      acc = zh_wave_sum(acc) + extra[u];
+      if (lane == 0) a.f_bits[bd.first_frag + k0 + u] = acc;
+      total += acc;
+    }
   }
   if (lane == 0) a.b_bits[b] = total;
   KPROF_MARK(6);
@@ -906,8 +1038,9 @@ __global__ __launch_bounds__(64) void zh_huffman_probe_kernel(const uint32_t* __
   if (contract) {
     const int n = huffman_codes_fast(s_freq, num_freq, min_codes, limit, s_codes, s_lens, *reinterpret_cast<FastWork*>(&s_work), s_num);
     if (lane == 0) s_n = n;
-  } else if (lane == 0) {
-    s_n = huffman_codes(s_freq, num_freq, min_codes, limit, s_codes, s_lens, s_work);
+  } else {
+    const int n = huffman_codes(s_freq, num_freq, min_codes, limit, s_codes, s_lens, s_work);
+    if (lane == 0) s_n = n;
   }
   zh_wave_sync();
   const int n = s_n;
