@@ -329,4 +329,4 @@ def test_emu_split_inflate_edges(eng, inflate_mode):
 
 def test_emu_segmented_streams(eng, monkeypatch):
     pc.check_segmented(eng, 1024, monkeypatch, 2048)
-    pc.check_segmented(eng, 512, monkeypatch, 600)  # chains of more than two window groups
+    pc.check_segmented(eng, 1024, monkeypatch, 600)  # chains of more than two window groups

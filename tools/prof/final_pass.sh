@@ -37,6 +37,7 @@ timeout 900 python tools/gpu_fuzz_chain.py 600 20 2>&1 | tail -2 > $O/${T}_fuzz_
 (timeout 900 python tools/gpu_fuzz.py --mutations 10000 2>&1 | tail -3; timeout 900 python tools/gpu_fuzz.py --seg-mutations 4000 2>&1 | tail -2) > $O/${T}_fuzz_damaged.log 2>&1
 timeout 300 python tools/kprof.py --l1-parse 1 --buffers 1024 2>&1 | head -13 > $O/${T}_kprof_l1p.txt
 timeout 300 python tools/kprof.py --foreign 6 --buffers 1024 > $O/${T}_kprof_foreign6.txt 2>&1
+timeout 300 python tools/kprof.py --buffers 1024 > $O/${T}_kprof_exact.txt 2>&1   # (with the sub-phases of the Huffman replay)
 cd /tmp
 rm -rf /tmp/kt
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $O/${T}_rocprof_bench.log 2>&1

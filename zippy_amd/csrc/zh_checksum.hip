@@ -2,12 +2,14 @@
 // GF(2) / modular combination into whole-buffer checksums.
 //
 // Replaces crc.nim:29-72 (slice-by-8 / PCLMUL folding; gfx950 has no carry-less
-// multiply) and adler32.nim:19-63.  One 64-lane wave per piece:
+// multiply) and adler32.nim:19-63.  One 64-lane wave per piece (four waves a workgroup share the tables):
 //   * lane k owns the 16-byte column k of every 1 KiB row, so a row is one fully
 //     coalesced 1 KiB global load (global_load_dwordx4 per lane);
-//   * per row a lane does slice-by-4 over its 16 bytes (4 LDS table lookups per
-//     dword) and then "skips" the other lanes' 1008 bytes with one 4-lookup
-//     multiplication by x^(8*1008) mod P (tables Z0..Z3);
+//   * per row a lane takes its 16 bytes a dword at a time through THREE tables of 11 + 11 + 10 index bits
+//     (what advancing the state by four bytes does is linear in the state's bits: any split of the 32 will
+//     do; the kernel is bound by its LDS lookups -- a 64-lane lookup at random addresses is ~ 16 cycles of
+//     the CU's LDS --, so a dword is 3 of them instead of slice-by-4's 4) and then "skips" the other lanes'
+//     1008 bytes with one 4-lookup multiplication by x^(8*1008) mod P (tables Z0..Z3);
 //   * lanes are aligned to the end of the piece by one multiplication with
 //     x^(8*d) (d from a small table) and XOR-reduced across the wave.
 // Algorithmic traffic: each input byte is read once.
@@ -45,31 +47,40 @@ __host__ __device__ inline uint32_t gf2_xpow8(uint64_t n) {
 }
 
 struct ChecksumTables {
-  uint32_t t[4][256];   // slice-by-4 byte tables
+  uint32_t t0[256];     // one byte (crc.nim's table 0): heads and tails
+  uint32_t a[3][2048];  // four bytes: state ^ dword -> a[0][bits 0..10] ^ a[1][bits 11..21] ^ a[2][bits 22..31]
   uint32_t z[4][256];   // multiply a state by x^(8*1008): Zj[b] = (b << 8j) * x^(8*1008)
   uint32_t xz[2048];    // x^(8*j) mod P for j < 2048
 };
+constexpr uint32_t kWavesPerGroup = 4;
 
 }  // namespace
 
 
-__global__ __launch_bounds__(64) void zh_checksum_pieces_kernel(
+__global__ __launch_bounds__(64 * kWavesPerGroup) void zh_checksum_pieces_kernel(
     const uint8_t* __restrict__ d_data, const ZhPieceDesc* __restrict__ pieces, uint32_t npieces,
     const uint64_t* __restrict__ dyn_len, const ChecksumTables* __restrict__ tabs, int want_crc,
     int want_adler, uint32_t* __restrict__ out_crc, uint32_t* __restrict__ out_adler,
     uint32_t* __restrict__ out_len) {
-  __shared__ uint32_t s_t[4][256];
+  __shared__ uint32_t s_t0[256];
+  __shared__ uint32_t s_a0[2048], s_a1[2048], s_a2[1024];
   __shared__ uint32_t s_z[4][256];
   const unsigned lane = zh_lane();
   if (want_crc) {
-    for (unsigned i = lane; i < 1024; i += 64) {
-      (&s_t[0][0])[i] = (&tabs->t[0][0])[i];
-      (&s_z[0][0])[i] = (&tabs->z[0][0])[i];
+    for (unsigned i = threadIdx.x; i < 2048; i += 64 * kWavesPerGroup) {
+      s_a0[i] = tabs->a[0][i];
+      s_a1[i] = tabs->a[1][i];
+      if (i < 1024) {
+        s_a2[i] = tabs->a[2][i];
+        (&s_z[0][0])[i] = (&tabs->z[0][0])[i];
+      }
+      if (i < 256) s_t0[i] = tabs->t0[i];
     }
   }
-  zh_wave_sync();
+  __syncthreads();
 
-  for (uint32_t p = blockIdx.x; p < npieces; p += gridDim.x) {
+  // (a wave a piece; no barrier below)
+  for (uint32_t p = blockIdx.x * kWavesPerGroup + (threadIdx.x >> 6); p < npieces; p += gridDim.x * kWavesPerGroup) {
     const ZhPieceDesc pd = pieces[p];
     uint32_t len = pd.len;
     if (dyn_len) {
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(64) void zh_checksum_pieces_kernel(
     if (lane == 0) {
       for (uint32_t i = 0; i < head; i++) {
         uint32_t b = base[i];
-        if (want_crc) crc_head = s_t[0][(crc_head ^ b) & 255u] ^ (crc_head >> 8);
+        if (want_crc) crc_head = s_t0[(crc_head ^ b) & 255u] ^ (crc_head >> 8);
         sum_b += b;
         sum_ib += (uint64_t)i * b;
       }
@@ -112,9 +123,8 @@ __global__ __launch_bounds__(64) void zh_checksum_pieces_kernel(
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          uint32_t c = crc_rows ^ w[k];
-          crc_rows = s_t[3][c & 255u] ^ s_t[2][(c >> 8) & 255u] ^ s_t[1][(c >> 16) & 255u] ^
-                     s_t[0][c >> 24];
+          const uint32_t c = crc_rows ^ w[k];
+          crc_rows = s_a0[c & 2047u] ^ s_a1[(c >> 11) & 2047u] ^ s_a2[c >> 22];
         }
       }
       if (want_adler) {
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(64) void zh_checksum_pieces_kernel(
     if (t_end > tail) t_end = tail;
     for (uint32_t i = t_begin; i < t_end; i++) {
       uint32_t b = bp[((size_t)rows << 10) + i];
-      if (want_crc) crc_tail = s_t[0][(crc_tail ^ b) & 255u] ^ (crc_tail >> 8);
+      if (want_crc) crc_tail = s_t0[(crc_tail ^ b) & 255u] ^ (crc_tail >> 8);
       sum_b += b;
       sum_ib += (uint64_t)(head + (rows << 10) + i) * b;
     }
@@ -203,14 +213,19 @@ __global__ __launch_bounds__(64) void zh_checksum_combine_kernel(
       s1 = (s1 + s1b + 65520u) % 65521u;
     }
   }
-  for (unsigned d = 1; d < 64; d <<= 1) {  // (this) || (lane + d)
+  // x^(8 * bytes) for a right-hand side of `share << k` whole pieces, squared from level to level: a tree of
+  // gf2_xpow8() calls (twenty squarings and multiplications each) was most of this kernel; only the side that holds a
+  // buffer's short last piece still needs one
+  uint32_t x_whole = share == 1u ? x_full : gf2_xpow8((uint64_t)share << 15);
+  uint64_t whole = (uint64_t)share << 15;
+  for (unsigned d = 1; d < 64; d <<= 1, x_whole = gf2_mul(x_whole, x_whole), whole <<= 1) {  // (this) || (lane + d)
     const uint32_t crc_r = (uint32_t)__shfl((int)crc, (int)((lane + d) & 63u), 64);
     const uint64_t tot_r = (uint64_t)(uint32_t)__shfl((int)(uint32_t)total, (int)((lane + d) & 63u), 64) |
                            ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(total >> 32), (int)((lane + d) & 63u), 64) << 32);
     const uint32_t s1_r = (uint32_t)__shfl((int)(uint32_t)s1, (int)((lane + d) & 63u), 64);
     const uint32_t s2_r = (uint32_t)__shfl((int)(uint32_t)s2, (int)((lane + d) & 63u), 64);
     if ((lane & (2 * d - 1)) == 0 && lane + d < 64) {
-      if (want_crc) crc = gf2_mul(gf2_xpow8(tot_r), crc) ^ crc_r;
+      if (want_crc) crc = gf2_mul(tot_r == whole ? x_whole : gf2_xpow8(tot_r), crc) ^ crc_r;
       if (want_adler) {
         s2 = (s2 + s2_r + (tot_r % 65521u) * ((s1 + 65520u) % 65521u)) % 65521u;
         s1 = (s1 + s1_r + 65520u) % 65521u;
@@ -235,8 +250,16 @@ extern "C" const void* zh_checksum_tables(int device) {
   if (g_tabs_dev[device]) return g_tabs_dev[device];
   ChecksumTables* h = new ChecksumTables;
   constexpr zh::CrcTables ct = zh::make_crc_tables();
-  for (int k = 0; k < 4; k++)
-    for (int i = 0; i < 256; i++) h->t[k][i] = ct.t[k][i];
+  for (int i = 0; i < 256; i++) h->t0[i] = ct.t[0][i];
+  // what slice-by-4 does to a state: linear, so the contribution of any group of its bits is a table
+  auto four_bytes = [&](uint32_t c) {
+    return ct.t[3][c & 255u] ^ ct.t[2][(c >> 8) & 255u] ^ ct.t[1][(c >> 16) & 255u] ^ ct.t[0][c >> 24];
+  };
+  for (uint32_t v = 0; v < 2048; v++) {
+    h->a[0][v] = four_bytes(v);
+    h->a[1][v] = four_bytes(v << 11);
+    h->a[2][v] = v < 1024 ? four_bytes(v << 22) : 0u;
+  }
   const uint32_t x1008 = gf2_xpow8(1008);
   for (int j = 0; j < 4; j++)
     for (uint32_t b = 0; b < 256; b++) h->z[j][b] = gf2_mul(x1008, b << (8 * j));
@@ -266,8 +289,10 @@ extern "C" void zh_launch_checksum_pieces(hipStream_t stream, const void* tabs, 
                                           const uint64_t* dyn_len, int want_crc, int want_adler,
                                           uint32_t* out_crc, uint32_t* out_adler, uint32_t* out_len) {
   if (!npieces) return;
-  uint32_t grid = npieces < 8192u ? npieces : 8192u;
-  hipLaunchKernelGGL(zh_checksum_pieces_kernel, dim3(grid), dim3(64), 0, stream, d_data, pieces,
+  // (25 KiB of tables a workgroup: six of them a CU, and each takes them from L2 once)
+  uint32_t grid = (npieces + kWavesPerGroup - 1u) / kWavesPerGroup;
+  if (grid > 3072u) grid = 3072u;
+  hipLaunchKernelGGL(zh_checksum_pieces_kernel, dim3(grid), dim3(64 * kWavesPerGroup), 0, stream, d_data, pieces,
                      npieces, dyn_len, (const ChecksumTables*)tabs, want_crc, want_adler, out_crc,
                      out_adler, out_len);
 }

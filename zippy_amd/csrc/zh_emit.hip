@@ -85,18 +85,14 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   const uint32_t nmatch = a.f_nmatch[f];
   const uint32_t spill = a.f_spill[f];  // bytes covered by a match begun in the previous fragment
   uint32_t mnext = 0;                   // first match that starts at or behind the current chunk
-  // cover [p, e) clipped to the chunk [c0, c1), as bits relative to c0
+  // [p, e) is inside a match: noted as the two places where "inside" flips, clipped to the chunk [c0, c1), as bits
+  // relative to c0 (matches do not overlap and a match covers at least two bytes behind its start: no two flips
+  // share a bit); build_chunk turns the flips into the bitmap with a prefix parity
   auto cover = [&](uint32_t p, uint32_t e, uint32_t c0, uint32_t c1) {
     if (p < c0) p = c0;
-    if (e > c1) e = c1;
-    if (p >= e) return;
-    p -= c0;
-    e -= c0;
-    for (uint32_t w = p >> 5; w <= (e - 1) >> 5; w++) {
-      const uint32_t lo = w == (p >> 5) ? (p & 31u) : 0u;
-      const uint32_t hi = w == ((e - 1) >> 5) ? ((e - 1) & 31u) : 31u;
-      atomicOr(&s_cover[w], (0xffffffffu >> (31u - hi)) & (0xffffffffu << lo));
-    }
+    if (p >= e || p >= c1) return;
+    atomicOr(&s_cover[(p - c0) >> 5], 1u << ((p - c0) & 31u));
+    if (e < c1) atomicOr(&s_cover[(e - c0) >> 5], 1u << ((e - c0) & 31u));
   };
   auto build_chunk = [&](uint32_t c0) {
     const uint32_t c1 = c0 + kChunk < n ? c0 + kChunk : n;
@@ -132,6 +128,20 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
       mnext += cnt;
       if (cnt < 64u) break;
     }
+    zh_wave_sync();
+    // flips -> "inside": bit i = parity of the flips at or before i; a lane the words `lane` and `lane + 64`
+    static_assert(kChunk / 32 == 128, "two bitmap words a lane");
+    uint32_t x0 = s_cover[lane], x1 = s_cover[lane + 64u];
+#pragma unroll
+    for (uint32_t sh = 1; sh < 32; sh <<= 1) {
+      x0 ^= x0 << sh;
+      x1 ^= x1 << sh;
+    }
+    const uint64_t odd0 = __ballot((x0 >> 31) != 0u), odd1 = __ballot((x1 >> 31) != 0u);
+    if (__popcll(odd0 & zh_lanemask_lt()) & 1) x0 = ~x0;
+    if ((__popcll(odd0) + __popcll(odd1 & zh_lanemask_lt())) & 1) x1 = ~x1;
+    s_cover[lane] = x0;
+    s_cover[lane + 64u] = x1;
     zh_wave_sync();
   };
 

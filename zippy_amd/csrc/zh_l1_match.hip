@@ -503,33 +503,63 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   KPROF_MARK(3);
   const uint32_t nmatch = s_nmatch;
 
-  // ---- coverage bitmap + match histograms (lanes over matches) ----
+  // ---- match histograms, and the coverage bitmap as the places where "inside a match" flips: a match's first
+  // byte and the byte behind its last (xor: a match that starts where the one before it ends flips the same bit
+  // twice).  The next 64 matches' fields are asked for before these are filed (clamped, unconditional loads) ----
   uint32_t extra_bits = 0, covered = 0;
-  for (uint32_t m = lane; m < nmatch; m += 64) {
-    const uint32_t p = m_pos[m], l = m_len[m], o = m_off[m];
-    const uint32_t li = zh_len_code(l), di = zh_dist_code(o);
-    atomicAdd(&s_hist[257 + li], 1u);
-    atomicAdd(&s_hist[ZH_NUM_LITLEN + di], 1u);
-    extra_bits += zh_len_extra_bits(li) + zh_dist_extra_bits(di);
-    covered += l;
-    const uint32_t e = p + l;  // set bits [p, e)
-    for (uint32_t w = p >> 5; w <= (e - 1) >> 5; w++) {
-      const uint32_t lo = w == (p >> 5) ? (p & 31u) : 0u;
-      const uint32_t hi = w == ((e - 1) >> 5) ? ((e - 1) & 31u) : 31u;
-      const uint32_t mask = (0xffffffffu >> (31u - hi)) & (0xffffffffu << lo);
-      atomicOr(&s_cover[w], mask);
+  {
+    const uint32_t mlast = nmatch ? nmatch - 1u : 0u;
+    auto at = [&](uint32_t m) { return m < nmatch ? m : mlast; };
+    uint32_t pq = m_pos[at(lane)], lq = m_len[at(lane)], oq = m_off[at(lane)];
+    for (uint32_t m = lane; m - lane < nmatch; m += 64) {
+      const uint32_t p = pq, l = lq, o = oq;
+      pq = m_pos[at(m + 64u)];
+      lq = m_len[at(m + 64u)];
+      oq = m_off[at(m + 64u)];
+      if (m < nmatch) {
+        const uint32_t li = zh_len_code(l), di = zh_dist_code(o);
+        atomicAdd(&s_hist[257 + li], 1u);
+        atomicAdd(&s_hist[ZH_NUM_LITLEN + di], 1u);
+        extra_bits += zh_len_extra_bits(li) + zh_dist_extra_bits(di);
+        covered += l;
+        atomicXor(&s_cover[p >> 5], 1u << (p & 31u));
+        if (p + l < kCntWords * 32u) atomicXor(&s_cover[(p + l) >> 5], 1u << ((p + l) & 31u));
+      }
     }
   }
   zh_wave_sync();
-  // ---- literal histogram (lanes over positions) ----
-  for (uint32_t base = 0; base < n; base += 256) {  // four positions per lane and pass
-    const uint32_t p = base + 4u * lane;
-    if (p < n) {
-      const uint32_t w = ld32(p);
-      const uint32_t cov = s_cover[p >> 5] >> (p & 31u);  // p is a multiple of 4: same word for all four
+  // flips -> "inside": bit i = parity of the flips at or before i; 64 words a turn, a word a lane
+  {
+    uint32_t carry = 0;  // parity of all flips before this turn's words
+    for (uint32_t w0 = 0; w0 < kCntWords && w0 * 32u < n; w0 += 64) {
+      uint32_t x = s_cover[w0 + lane];
 #pragma unroll
-      for (uint32_t k = 0; k < 4; k++)
-        if (p + k < n && !((cov >> k) & 1u)) atomicAdd(&s_hist[(w >> (8u * k)) & 255u], 1u);
+      for (uint32_t sh = 1; sh < 32; sh <<= 1) x ^= x << sh;
+      const uint64_t odd = __ballot((x >> 31) != 0u);
+      if ((carry + (uint32_t)__popcll(odd & zh_lanemask_lt())) & 1u) x = ~x;
+      s_cover[w0 + lane] = x;
+      carry += (uint32_t)__popcll(odd);
+    }
+  }
+  zh_wave_sync();
+  // ---- literal histogram (lanes over positions): four positions a lane and pass, four passes' source words in
+  // flight together ----
+  for (uint32_t base = 0; base < n; base += 1024) {
+    uint32_t wq[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {
+      const uint32_t p = base + 256u * u + 4u * lane;
+      wq[u] = p < n ? ld32(p) : 0u;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {
+      const uint32_t p = base + 256u * u + 4u * lane;
+      if (p < n) {
+        const uint32_t cov = s_cover[p >> 5] >> (p & 31u);  // p is a multiple of 4: same word for all four
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+          if (p + k < n && !((cov >> k) & 1u)) atomicAdd(&s_hist[(wq[u] >> (8u * k)) & 255u], 1u);
+      }
     }
   }
   extra_bits = zh_wave_sum(extra_bits);
