@@ -999,14 +999,20 @@ def check_stored_chain_segmented(eng, monkeypatch, nblocks=70, text_bytes=600000
         c = zlib.compressobj(6, zlib.DEFLATED, -15)
         return c.compress(data) + (c.flush() if last else c.flush(zlib.Z_FULL_FLUSH))
     stored = b"".join(bytes([0]) + struct.pack("<HH", 65535, 0) + noise[o:o + 65535] for o in range(0, len(noise), 65535))
-    for blob, want in ((dyn(text, False) + stored + dyn(text[::-1], True), text + noise + text[::-1]),
-                       (stored + dyn(text, True), noise + text)):
+    last = bytes([1]) + struct.pack("<HH", 777, 777 ^ 0xffff) + noise[:777]
+    for blob, want, holds in ((dyn(text, False) + stored + dyn(text[::-1], True), text + noise + text[::-1], None),
+                              (stored + dyn(text, True), noise + text, None),
+                              # nothing but stored blocks (incompressible data): chained stored blocks are segment
+                              # starts too, so this stream IS decoded by many workgroups
+                              (stored + last, noise + noise[:777], True)):
         assert zlib.decompress(blob, -15) == want
         before = eng.segment_stats()
         outs, sts = eng.uncompress_batch([blob], oracle.dfDeflate)
         assert sts == [0] and outs[0] == want
         cut, held = eng.segment_stats()
         assert cut - before[0] == 1, "the stream was not cut into segments"
+        if holds:
+            assert held - before[1] == 1, "a chain of stored blocks left to one workgroup"
     for k in ("ZH_SEG_MIN", "ZH_SEG_BYTES", "ZH_SEG_SETUP"):
         monkeypatch.delenv(k)
 

@@ -481,9 +481,10 @@ def test_gpu_one_gib_stream_decodes_segment_wise():
     res = gpu_big_buffer.run(1024, level=1, with_oracle=False, with_zlib=False)
     assert res["trailer_ok"] and res["decoded_segment_wise"], res
     assert max(res["uncompress_s"][1:]) < 0.5, res  # (20 ms on an MI355X; one workgroup takes 2 s)
-    # the kinds that have no block starts to find: 1 GiB of random bytes is 16 K stored blocks, which one workgroup takes
-    # 64 headers and eight blocks' bytes at a time (193 ms with a header and a block a round); literals only (level -2)
+    # 1 GiB of random bytes is 16 K stored blocks: chained stored blocks are segment starts too (zh_seg_find_kernel), so
+    # the chain is read and copied by many workgroups (17 ms; one workgroup took 74 ms 64 headers and four blocks' bytes
+    # at a time, 193 ms with a header and a block a round); literals only (level -2)
     rand = gpu_big_buffer.run(1024, level=1, with_oracle=False, with_zlib=False, kind="rand")
-    assert rand["trailer_ok"] and min(rand["uncompress_s"]) < 0.1, rand
+    assert rand["trailer_ok"] and rand["decoded_segment_wise"] and min(rand["uncompress_s"]) < 0.05, rand
     lits = gpu_big_buffer.run(1024, level=-2, with_oracle=False, with_zlib=False)
     assert lits["trailer_ok"] and min(lits["uncompress_s"]) < 0.2, lits

@@ -51,6 +51,7 @@ struct ChecksumTables {
   uint32_t a[3][2048];  // four bytes: state ^ dword -> a[0][bits 0..10] ^ a[1][bits 11..21] ^ a[2][bits 22..31]
   uint32_t z[4][256];   // multiply a state by x^(8*1008): Zj[b] = (b << 8j) * x^(8*1008)
   uint32_t xz[2048];    // x^(8*j) mod P for j < 2048
+  uint32_t zp[4][256];  // multiply a state by x^(8*32768), a whole piece: the combine's step
 };
 constexpr uint32_t kWavesPerGroup = 4;
 
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void zh_checksum_pieces_kernel
 __global__ __launch_bounds__(64) void zh_checksum_combine_kernel(
     const ZhBufDesc* __restrict__ bufs, uint32_t nbufs, const uint32_t* __restrict__ piece_crc,
     const uint32_t* __restrict__ piece_adler, const uint32_t* __restrict__ piece_len, int want_crc,
-    int want_adler, uint32_t* __restrict__ buf_crc, uint32_t* __restrict__ buf_adler) {
+    int want_adler, uint32_t* __restrict__ buf_crc, uint32_t* __restrict__ buf_adler,
+    const ChecksumTables* __restrict__ tabs) {
   const uint32_t i = blockIdx.x;
   const unsigned lane = threadIdx.x & 63u;
   const ZhBufDesc b = bufs[i];
@@ -197,20 +199,46 @@ __global__ __launch_bounds__(64) void zh_checksum_combine_kernel(
   uint32_t crc = 0;
   uint64_t s1 = 1, s2 = 0, total = 0;
   const uint32_t x_full = gf2_xpow8(32768);
-  for (; k < k_end; k++) {
-    const uint32_t p = b.first_piece + k;
-    const uint32_t len = piece_len[p];
-    if (len == 0) continue;
-    total += len;
-    if (want_crc) {
-      const uint32_t x = len == 32768u ? x_full : gf2_xpow8(len);
-      crc = gf2_mul(x, crc) ^ piece_crc[p];
+  // (a lane with many pieces -- one buffer of GiBs -- folds them as a chain of table look-ups: the table in LDS, a
+  // hundred cycles a link instead of a trip to L2)
+  __shared__ uint32_t s_zp[4][256];
+  const bool in_lds = want_crc && share > 4u;
+  if (in_lds)
+    for (uint32_t t = lane; t < 1024u; t += 64u) (&s_zp[0][0])[t] = (&tabs->zp[0][0])[t];
+  zh_wave_sync();
+  // (eight pieces' lengths and checksums asked for at once: a piece a trip to L2 was what one buffer of GiBs waited for)
+  constexpr uint32_t kAhead = 8;
+  for (; k < k_end; k += kAhead) {
+    uint32_t lens[kAhead], crcs[kAhead], adlers[kAhead];
+#pragma unroll
+    for (uint32_t u = 0; u < kAhead; u++) {
+      const uint32_t p = b.first_piece + (k + u < k_end ? k + u : k_end - 1u);
+      lens[u] = piece_len[p];
+      crcs[u] = want_crc ? piece_crc[p] : 0u;
+      adlers[u] = want_adler ? piece_adler[p] : 0u;
     }
-    if (want_adler) {
-      const uint32_t a = piece_adler[p];
-      const uint64_t s1b = a & 0xffffu, s2b = a >> 16;
-      s2 = (s2 + s2b + (uint64_t)(len % 65521u) * ((s1 + 65520u) % 65521u)) % 65521u;
-      s1 = (s1 + s1b + 65520u) % 65521u;
+#pragma unroll
+    for (uint32_t u = 0; u < kAhead; u++) {
+      const uint32_t len = k + u < k_end ? lens[u] : 0u;
+      if (len == 0) continue;
+      total += len;
+      if (want_crc) {
+        // (a whole piece behind: four table entries instead of a 32-step multiplication -- one buffer of 4 GiB is
+        // 2048 pieces a lane)
+        if (len == 32768u && in_lds)
+          crc = s_zp[0][crc & 255u] ^ s_zp[1][(crc >> 8) & 255u] ^ s_zp[2][(crc >> 16) & 255u] ^ s_zp[3][crc >> 24];
+        else if (len == 32768u)
+          crc = tabs->zp[0][crc & 255u] ^ tabs->zp[1][(crc >> 8) & 255u] ^ tabs->zp[2][(crc >> 16) & 255u] ^ tabs->zp[3][crc >> 24];
+        else
+          crc = gf2_mul(gf2_xpow8(len), crc);
+        crc ^= crcs[u];
+      }
+      if (want_adler) {
+        const uint32_t a = adlers[u];
+        const uint64_t s1b = a & 0xffffu, s2b = a >> 16;
+        s2 = (s2 + s2b + (uint64_t)(len % 65521u) * ((s1 + 65520u) % 65521u)) % 65521u;
+        s1 = (s1 + s1b + 65520u) % 65521u;
+      }
     }
   }
   // x^(8 * bytes) for a right-hand side of `share << k` whole pieces, squared from level to level: a tree of
@@ -263,6 +291,9 @@ extern "C" const void* zh_checksum_tables(int device) {
   const uint32_t x1008 = gf2_xpow8(1008);
   for (int j = 0; j < 4; j++)
     for (uint32_t b = 0; b < 256; b++) h->z[j][b] = gf2_mul(x1008, b << (8 * j));
+  const uint32_t x32768 = gf2_xpow8(32768);
+  for (int j = 0; j < 4; j++)
+    for (uint32_t b = 0; b < 256; b++) h->zp[j][b] = gf2_mul(x32768, b << (8 * j));
   uint32_t x = 0x80000000u;
   const uint32_t x8 = 0x00800000u;
   for (int j = 0; j < 2048; j++) {
@@ -297,12 +328,12 @@ extern "C" void zh_launch_checksum_pieces(hipStream_t stream, const void* tabs, 
                      out_adler, out_len);
 }
 
-extern "C" void zh_launch_checksum_combine(hipStream_t stream, const ZhBufDesc* bufs, uint32_t nbufs,
+extern "C" void zh_launch_checksum_combine(hipStream_t stream, const void* tabs, const ZhBufDesc* bufs, uint32_t nbufs,
                                            const uint32_t* piece_crc, const uint32_t* piece_adler,
                                            const uint32_t* piece_len, int want_crc, int want_adler,
                                            uint32_t* buf_crc, uint32_t* buf_adler) {
   if (!nbufs) return;
   hipLaunchKernelGGL(zh_checksum_combine_kernel, dim3(nbufs), dim3(64), 0, stream, bufs,
                      nbufs, piece_crc, piece_adler, piece_len, want_crc, want_adler, buf_crc,
-                     buf_adler);
+                     buf_adler, (const ChecksumTables*)tabs);
 }

@@ -154,6 +154,8 @@ struct ZhSegArgs {
   uint64_t* start_bit;          // [nsegs] first bit of the segment's first block, or kSegNone
   uint64_t* start2_bit;         // [nsegs] the next position of the segment that reads like a block's start (the probe of
                                 //   zh_inflate_tokens_kernel falls back on it), or kSegNone
+  uint64_t* stored_bit;         // [nsegs] first bit of the segment's first STORED block that is followed by another (a start
+                                //   only where the segment has no compressed block's: zh_seg_check's merge), or kSegNone
   uint64_t* held_start;         // [nsegs] a found start that zh_seg_decide_kernel's grouping set aside (a group keeps its first
                                 //   start's decoder): a repair round gets it back (kSegNone: none)
   uint64_t* end_bit;            // [nsegs] the block boundary the tokens kernel stopped at

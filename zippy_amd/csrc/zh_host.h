@@ -31,7 +31,7 @@ void zh_launch_checksum_pieces(hipStream_t, const void* tabs, const uint8_t* d_d
                                const ZhPieceDesc* pieces, uint32_t npieces, const uint64_t* dyn_len,
                                int want_crc, int want_adler, uint32_t* out_crc, uint32_t* out_adler,
                                uint32_t* out_len);
-void zh_launch_checksum_combine(hipStream_t, const ZhBufDesc* bufs, uint32_t nbufs,
+void zh_launch_checksum_combine(hipStream_t, const void* tabs, const ZhBufDesc* bufs, uint32_t nbufs,
                                 const uint32_t* piece_crc, const uint32_t* piece_adler,
                                 const uint32_t* piece_len, int want_crc, int want_adler,
                                 uint32_t* buf_crc, uint32_t* buf_adler);

@@ -154,7 +154,7 @@ static int checksum_host(zh_ctx* ctx, const void* const* srcs, const size_t* len
   zh_launch_checksum_pieces(s, ctx->cktabs, d.p, carve<ZhPieceDesc>(base, o_p), (uint32_t)np, nullptr, want_crc,
                             !want_crc, carve<uint32_t>(base, o_pc), carve<uint32_t>(base, o_pa),
                             carve<uint32_t>(base, o_pl));
-  zh_launch_checksum_combine(s, carve<ZhBufDesc>(base, o_b), (uint32_t)n, carve<uint32_t>(base, o_pc),
+  zh_launch_checksum_combine(s, ctx->cktabs, carve<ZhBufDesc>(base, o_b), (uint32_t)n, carve<uint32_t>(base, o_pc),
                              carve<uint32_t>(base, o_pa), carve<uint32_t>(base, o_pl), want_crc, !want_crc,
                              carve<uint32_t>(base, o_oc), carve<uint32_t>(base, o_oa));
   ZH_HIP(ctx, hipMemcpyAsync(out, base + (want_crc ? o_oc : o_oa), n * 4, hipMemcpyDeviceToHost, s));

@@ -63,10 +63,11 @@ constexpr uint32_t kFindSlots = kSegFindSlots;  // candidates it can hand on (me
                                         // average, 700 at most; with 64 slots a batch in six of a stream of literals dropped some --
                                         // among them block starts that every segment of a 4 MiB block depends on)
 constexpr uint32_t kWin = 32768;
+constexpr uint32_t kSegCandStored = 0x80000000u;  // a queued candidate that reads like a stored block's header
 
 // A batch of the search: 65536 bit positions and the 74 bits of header behind the last of them,
 // staged in LDS as dwords.
-constexpr uint32_t kFindStage = kFindBatch / 32u + 8u;
+constexpr uint32_t kFindStage = kFindBatch / 32u + 8u;  // (a thread reads five dwords from its 64 positions' first)
 
 // the 32 bits at bit `rel` of the staged bytes
 __device__ __forceinline__ uint32_t seg_peek(const uint32_t* s_buf, uint32_t rel) {
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(kFindThreads) void zh_seg_find_kernel(const uint8_t
   if (batch == 0 && tid == 0) {  // the stream's first block: behind the container header, exact
     g.start_bit[sid] = first && live ? (uint64_t)a.body_pos[bid] * 8 : kSegNone;
     g.start2_bit[sid] = kSegNone;
+    g.stored_bit[sid] = kSegNone;
   }
   if (first || !live) return;
   const ZhBufDesc bd = a.bufs[bid];
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(kFindThreads) void zh_seg_find_kernel(const uint8_t
     const uint32_t mine = (part * kFindThreads + tid) * 64u;
     if (mine >= left) break;
     const uint32_t r = rel0 + mine, bi = r >> 5;
-    const uint32_t d0 = s_buf[bi], d1 = s_buf[bi + 1u], d2 = s_buf[bi + 2u], d3 = s_buf[bi + 3u];
+    const uint32_t d0 = s_buf[bi], d1 = s_buf[bi + 1u], d2 = s_buf[bi + 2u], d3 = s_buf[bi + 3u], d4 = s_buf[bi + 4u];
     const uint32_t e0 = zh_alignbit(d1, d0, r), e1 = zh_alignbit(d2, d1, r), e2 = zh_alignbit(d3, d2, r);
     auto x = [&](uint32_t k) -> uint64_t {  // bit j = stream bit r + j + k
       return (uint64_t)zh_alignbit(e1, e0, k) | ((uint64_t)zh_alignbit(e2, e1, k) << 32);
@@ -305,6 +307,24 @@ __global__ __launch_bounds__(kFindThreads) void zh_seg_find_kernel(const uint8_t
         KPROF_COUNT(6, 1);
         const uint32_t at = atomicAdd(&s_ncand, 1u);
         if (at < kFindSlots) s_cand[at] = off;  // (a full queue drops candidates: a later block start will do)
+      }
+    }
+    // Stored blocks (inflate.nim:252-266; incompressible stretches are chains of them, 16 K a GiB): a header at a byte
+    // boundary -- BFINAL = 0, BTYPE = 0 in a byte's low bits, then LEN and its complement -- is a candidate too (the
+    // check kernel wants another one behind its bytes).  The eight byte boundaries among the 64 positions out of the
+    // 104 bits already in registers.
+    {
+      const uint32_t skip = (8u - (r & 7u)) & 7u;  // bits to the first byte boundary
+      const uint32_t e3 = zh_alignbit(d4, d3, r);
+      const uint32_t y[4] = {zh_alignbit(e1, e0, skip), zh_alignbit(e2, e1, skip), zh_alignbit(e3, e2, skip), e3 >> skip};
+      auto byte_at = [&](uint32_t k) -> uint32_t { return (y[k >> 2] >> (8u * (k & 3u))) & 255u; };
+#pragma unroll
+      for (uint32_t t = 0; t < 8; t++) {
+        const uint32_t lenv = byte_at(t + 1u) | (byte_at(t + 2u) << 8), nlen = byte_at(t + 3u) | (byte_at(t + 4u) << 8);
+        if ((byte_at(t) & 7u) == 0u && (lenv ^ nlen) == 0xffffu && mine + skip + 8u * t < left) {
+          const uint32_t at = atomicAdd(&s_ncand, 1u);
+          if (at < kFindSlots) s_cand[at] = (mine + skip + 8u * t) | kSegCandStored;
+        }
       }
     }
     KPROF_MARK(2);
@@ -441,6 +461,19 @@ __device__ bool seg_lengths_ok_wave(const uint8_t* src, uint64_t len, uint64_t p
 // A segment keeps the TWO lowest positions that read like a block's start: what reads like one and is none (bits of
 // a payload: about one a GiB, many more in streams of literals only) would otherwise hide the block start behind it
 // in the same segment -- and with blocks of many segments that start is the one every segment of its block needs.
+// A stored block's header at bit p (a byte boundary) with another stored block's header behind its bytes: LEN and
+// its complement twice over, 2^-36 of random positions.  (The last stored block of a chain, with a compressed block
+// or the stream's end behind it, is not taken: whoever decodes the chain gets there.)
+__device__ inline bool seg_stored_chain_ok(const uint8_t* src, uint64_t len, uint64_t p) {
+  const uint64_t q = p >> 3;
+  if (q + 10u > len) return false;
+  const uint32_t lenv = src[q + 1] | ((uint32_t)src[q + 2] << 8), nlen = src[q + 3] | ((uint32_t)src[q + 4] << 8);
+  if ((src[q] & 7u) != 0u || (lenv ^ nlen) != 0xffffu) return false;
+  const uint64_t q2 = q + 5u + lenv;
+  if (q2 + 5u > len) return false;
+  const uint32_t len2 = src[q2 + 1] | ((uint32_t)src[q2 + 2] << 8), nlen2 = src[q2 + 3] | ((uint32_t)src[q2 + 4] << 8);
+  return (src[q2] & 6u) == 0u && (len2 ^ nlen2) == 0xffffu;
+}
 __device__ __forceinline__ void seg_note_start(const ZhSegArgs& g, uint32_t sid, uint64_t p) {
   const uint64_t old = atomicMin((unsigned long long*)&g.start_bit[sid], (unsigned long long)p);
   if (old != p) atomicMin((unsigned long long*)&g.start2_bit[sid], (unsigned long long)(old > p ? old : p));
@@ -460,7 +493,12 @@ __global__ __launch_bounds__(64) void zh_seg_check_kernel(const uint8_t* __restr
 #ifdef ZH_XCHECK
   if (serial) {  // a thread per candidate (the test build's cross-check)
     for (uint32_t c = lane; c < nc; c += 64u) {
-      const uint64_t p = base + g.cand_off[(size_t)w * kFindSlots + c];
+      const uint32_t cand = g.cand_off[(size_t)w * kFindSlots + c];
+      const uint64_t p = base + (cand & ~kSegCandStored);
+      if (cand & kSegCandStored) {
+        if (seg_stored_chain_ok(d_src + bd.src_off, len, p)) atomicMin((unsigned long long*)&g.stored_bit[sid], (unsigned long long)p);
+        continue;
+      }
       if (p >= *(volatile uint64_t*)&g.start2_bit[sid]) continue;  // (two lower positions have passed already)
       if (seg_lengths_ok(d_src + bd.src_off, len, p)) seg_note_start(g, sid, p);
     }
@@ -472,8 +510,15 @@ __global__ __launch_bounds__(64) void zh_seg_check_kernel(const uint8_t* __restr
   KPROF_MARK(0);
   for (uint32_t c0 = 0; c0 < nc; c0 += 64u) {
     const uint32_t mine = c0 + lane < nc ? g.cand_off[(size_t)w * kFindSlots + c0 + lane] : 0u;
+    // (stored-block candidates: a lane each)
+    if (c0 + lane < nc && (mine & kSegCandStored)) {
+      const uint64_t p = base + (mine & ~kSegCandStored);
+      if (seg_stored_chain_ok(d_src + bd.src_off, len, p)) atomicMin((unsigned long long*)&g.stored_bit[sid], (unsigned long long)p);
+    }
     for (uint32_t c = 0; c < 64u && c0 + c < nc; c++) {
-      const uint64_t p = base + (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)c);
+      const uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)c);
+      if (cand & kSegCandStored) continue;
+      const uint64_t p = base + cand;
       if (p >= zh_bcast64(*(volatile uint64_t*)&g.start2_bit[sid])) continue;  // (two lower positions have passed already)
       KPROF_COUNT(3, 1);
       if (seg_lengths_ok_wave(d_src + bd.src_off, len, p, s_lut, s_hdr)) {
@@ -484,6 +529,15 @@ __global__ __launch_bounds__(64) void zh_seg_check_kernel(const uint8_t* __restr
   }
   KPROF_MARK(1);
   KPROF_FLUSH(16, 8);
+}
+
+// A segment with no compressed block's start takes its first chained stored block's: inside a chain of stored blocks
+// (incompressible data) every segment then has a decoder and a writer of its own instead of one workgroup copying the
+// whole chain.  Compressed blocks' starts come first: the segments behind a long block take their sub-starts from its
+// tables.
+__global__ __launch_bounds__(256) void zh_seg_stored_starts_kernel(ZhSegArgs g) {
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k < g.nsegs && g.start_bit[k] == kSegNone) g.start_bit[k] = g.stored_bit[k];
 }
 
 // One wave per stream: is it worth it, and with how many decoders?  Fewer than four found starts
@@ -905,6 +959,7 @@ extern "C" void zh_launch_seg_check(hipStream_t stream, const uint8_t* d_src, Zh
   const int serial = 0;
 #endif
   hipLaunchKernelGGL(zh_seg_check_kernel, dim3(g.nfind), dim3(64), 0, stream, d_src, a, g, serial);
+  hipLaunchKernelGGL(zh_seg_stored_starts_kernel, dim3((g.nsegs + 255u) / 256u), dim3(256), 0, stream, g);
 }
 // ZH_SEG_FAKE_START=<bit> (tests): bits that read like a block header and are none happen in any long stream's
 // payload, about once a GiB -- too rare for a test to wait for.  This plants one: the segment whose search range

@@ -341,7 +341,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
                                 want_adler, p->piece_crc, p->piece_adler, p->piece_len);
       if (!aside) prof_mark(p, "zh_checksum_combine_kernel");
       else if (p->k_aux_used) ZH_HIP(ctx, hipEventRecord(p->k_aux[1], cs));
-      zh_launch_checksum_combine(cs, p->d_bufs, (uint32_t)p->n, p->piece_crc, p->piece_adler,
+      zh_launch_checksum_combine(cs, ctx->cktabs, p->d_bufs, (uint32_t)p->n, p->piece_crc, p->piece_adler,
                                  p->piece_len, want_crc, want_adler, p->buf_crc, p->buf_adler);
       if (aside) {
         if (p->k_aux_used) ZH_HIP(ctx, hipEventRecord(p->k_aux[2], cs));
@@ -449,7 +449,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
         zh_launch_checksum_pieces(s, ctx->cktabs, d_dst, p->d_pieces, p->npieces, p->out_len,
                                   want_crc, want_adler, p->piece_crc, p->piece_adler, p->piece_len);
         prof_mark(p, "zh_checksum_combine_kernel");
-        zh_launch_checksum_combine(s, p->d_bufs, (uint32_t)p->n, p->piece_crc, p->piece_adler,
+        zh_launch_checksum_combine(s, ctx->cktabs, p->d_bufs, (uint32_t)p->n, p->piece_crc, p->piece_adler,
                                    p->piece_len, want_crc, want_adler, p->buf_crc, p->buf_adler);
         prof_mark(p, "zh_verify_kernel");
         zh_launch_verify(s, a, p->buf_crc, p->buf_adler);

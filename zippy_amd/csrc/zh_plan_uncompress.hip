@@ -94,7 +94,7 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
                o_wlen = ar.reserve(ns * 8), o_valid = ar.reserve(ns * 4), o_prev = ar.reserve(ns * 4),
                o_ostart = ar.reserve(ns * 8), o_sok = ar.reserve(n * 4), o_order = ar.reserve(ns * 4),
                o_nchain = ar.reserve(n * 4), o_repair = ar.reserve(n * 4), o_ordinal = ar.reserve(ns * 4), o_go = ar.reserve(n * 4), o_etoff = ar.reserve(ns * 8), o_etcap = ar.reserve(ns * 8), o_substart = ar.reserve(ns * 8), o_subhdr = ar.reserve(ns * 8),
-               o_issub = ar.reserve(ns * 4), o_held = ar.reserve(ns * 8);
+               o_issub = ar.reserve(ns * 4), o_held = ar.reserve(ns * 8), o_stored = ar.reserve(ns * 8);
   const size_t nfind = find_seg.size();
   const size_t o_fseg = ar.reserve(nfind * 4), o_fbatch = ar.reserve(nfind * 4), o_cn = ar.reserve(nfind * 4),
                o_coff = ar.reserve(nfind * (size_t)kSegFindSlots * 4);
@@ -138,6 +138,7 @@ static void plan_segments(zh_plan* p, const std::vector<ZhBufDesc>& bufs, uint64
   g.sym_base = carve<uint64_t>(base, o_symb);
   g.start_bit = carve<uint64_t>(base, o_start);
   g.start2_bit = carve<uint64_t>(base, o_start2);
+  g.stored_bit = carve<uint64_t>(base, o_stored);
   g.end_bit = carve<uint64_t>(base, o_end);
   g.final_block = carve<uint32_t>(base, o_final);
   g.seg_status = carve<int32_t>(base, o_sst);
