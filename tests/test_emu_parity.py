@@ -33,6 +33,16 @@ def test_emu_compress_identical_level1(eng):
     pc.check_compress_identical(eng, inputs, levels=(1,))
 
 
+def test_emu_trailer_behind_the_emission(eng, monkeypatch):
+    """Large batches write the trailer with a kernel of its own behind the emission (the checksum runs beside both the
+    code builder and the emission: zh_plan_run.hip); ZH_TRAILER_LATE=1 takes the tests' small ones that way too."""
+    monkeypatch.setenv("ZH_TRAILER_LATE", "1")
+    inputs = [synth.corpus_file("alice29.txt")[:70000], synth.corpus_file("geo.protodata")[:40000], b"", b"abc"]
+    pc.check_compress_identical(eng, inputs, levels=(1, -1, 0), formats=(oracle.dfGzip, oracle.dfZlib, oracle.dfDeflate))
+    monkeypatch.setenv("ZH_TRAILER_LATE", "0")
+    pc.check_compress_identical(eng, inputs[:2], levels=(1,), formats=(oracle.dfGzip,))
+
+
 def test_emu_compress_identical_other_levels(eng):
     inputs = [synth.corpus_file("html")[:40000], synth.corpus_file("alice29.txt")[:3000], b"",
               b"abc", b"\x00" * 5000]

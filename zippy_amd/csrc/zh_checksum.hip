@@ -3,13 +3,15 @@
 //
 // Replaces crc.nim:29-72 (slice-by-8 / PCLMUL folding; gfx950 has no carry-less
 // multiply) and adler32.nim:19-63.  One 64-lane wave per piece (four waves a workgroup share the tables):
-//   * lane k owns the 16-byte column k of every 1 KiB row, so a row is one fully
-//     coalesced 1 KiB global load (global_load_dwordx4 per lane);
+//   * lane k owns the 32-byte column k of every 2 KiB row: two 16-byte loads a lane whose 64 pieces each lie 32
+//     bytes apart (16 bytes a lane and 1 KiB rows, fully coalesced, until round 5: the skip below is then paid twice
+//     as often -- 1.30 against 1.23 ms for 4 GiB; at 64 bytes a lane the loads' stride costs more than the skips
+//     save, 1.80 ms);
 //   * per row a lane takes its 16 bytes a dword at a time through THREE tables of 11 + 11 + 10 index bits
 //     (what advancing the state by four bytes does is linear in the state's bits: any split of the 32 will
 //     do; the kernel is bound by its LDS lookups -- a 64-lane lookup at random addresses is ~ 16 cycles of
 //     the CU's LDS --, so a dword is 3 of them instead of slice-by-4's 4) and then "skips" the other lanes'
-//     1008 bytes with one 4-lookup multiplication by x^(8*1008) mod P (tables Z0..Z3);
+//     bytes of the row with one 4-lookup multiplication by x^(8*(row - its own bytes)) mod P (tables Z0..Z3);
 //   * lanes are aligned to the end of the piece by one multiplication with
 //     x^(8*d) (d from a small table) and XOR-reduced across the wave.
 // Algorithmic traffic: each input byte is read once.
@@ -46,11 +48,17 @@ __host__ __device__ inline uint32_t gf2_xpow8(uint64_t n) {
   return result;
 }
 
+#ifndef ZH_CK_LANE
+#define ZH_CK_LANE 32
+#endif
+constexpr uint32_t kLaneBytes = ZH_CK_LANE;       // contiguous bytes a lane owns in a row (16-byte loads)
+constexpr uint32_t kRowBytes = 64u * kLaneBytes;  // a wave's row
+static_assert(kLaneBytes % 16u == 0 && kLaneBytes <= 64u, "");
 struct ChecksumTables {
   uint32_t t0[256];     // one byte (crc.nim's table 0): heads and tails
   uint32_t a[3][2048];  // four bytes: state ^ dword -> a[0][bits 0..10] ^ a[1][bits 11..21] ^ a[2][bits 22..31]
-  uint32_t z[4][256];   // multiply a state by x^(8*1008): Zj[b] = (b << 8j) * x^(8*1008)
-  uint32_t xz[2048];    // x^(8*j) mod P for j < 2048
+  uint32_t z[4][256];   // multiply a state by x^(8*(kRowBytes - kLaneBytes)): Zj[b] = (b << 8j) * x^(...), the other lanes' bytes of a row
+  uint32_t xz[2 * kRowBytes];  // x^(8*j) mod P
   uint32_t zp[4][256];  // multiply a state by x^(8*32768), a whole piece: the combine's step
 };
 constexpr uint32_t kWavesPerGroup = 4;
@@ -96,8 +104,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void zh_checksum_pieces_kernel
     uint32_t head = (uint32_t)((16u - ((uintptr_t)base & 15u)) & 15u);
     if (head > len) head = len;
     const uint32_t body = len - head;
-    const uint32_t rows = body >> 10;
-    const uint32_t tail = body & 1023u;
+    const uint32_t rows = body / kRowBytes;
+    const uint32_t tail = body % kRowBytes;
     const uint8_t* bp = base + head;
 
     uint32_t crc_rows = 0, crc_tail = 0, crc_head = 0;
@@ -111,51 +119,69 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void zh_checksum_pieces_kernel
         sum_ib += (uint64_t)i * b;
       }
     }
-    // (a row ahead: the next row's sixteen bytes are asked for before this row's go through the tables)
-    uint4 vn = rows ? *reinterpret_cast<const uint4*>(bp + lane * 16u) : make_uint4(0, 0, 0, 0);
-    for (uint32_t r = 0; r < rows; r++) {
-      const uint4 v = vn;
-      vn = *reinterpret_cast<const uint4*>(bp + ((size_t)(r + 1u < rows ? r + 1u : r) << 10) + lane * 16u);
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-      if (want_crc) {
-        if (r) {  // skip the other 63 lanes' bytes of the previous row boundary
-          crc_rows = s_z[0][crc_rows & 255u] ^ s_z[1][(crc_rows >> 8) & 255u] ^
-                     s_z[2][(crc_rows >> 16) & 255u] ^ s_z[3][crc_rows >> 24];
-        }
+    auto four_bytes = [&](uint32_t state, uint32_t w) -> uint32_t {
+      const uint32_t c = state ^ w;
+      return s_a0[c & 2047u] ^ s_a1[(c >> 11) & 2047u] ^ s_a2[c >> 22];
+    };
+    auto adler_dword = [&](uint32_t w, uint32_t at) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint32_t c = crc_rows ^ w[k];
-          crc_rows = s_a0[c & 2047u] ^ s_a1[(c >> 11) & 2047u] ^ s_a2[c >> 22];
-        }
+      for (int j = 0; j < 4; j++) {
+        const uint32_t b = (w >> (8 * j)) & 255u;
+        sum_b += b;
+        sum_ib += (uint64_t)(at + j) * b;
       }
-      if (want_adler) {
-        const uint32_t i0 = head + (r << 10) + lane * 16u;
+    };
+    // (a row ahead: the next row's bytes are asked for before this row's go through the tables)
+    constexpr uint32_t kVec = kLaneBytes / 16u;
+    uint4 vn[kVec];
+#pragma unroll
+    for (uint32_t q = 0; q < kVec; q++)
+      vn[q] = rows ? *reinterpret_cast<const uint4*>(bp + lane * kLaneBytes + 16u * q) : make_uint4(0, 0, 0, 0);
+    for (uint32_t r = 0; r < rows; r++) {
+      uint4 v[kVec];
+#pragma unroll
+      for (uint32_t q = 0; q < kVec; q++) {
+        v[q] = vn[q];
+        vn[q] = *reinterpret_cast<const uint4*>(bp + (size_t)(r + 1u < rows ? r + 1u : r) * kRowBytes + lane * kLaneBytes + 16u * q);
+      }
+      if (want_crc && r) {  // skip the other 63 lanes' bytes between this lane's bytes of two rows
+        crc_rows = s_z[0][crc_rows & 255u] ^ s_z[1][(crc_rows >> 8) & 255u] ^
+                   s_z[2][(crc_rows >> 16) & 255u] ^ s_z[3][crc_rows >> 24];
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < kVec; q++) {
+        const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            uint32_t b = (w[k] >> (8 * j)) & 255u;
-            sum_b += b;
-            sum_ib += (uint64_t)(i0 + 4 * k + j) * b;
-          }
+          if (want_crc) crc_rows = four_bytes(crc_rows, w[k]);
+          if (want_adler) adler_dword(w[k], head + r * kRowBytes + lane * kLaneBytes + 16u * q + 4u * k);
         }
       }
     }
-    // tail: lane k takes bytes [16k, 16k+16) of the last partial row
-    uint32_t t_begin = lane * 16u, t_end = t_begin + 16u;
+    // tail: lane k takes bytes [kLaneBytes k, kLaneBytes (k + 1)) of the last partial row, whole dwords first
+    uint32_t t_begin = lane * kLaneBytes, t_end = t_begin + kLaneBytes;
     if (t_begin > tail) t_begin = tail;
     if (t_end > tail) t_end = tail;
-    for (uint32_t i = t_begin; i < t_end; i++) {
-      uint32_t b = bp[((size_t)rows << 10) + i];
-      if (want_crc) crc_tail = s_t0[(crc_tail ^ b) & 255u] ^ (crc_tail >> 8);
-      sum_b += b;
-      sum_ib += (uint64_t)(head + (rows << 10) + i) * b;
+    {
+      const uint8_t* tp = bp + (size_t)rows * kRowBytes;
+      uint32_t i = t_begin;
+      for (; i + 4u <= t_end; i += 4u) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(tp + i);  // (bp is 16-byte aligned, i a multiple of four)
+        if (want_crc) crc_tail = four_bytes(crc_tail, w);
+        if (want_adler) adler_dword(w, head + rows * kRowBytes + i);
+      }
+      for (; i < t_end; i++) {
+        const uint32_t b = tp[i];
+        if (want_crc) crc_tail = s_t0[(crc_tail ^ b) & 255u] ^ (crc_tail >> 8);
+        sum_b += b;
+        sum_ib += (uint64_t)(head + rows * kRowBytes + i) * b;
+      }
     }
 
     if (want_crc) {
       // align every partial state to the end of the piece and fold
       uint32_t acc = 0;
-      if (rows) acc ^= gf2_mul(tabs->xz[16u * (63u - lane) + tail], crc_rows);
+      if (rows) acc ^= gf2_mul(tabs->xz[kLaneBytes * (63u - lane) + tail], crc_rows);
       if (t_end > t_begin) acc ^= gf2_mul(tabs->xz[tail - t_end], crc_tail);
       acc = zh_wave_xor(acc);
       if (lane == 0) {
@@ -288,15 +314,15 @@ extern "C" const void* zh_checksum_tables(int device) {
     h->a[1][v] = four_bytes(v << 11);
     h->a[2][v] = v < 1024 ? four_bytes(v << 22) : 0u;
   }
-  const uint32_t x1008 = gf2_xpow8(1008);
+  const uint32_t x_skip = gf2_xpow8(kRowBytes - kLaneBytes);
   for (int j = 0; j < 4; j++)
-    for (uint32_t b = 0; b < 256; b++) h->z[j][b] = gf2_mul(x1008, b << (8 * j));
+    for (uint32_t b = 0; b < 256; b++) h->z[j][b] = gf2_mul(x_skip, b << (8 * j));
   const uint32_t x32768 = gf2_xpow8(32768);
   for (int j = 0; j < 4; j++)
     for (uint32_t b = 0; b < 256; b++) h->zp[j][b] = gf2_mul(x32768, b << (8 * j));
   uint32_t x = 0x80000000u;
   const uint32_t x8 = 0x00800000u;
-  for (int j = 0; j < 2048; j++) {
+  for (uint32_t j = 0; j < 2 * kRowBytes; j++) {
     h->xz[j] = x;
     x = gf2_mul(x8, x);
   }

@@ -74,7 +74,8 @@ void zh_launch_huffman(hipStream_t, ZhCompressArgs a, int contract);
 void zh_launch_huffman_probe(hipStream_t, const uint32_t* freq, int num_freq, int min_codes, int limit, int contract,
                              uint16_t* codes, uint8_t* lens, int* n_out);
 void zh_launch_layout(hipStream_t, uint8_t* d_dst, ZhCompressArgs a, const uint32_t* buf_crc,
-                      const uint32_t* buf_adler);
+                      const uint32_t* buf_adler, int with_trailer);
+void zh_launch_trailer(hipStream_t, uint8_t* d_dst, ZhCompressArgs a, const uint32_t* buf_crc, const uint32_t* buf_adler);
 void zh_launch_emit(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhCompressArgs a);
 }
 
@@ -248,6 +249,7 @@ struct zh_plan {
   uint64_t sg_sym_count = 0;
   // profiling
   bool profiling = false;
+  bool trailer_late = false;  // compress: the checksum joins behind the emission (large batches; zh_plan_run.hip)
   std::vector<const char*> k_names;
   std::vector<hipEvent_t> k_events;
   std::vector<float> k_ms;

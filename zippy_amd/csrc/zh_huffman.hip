@@ -871,9 +871,23 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   KPROF_FLUSH(40, 8);
 }
 
+// The trailer (after padding to a byte, deflate.nim:473): the source's checksum and, for gzip, its length.
+__device__ inline void write_trailer(uint8_t* out, uint64_t tpos, int fmt, uint32_t crc, uint32_t adler, uint64_t src_len,
+                                     unsigned lane) {
+  if (fmt == ZH_DF_GZIP) {  // zippy.nim:47-58
+    const uint32_t isize = (uint32_t)(src_len & 0xffffffffu);
+    if (lane < 4) or_byte(out, tpos + lane, crc >> (8 * lane));
+    else if (lane < 8) or_byte(out, tpos + lane, isize >> (8 * (lane - 4)));
+  } else if (fmt == ZH_DF_ZLIB) {  // zippy.nim:71-78 (big-endian)
+    if (lane < 4) or_byte(out, tpos + lane, adler >> (8 * (3 - lane)));
+  }
+}
+
+// with_trailer = 0: the trailer comes later, from zh_trailer_kernel (the checksum is still on its way: it runs beside
+// the code builder AND the emission, zh_plan_run.hip)
 __global__ __launch_bounds__(64) void zh_layout_kernel(uint8_t* __restrict__ d_dst, ZhCompressArgs a,
                                                        const uint32_t* __restrict__ buf_crc,
-                                                       const uint32_t* __restrict__ buf_adler) {
+                                                       const uint32_t* __restrict__ buf_adler, int with_trailer) {
   const unsigned lane = zh_lane();
   const uint32_t bi = blockIdx.x;
   const ZhBufDesc bd = a.bufs[bi];
@@ -949,20 +963,28 @@ __global__ __launch_bounds__(64) void zh_layout_kernel(uint8_t* __restrict__ d_d
     }
   }
 
-  // ---- trailer (after padding to a byte, deflate.nim:473) ----
-  const uint64_t tpos = hdr_len + body_bytes;
-  if (fmt == ZH_DF_GZIP) {  // zippy.nim:47-58
-    const uint32_t crc = buf_crc[bi], isize = (uint32_t)(bd.src_len & 0xffffffffu);
-    if (lane < 4) or_byte(out, tpos + lane, crc >> (8 * lane));
-    else if (lane < 8) or_byte(out, tpos + lane, isize >> (8 * (lane - 4)));
-  } else if (fmt == ZH_DF_ZLIB) {  // zippy.nim:71-78 (big-endian)
-    const uint32_t ad = buf_adler[bi];
-    if (lane < 4) or_byte(out, tpos + lane, ad >> (8 * (3 - lane)));
-  }
+  if (with_trailer)
+    write_trailer(out, hdr_len + body_bytes, fmt, fmt == ZH_DF_GZIP ? buf_crc[bi] : 0u, fmt == ZH_DF_ZLIB ? buf_adler[bi] : 0u,
+                  bd.src_len, lane);
   if (lane == 0) {
     a.out_len[bi] = total_len;
     a.status[bi] = ZH_OK;
   }
+}
+
+// One wave per buffer, behind everything else of a compress run: the trailer of a buffer whose layout went without.
+__global__ __launch_bounds__(64) void zh_trailer_kernel(uint8_t* __restrict__ d_dst, ZhCompressArgs a,
+                                                        const uint32_t* __restrict__ buf_crc,
+                                                        const uint32_t* __restrict__ buf_adler) {
+  const unsigned lane = zh_lane();
+  const uint32_t bi = blockIdx.x;
+  if (a.status[bi] != ZH_OK) return;
+  const ZhBufDesc bd = a.bufs[bi];
+  const int fmt = a.data_format;
+  const uint32_t hdr_len = fmt == ZH_DF_GZIP ? 10 + bd.fname_len + 1 : fmt == ZH_DF_ZLIB ? 2 : 0;
+  const uint64_t body_bytes = (a.b_start[a.nblocks + bi] + 7) >> 3;  // (the layout's closing entry: the body's bits)
+  write_trailer(d_dst + bd.dst_off, hdr_len + body_bytes, fmt, fmt == ZH_DF_GZIP ? buf_crc[bi] : 0u,
+                fmt == ZH_DF_ZLIB ? buf_adler[bi] : 0u, bd.src_len, lane);
 }
 
 // One wave per block, after zh_layout_kernel: the block's header, the bit position of each of its
@@ -1062,10 +1084,15 @@ extern "C" void zh_launch_huffman(hipStream_t stream, ZhCompressArgs a, int cont
   else
     hipLaunchKernelGGL(zh_huffman_kernel<false>, dim3(a.nblocks), dim3(64), 0, stream, a);
 }
+extern "C" void zh_launch_trailer(hipStream_t stream, uint8_t* d_dst, ZhCompressArgs a, const uint32_t* buf_crc,
+                                  const uint32_t* buf_adler) {
+  if (!a.nbufs || a.data_format == ZH_DF_DEFLATE) return;
+  hipLaunchKernelGGL(zh_trailer_kernel, dim3(a.nbufs), dim3(64), 0, stream, d_dst, a, buf_crc, buf_adler);
+}
 extern "C" void zh_launch_layout(hipStream_t stream, uint8_t* d_dst, ZhCompressArgs a,
-                                 const uint32_t* buf_crc, const uint32_t* buf_adler) {
+                                 const uint32_t* buf_crc, const uint32_t* buf_adler, int with_trailer) {
   if (!a.nbufs) return;
   hipLaunchKernelGGL(zh_layout_kernel, dim3(a.nbufs), dim3(64), 0, stream, d_dst, a, buf_crc,
-                     buf_adler);
+                     buf_adler, with_trailer);
   hipLaunchKernelGGL(zh_block_layout_kernel, dim3(a.nblocks), dim3(64), 0, stream, d_dst, a);
 }
