@@ -827,7 +827,10 @@ def main():
             "kernel_launches": {k: v for k, v in launches.items() if v > 1},
             "kernels_note": "ms a step, all launches of a kernel together (kernel_launches: the checksum kernels run in both "
                             "passes; a batch whose per-position scratch exceeds ZH_SCRATCH_MB runs the chain kernels / the inflate "
-                            "pair over ranges of it, DESIGN.md 3); the roofline entries are a launch",
+                            "pair over ranges of it, DESIGN.md 3; from 2048 streams on the inflate pair runs as two halves "
+                            "on two streams, each launch timed BESIDE the other half's: their sum exceeds the pass, and "
+                            "'(waiting for the other half)' is the first stream's wait for the second); the roofline entries "
+                            "are a launch",
             "roofline": roof(own.get(dom, N + C), avg[dom], dom),
             "roofline_passes": {},
             # (the checksum kernels run in both passes, N bytes each time: a launch reads `b`, all of them `b` x launches)

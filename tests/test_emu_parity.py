@@ -43,6 +43,18 @@ def test_emu_trailer_behind_the_emission(eng, monkeypatch):
     pc.check_compress_identical(eng, inputs[:2], levels=(1,), formats=(oracle.dfGzip,))
 
 
+def test_emu_uncompress_two_halves(eng, monkeypatch):
+    """Large uncompress batches run as two halves on two streams (zh_plan_run.hip: a half's writer beside the other
+    half's tokens kernel); ZH_INFLATE_HALVES=4 takes the tests' batches that way: fixtures, own streams, damaged ones."""
+    monkeypatch.setenv("ZH_INFLATE_HALVES", "4")
+    eng.set_inflate_mode(0)
+    try:
+        pc.check_fixtures(eng, max_len=130000)
+        pc.check_errors_match_oracle(eng, pc.mutated_fixtures(40, seed=7, max_len=40000))
+    finally:
+        eng.set_inflate_mode(-1)
+
+
 def test_emu_compress_identical_other_levels(eng):
     inputs = [synth.corpus_file("html")[:40000], synth.corpus_file("alice29.txt")[:3000], b"",
               b"abc", b"\x00" * 5000]

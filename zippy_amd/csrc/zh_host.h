@@ -249,13 +249,16 @@ struct zh_plan {
   uint64_t sg_sym_count = 0;
   // profiling
   bool profiling = false;
-  bool trailer_late = false;  // compress: the checksum joins behind the emission (large batches; zh_plan_run.hip)
+  bool trailer_late = false;
+  uint32_t halves_min = 0;    // uncompress: batches of at least this many streams go as two halves on two streams (0: never; zh_plan_run.hip)  // compress: the checksum joins behind the emission (large batches; zh_plan_run.hip)
   std::vector<const char*> k_names;
   std::vector<hipEvent_t> k_events;
   std::vector<float> k_ms;
   // kernels on the context's second stream (the checksum of a compress run): start / between / end
   hipEvent_t k_aux[3] = {nullptr, nullptr, nullptr};
   bool k_aux_used = false;
+  hipEvent_t k_half[3] = {nullptr, nullptr, nullptr};  // ... of the second half's tokens kernel and writer (uncompress plans)
+  bool k_half_used = false;
 };
 
 template <class T>

@@ -45,6 +45,16 @@ extern "C" int zh_plan_kernel_times(zh_plan* p, const char** names, float* ms, i
       cnt++;
     }
   }
+  if (p->k_half_used) {  // the second half of an uncompress batch, on the second stream beside the first half's writer
+    static const char* const half_names[2] = {"zh_inflate_tokens_kernel", "zh_inflate_write_kernel"};
+    for (int k = 0; k < 2 && cnt < max_entries; k++) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, p->k_half[k], p->k_half[k + 1]) != hipSuccess) break;
+      names[cnt] = half_names[k];
+      ms[cnt] = t;
+      cnt++;
+    }
+  }
   return cnt;
 }
 
@@ -62,6 +72,8 @@ extern "C" void zh_plan_destroy(zh_plan* p) {
   if (p->unpack_lens) ctx_free(p->ctx, p->unpack_lens);
   for (auto e : p->k_events) (void)hipEventDestroy(e);
   for (auto e : p->k_aux)
+    if (e) (void)hipEventDestroy(e);
+  for (auto e : p->k_half)
     if (e) (void)hipEventDestroy(e);
   delete p;
 }
@@ -430,7 +442,38 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       zh_launch_segments_reduce(s, p->seg, a);
     } else if (split) {
       // two kernels: tokens (parallel over each stream), then bytes (zh_inflate_split.hip)
-      if (p->tok_groups.size() <= 1) {
+      p->k_half_used = false;
+      if (p->tok_groups.size() <= 1 && p->halves_min >= 2u && a1.nbufs >= p->halves_min && checksum_aside(ctx)) {
+        // Two halves, the second on the context's second stream: 4096 workgroups are 3.2 rounds of the machine for
+        // either kernel, and both wait more than they work -- side by side a half's writer fills what
+        // the other half's tokens kernel leaves idle, and only the last tail is nobody's to fill (own streams 20.8 ->
+        // 19.7 ms, zlib level-6 members 24.3 -> 23.4; three and four parts: slower).
+        // Kernel times: both halves' launches are reported, each as long as it took BESIDE the other.
+        ZhInflateArgs ah[2] = {a1, a1};
+        ah[0].nbufs = a1.nbufs / 2u;
+        ah[1].first_buf = a1.first_buf + ah[0].nbufs;
+        ah[1].nbufs = a1.nbufs - ah[0].nbufs;
+        hipStream_t s2 = ctx->aux_stream;
+        ZH_HIP(ctx, hipEventRecord(ctx->aux_fork, s));
+        ZH_HIP(ctx, hipStreamWaitEvent(s2, ctx->aux_fork, 0));
+        if (p->profiling) {
+          for (hipEvent_t& e : p->k_half)
+            if (!e && hipEventCreate(&e) != hipSuccess) p->profiling = false;
+          p->k_half_used = p->profiling;
+        }
+        if (p->k_half_used) ZH_HIP(ctx, hipEventRecord(p->k_half[0], s2));
+        zh_launch_inflate_tokens(s2, d_src, ah[1], p->tok_pool, p->tok_off, p->tok_cap);
+        if (p->k_half_used) ZH_HIP(ctx, hipEventRecord(p->k_half[1], s2));
+        zh_launch_inflate_write(s2, d_src, d_dst, ah[1], p->tok_pool, p->tok_off);
+        if (p->k_half_used) ZH_HIP(ctx, hipEventRecord(p->k_half[2], s2));
+        ZH_HIP(ctx, hipEventRecord(ctx->aux_join, s2));
+        prof_mark(p, "zh_inflate_tokens_kernel");
+        zh_launch_inflate_tokens(s, d_src, ah[0], p->tok_pool, p->tok_off, p->tok_cap);
+        prof_mark(p, "zh_inflate_write_kernel");
+        zh_launch_inflate_write(s, d_src, d_dst, ah[0], p->tok_pool, p->tok_off);
+        prof_mark(p, "(waiting for the other half)");
+        ZH_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_join, 0));
+      } else if (p->tok_groups.size() <= 1) {
         prof_mark(p, "zh_inflate_tokens_kernel");
         zh_launch_inflate_tokens(s, d_src, a1, p->tok_pool, p->tok_off, p->tok_cap);
         prof_mark(p, "zh_inflate_write_kernel");

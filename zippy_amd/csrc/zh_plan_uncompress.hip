@@ -229,6 +229,10 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
     toff[i] = twords;
     twords += tcap[i] + 1024;  // (the writer reads whole batches of records, up to 640 behind the last)
   }
+  // large batches decode as two halves on two streams (zh_plan_run.hip): from 2048 streams on, so that a half still is
+  // a batch for the narrow kernels; ZH_INFLATE_HALVES=<smallest such batch> (0: never; the tests: 4)
+  p->halves_min = 2048;
+  if (const char* e = getenv("ZH_INFLATE_HALVES")) p->halves_min = (uint32_t)strtoul(e, nullptr, 10);
   plan_segments(p, bufs, &twords);
   if (!p->segmented && n) {
     // groups of streams whose token regions fit the scratch budget share the pool in turn (zh_plan_run); a
