@@ -60,6 +60,7 @@ struct ChecksumTables {
   uint32_t z[4][256];   // multiply a state by x^(8*(kRowBytes - kLaneBytes)): Zj[b] = (b << 8j) * x^(...), the other lanes' bytes of a row
   uint32_t xz[2 * kRowBytes];  // x^(8*j) mod P
   uint32_t zp[4][256];  // multiply a state by x^(8*32768), a whole piece: the combine's step
+  uint32_t init_whole;  // what the initial 0xffffffff has become behind a whole piece: 0xffffffff * x^(8*32768)
 };
 constexpr uint32_t kWavesPerGroup = 4;
 
@@ -186,8 +187,10 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void zh_checksum_pieces_kernel
       acc = zh_wave_xor(acc);
       if (lane == 0) {
         if (head) acc ^= gf2_mul(gf2_xpow8(len - head), crc_head);
-        // standard conditioning: init 0xffffffff travels through len bytes, final NOT
-        uint32_t crc = ~(acc ^ gf2_mul(gf2_xpow8(len), 0xffffffffu));
+        // standard conditioning: init 0xffffffff travels through len bytes, final NOT.  (For a whole piece a constant:
+        // gf2_xpow8() is thirty 32-step multiplications by ONE lane -- the counters had three quarters of this kernel's
+        // vector instructions on a single lane.)
+        uint32_t crc = ~(acc ^ (len == 32768u ? tabs->init_whole : gf2_mul(gf2_xpow8(len), 0xffffffffu)));
         out_crc[p] = crc;
       }
     }
@@ -318,6 +321,7 @@ extern "C" const void* zh_checksum_tables(int device) {
   for (int j = 0; j < 4; j++)
     for (uint32_t b = 0; b < 256; b++) h->z[j][b] = gf2_mul(x_skip, b << (8 * j));
   const uint32_t x32768 = gf2_xpow8(32768);
+  h->init_whole = gf2_mul(x32768, 0xffffffffu);
   for (int j = 0; j < 4; j++)
     for (uint32_t b = 0; b < 256; b++) h->zp[j][b] = gf2_mul(x32768, b << (8 * j));
   uint32_t x = 0x80000000u;
