@@ -438,21 +438,18 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
 
     nb = host.shape[0]
     full_size = nb == 4096  # (the PMC passes were taken on BASELINE's sizes)
-    batch("c2", "config 2: 1024 x 64 KiB, compress BestSpeed gzip", min(1024, nb * 16), 65536, 1, True, False, sample=8)
-    batch("c2_parallel_parse", "config 2 with the opt-in parallel BestSpeed parse (valid streams, not the "
-          "reference's bytes)", min(1024, nb * 16), 65536, 1, True, False, l1_parse=1)
-    batch("c3_own", "config 3: %d x 1 MiB uncompress only (this library's BestSpeed streams), CRC-32 verified" % nb,
+    batch("c2", "c2: 1024x64KiB compress L1", min(1024, nb * 16), 65536, 1, True, False, sample=8)
+    batch("c2_parallel_parse", "c2, contract mode", min(1024, nb * 16), 65536, 1, True, False, l1_parse=1)
+    batch("c3_own", "c3: %dx1MiB uncompress, own L1 streams" % nb,
           nb, 1 << 20, 1, False, True)
-    batch("c3_zlib6", "config 3: %d x 1 MiB uncompress only, gzip members made by system zlib level 6 "
-          "(multi-block dynamic streams), CRC-32 verified" % nb, nb, 1 << 20, 1, False, True, foreign=6)
+    batch("c3_zlib6", "c3: %dx1MiB uncompress, zlib-6 gzip members" % nb, nb, 1 << 20, 1, False, True, foreign=6)
     share = max(1, nb // 8)
-    batch("c4_share", "config 4: one GPU's share of eight (%d x 1 MiB), compress DefaultCompression gzip" % share,
+    batch("c4_share", "c4: one GPU's share of eight (%dx1MiB), compress L-1" % share,
           share, 1 << 20, -1, True, False, nsteps=max(2, steps // 2), sample=8)
     # one GPU's share of the HEADLINE step when eight split the batch (strong scaling, SCALE_rNN's N = 8 point as
     # far as one GPU can show it), with what the GPU adds to a transfer leg (pack / unpack)
-    batch("share512", "one GPU's share of eight of the headline step (%d x 1 MiB, compress BestSpeed gzip + "
-          "uncompress)" % share, share, 1 << 20, 1, True, True, pack=True)
-    batch("share512_parallel_parse", "the same share with the opt-in parallel BestSpeed parse", share, 1 << 20, 1,
+    batch("share512", "one GPU's share of eight of the headline step (%dx1MiB)" % share, share, 1 << 20, 1, True, True, pack=True)
+    batch("share512_parallel_parse", "the same share, contract mode", share, 1 << 20, 1,
           True, True, l1_parse=1)
 
     # config 5: ONE large buffer as independent 32 KiB deflate blocks (tools/bench_c5.py)
@@ -474,8 +471,7 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
         (ulen,), (ust,) = uplan.results()
         assert ust == 0 and ulen == size and torch.equal(d_back, d_src), "config 5"
     tc, tu, kms = time_plans(torch, stream, cplan, uplan, (d_src, d_comp, d_back), steps, 1, verify5)
-    out["c5"] = entry("config 5: 1 x %d MiB as independent 32 KiB deflate blocks, compress BestSpeed gzip + "
-                      "indexed uncompress" % mib, size, clen, tc, tu, kms, "c5")
+    out["c5"] = entry("c5: 1x%dMiB as 32KiB blocks, compress L1 + indexed uncompress" % mib, size, clen, tc, tu, kms, "c5")
     import oracle  # (checker only, outside the timed region: the first 8 MiB as 32 KiB blocks, bytes and index)
     part = 8 << 20
     if size >= part:
@@ -825,22 +821,14 @@ def main():
             "ratio": round(total_uncompressed / comp_all, 4),
             "kernels_ms": {k: round(v, 4) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
             "kernel_launches": {k: v for k, v in launches.items() if v > 1},
-            "kernels_note": "ms a step, all launches of a kernel together (kernel_launches: the checksum kernels run in both "
-                            "passes; a batch whose per-position scratch exceeds ZH_SCRATCH_MB runs the chain kernels / the inflate "
-                            "pair over ranges of it, DESIGN.md 3; from 2048 streams on the inflate pair runs as two halves "
-                            "on two streams, each launch timed BESIDE the other half's: their sum exceeds the pass, and "
-                            "'(waiting for the other half)' is the first stream's wait for the second); the roofline entries "
-                            "are a launch",
+            "kernels_note": "ms a step, all launches of a kernel together; DESIGN.md 5 says how to read it",
             "roofline": roof(own.get(dom, N + C), avg[dom], dom),
             "roofline_passes": {},
             # (the checksum kernels run in both passes, N bytes each time: a launch reads `b`, all of them `b` x launches)
             "roofline_kernels": {k: roof(b * (launches.get(k, 1) if k.startswith("zh_checksum") else 1), avg[k], k)
                                  for k, b in own.items() if k in avg},
             "source_sha": source_sha(),
-            "traffic_note": "bytes a launch across the L2's memory side (Infinity Cache hits included: not all of it reaches HBM), "
-                            "read requests counted by size (gfx950: 128-byte requests almost only, whatever a lane asked for) + "
-                            "WRITE_SIZE; traffic_raw: FETCH_SIZE + WRITE_SIZE as rocprofv3 reports them (profiles/hbm_traffic.json, "
-                            "tools/pmc_traffic.py)",
+            "traffic_note": "L2 memory-side bytes a launch, read requests by size + WRITE_SIZE (profiles/hbm_traffic.json; DESIGN.md 5)",
             "parity_sample": parity_sample,
         }
         if do_c:
@@ -892,6 +880,23 @@ def main():
                 out["configs"]["c4_share"]["cpu_baseline_level_-1"]["device_vs_cpu_size"] = (
                     "identical streams" if out["configs"]["c4_share"].get("parity_sample", {}).get("identical") else None)
         out["host_gen_s"] = round(t_gen, 1)
+        # the headline-adjacent numbers once more, compact and LAST: a reader who only sees the line's tail sees these
+        cf = out.get("configs", {})
+
+        def cv(tag, key="value"):
+            return cf.get(tag, {}).get(key)
+        out["summary"] = {
+            "value": out["value"], "ms": out["ms_per_step"], "c_GiBps": out["compress_GiBps"], "u_GiBps": out["uncompress_GiBps"],
+            "value_pp": out.get("value_parallel_parse"), "pp_ms": out.get("parallel_parse", {}).get("ms_per_step"),
+            "frac": out["roofline"]["frac"], "dom": out["roofline"].get("kernel"), "dom_ms": out["roofline"]["avg_launch_ms"],
+            "c2": cv("c2"), "c2_pp": cv("c2_parallel_parse"), "c3_own": cv("c3_own"), "c3_zlib6": cv("c3_zlib6"),
+            "c3_zlib_unsized": cv("c3_zlib_unsized"), "c4_share": cv("c4_share"), "c5": cv("c5"),
+            "share512_ms": cv("share512", "ms_per_step"), "share512_eff": cv("share512", "efficiency_vs_perfect_eighth"),
+            "share512_pp_ms": cv("share512_parallel_parse", "ms_per_step"),
+            "share512_pp_eff": cv("share512_parallel_parse", "efficiency_vs_perfect_eighth"),
+            "cpu_GiBps": out.get("cpu_baseline", {}).get("value"), "cpu_cores": out.get("cpu_baseline", {}).get("cores"),
+            "parity": (parity_sample or {}).get("identical"),
+        }
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

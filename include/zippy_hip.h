@@ -269,7 +269,11 @@ int zh_plan_set_src_lens_device(zh_plan *plan, const uint64_t *d_lens);
  *    or beyond d_packed + packed_cap (a caller that sized d_packed too small sees d_offsets[n] > packed_cap).
  *  - zh_plan_unpack, before zh_plan_run of an UNCOMPRESS plan: stream i (d_packed + d_offsets[i], d_offsets[i + 1] -
  *    d_offsets[i] bytes, at most the src_len[i] the plan was made with: the slot's size) is copied to d_slots +
- *    src_off[i], and the plan decodes streams of these lengths from now on (as after zh_plan_set_src_lens_device).
+ *    src_off[i], and the plan decodes streams of these lengths from now on (as after zh_plan_set_src_lens_device --
+ *    and, like there, for good: the plan's segment geometry was laid over the lengths it was made with, so from the
+ *    first unpack on it decodes every stream with one workgroup, large ones included; make a new plan to get the
+ *    segment-wise decode of large streams back).  ZH_ERR_ARGUMENT (more than 2^31 copy workgroups) is returned before
+ *    anything is launched or written, for both calls.
  * Device pointers throughout, kernel launches on the context's stream only, no host synchronisation: a pack may
  * follow a run, a run an unpack, at once. */
 int zh_plan_pack(zh_plan *plan, const void *d_slots, void *d_packed, uint64_t packed_cap, uint64_t *d_offsets);
@@ -413,9 +417,10 @@ int zh_debug_huffman(zh_ctx *ctx, const uint32_t *freq, int num_freq, int min_co
                      uint16_t *codes, uint8_t *lens, int *num_codes);
 /* Large streams are decoded by many workgroups each (segment-wise) when the chain of their segments holds, by one
  * workgroup otherwise -- same bytes and statuses either way, so only a count can tell the two apart: since the
- * context was made, *cut = streams that uncompress calls cut into segments, *held = those of them whose chain held
- * (counted when a call's / a plan's results are read).  A stream that is damaged, or has fewer than four block
- * starts and sub-starts, legitimately does not hold. */
+ * context was made, *cut = streams that uncompress runs cut into segments, *held = those of them whose chain held.
+ * Counted on the device by EVERY run of a segmented plan -- a sizing (count-only) pass and a re-run of the same plan
+ * count again --, so compare differences around the runs of interest.  A stream that is damaged, or has fewer than
+ * four block starts and sub-starts, legitimately does not hold. */
 int zh_debug_segment_stats(zh_ctx *ctx, uint64_t *cut, uint64_t *held);
 
 #ifdef __cplusplus

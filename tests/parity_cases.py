@@ -699,14 +699,18 @@ def check_unsized_streams(eng):
     assert sts == [0, 0, 0, 0] and outs == [plain[3], text, plain[7], plain[5]]
 
 
-def check_plan_slots_with_gaps(eng, upload, download, alloc):
-    """Device plan API (include/zippy_hip.h): output slots at odd offsets with caller data
-    between them -- the slots are zeroed one by one and nothing outside them changes; the
-    streams equal the oracle's; a misaligned d_dst is refused.  upload(bytes) -> (ptr, keep),
+def check_plan_slots_with_gaps(eng, upload, download, alloc, levels=(1, -2, 0, 6), fills=(0xAB, 0xFF)):
+    """Device plan API (include/zippy_hip.h): output slots at odd offsets in memory the caller has filled with a
+    pattern -- nothing is cleared beforehand (round 6: the layout kernels zero exactly the words that are OR-ed into,
+    csrc/zh_huffman.hip), so a stream's bytes must be the oracle's whatever was there, and NOTHING else may change:
+    neither the rest of a slot nor the caller's bytes between slots.  Compressed, fixed, stored (two chunks) and
+    empty buffers, the three containers; a misaligned d_dst is refused.  upload(bytes) -> (ptr, keep),
     alloc(n, fill) -> (ptr, keep), download(keep) -> bytes."""
     import pytest
     from zippy_amd.common import ZippyError
-    srcs = [synth.corpus_file("alice29.txt")[:50000], b"", synth.corpus_file("html")[:33000], b"x" * 70001]
+    rnd = np.random.default_rng(7).integers(0, 256, 70001, dtype=np.uint8).tobytes()
+    srcs = [synth.corpus_file("alice29.txt")[:50000], b"", synth.corpus_file("html")[:33000], b"x" * 70001, rnd, b"ab",
+            synth.corpus_file("alice29.txt")[:700]]
     src_off, pos = [], 0
     for s in srcs:
         src_off.append(pos)
@@ -716,20 +720,24 @@ def check_plan_slots_with_gaps(eng, upload, download, alloc):
     dst_off, pos = [], 7
     for i, c in enumerate(caps):
         dst_off.append(pos)
-        pos += c + (101, 1000, 3, 513)[i]
+        pos += c + (101, 1000, 3, 513, 0, 1, 2)[i]  # (slots 4 / 5: back to back at odd addresses)
     total = pos + 64
-    d_dst, keep_dst = alloc(total, 0xAB)
-    plan = eng.plan_compress(src_off, [len(s) for s in srcs], dst_off, caps, 1, oracle.dfGzip)
-    plan.run(d_src, d_dst)
-    lens, sts = plan.results()
-    assert all(st == 0 for st in sts)
-    got = download(keep_dst)
-    inside = bytearray(total)
-    for s, o, c, ln in zip(srcs, dst_off, caps, lens):
-        assert got[o:o + ln] == oracle.compress(s, 1, oracle.dfGzip, fname_len=0)
-        assert got[o + ln:o + c] == b"\0" * (c - ln)  # the rest of a slot is zeroed
-        inside[o:o + c] = b"\1" * c
-    assert all(got[i] == 0xAB for i in range(total) if not inside[i]), "bytes outside the slots changed"
+    plan = None
+    for k, level in enumerate(levels):
+        fmt = FORMATS[k % len(FORMATS)]
+        fill = fills[k % len(fills)]
+        d_dst, keep_dst = alloc(total, fill)
+        plan = eng.plan_compress(src_off, [len(s) for s in srcs], dst_off, caps, level, fmt)
+        plan.run(d_src, d_dst)
+        lens, sts = plan.results()
+        assert all(st == 0 for st in sts)
+        got = download(keep_dst)
+        mine = bytearray(total)
+        for i, (s, o, ln) in enumerate(zip(srcs, dst_off, lens)):
+            assert got[o:o + ln] == oracle.compress(s, level, fmt, fname_len=0), (level, fmt, i)
+            mine[o:o + ln] = b"\1" * ln
+        changed = [i for i in range(total) if not mine[i] and got[i] != fill]
+        assert not changed, "level %d: bytes outside the streams changed, first at %d" % (level, changed[0])
     with pytest.raises(ZippyError):
         plan.run(d_src, d_dst + 1)
 

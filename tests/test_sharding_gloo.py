@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: two gloo ranks shard a batch, each compresses its shard (kernel
+"""N > 1 path on CPU: 2, 8 and 16 gloo ranks shard a batch, each compresses its shard (kernel
 sources under the emulator -- test infrastructure), the compressed buffers come back
 to rank 0 in order and equal the oracle's output; then the reverse for uncompress."""
 import os
@@ -114,8 +114,10 @@ def _worker(rank, world, port, n_buffers, buf_bytes, result_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_buffers", [5, 2])
-def test_two_ranks_shard_compress_gather(tmp_path, n_buffers):
+# (world, buffers): two ranks with an uneven and an even split; BASELINE's eight ranks with 13 buffers (shards of two and of
+# one); sixteen ranks with 13 buffers: three ranks own NOTHING and still take part in every collective
+@pytest.mark.parametrize("world,n_buffers", [(2, 5), (2, 2), (8, 13), (16, 13)])
+def test_ranks_shard_compress_gather(tmp_path, world, n_buffers):
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
     import build_emu
@@ -123,7 +125,7 @@ def test_two_ranks_shard_compress_gather(tmp_path, n_buffers):
     import oracle
     oracle.build()
     result = str(tmp_path / "result.txt")
-    mp.spawn(_worker, args=(2, _free_port(), n_buffers, 20000, result), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_buffers, 20000 if world == 2 else 9000, result), nprocs=world, join=True)
     assert open(result).read() == "ok"
 
 

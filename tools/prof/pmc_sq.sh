@@ -15,6 +15,8 @@ declare -A CMD
 CMD[headline]="$B --buffers $N"
 CMD[c4_share]="$B --buffers 512 --level -1 --compress-only --no-parallel-parse"
 CMD[c3_zlib6]="$B --buffers $N --foreign 6"
+CMD[l1]="$B --buffers $N --compress-only --no-parallel-parse"        # the exact BestSpeed matcher's pass alone
+CMD[c3_own]="$B --buffers $N --uncompress-only --no-parallel-parse"  # the inflate pair on this library's streams
 W=${@:-headline c4_share c3_zlib6}
 cd /tmp
 pass() {  # workload, pass name, counters...

@@ -163,6 +163,14 @@ extern "C" int zh_create(int device, void* stream, zh_ctx** out) {
   if (const char* e = getenv("ZH_CHAIN_PREV"))
     if (strcmp(e, "serial") == 0) c->chain_links_serial = true;
 #endif
+  {  // zh_debug_segment_stats' two counters: here, zeroed on the context's stream, not lazily inside some plan's run
+    void* q = nullptr;
+    if (ctx_malloc(c, &q, 16) == hipSuccess && hipMemsetAsync(q, 0, 16, c->stream) == hipSuccess) {
+      c->d_seg_stats = static_cast<uint64_t*>(q);
+    } else {
+      (void)hipGetLastError();  // (the counters are a test aid: without them they read 0)
+    }
+  }
   *out = c;
   return ZH_OK;
 }
@@ -202,7 +210,9 @@ extern "C" int zh_device_malloc(zh_ctx* ctx, size_t bytes, void** d_out) {
 }
 extern "C" void zh_device_free(zh_ctx* ctx, void* d) {
   if (!ctx || !d) return;
+  (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);  // (kernels of the context may still be reading it)
+  if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);  // (a run joins it; a run that failed half-way too)
   ctx_free(ctx, d);
 }
 extern "C" int zh_device_upload(zh_ctx* ctx, void* d_dst, const void* src, size_t bytes) {

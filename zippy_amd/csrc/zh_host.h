@@ -194,6 +194,7 @@ struct zh_plan {
   uint32_t* head_scratch = nullptr;  // chain levels: `head` per block, previous-position links and
   size_t head_bytes = 0;             // best match per position (zh_chain_match.hip)
   uint16_t* l1_tables = nullptr;  // BestSpeed: pool of per-wave hash tables (zh_l1_match.hip)
+  void* l1_pool_own = nullptr;    // ... when it is an allocation of its own (ZH_L1_POOL: uncached / fine-grained memory)
   uint32_t* l1_counter = nullptr; // ... and the counter its waves draw fragments from
   // longest first (zh_l1_match.hip): a fragment's cycles in the last run, the order made of them, scratch; l1_runs: runs so far
   uint32_t *l1_cost = nullptr, *l1_order = nullptr, *l1_hist = nullptr;
@@ -212,8 +213,6 @@ struct zh_plan {
   size_t chain_scratch_frags = 0;  // fragments the scratch holds (the largest range)
   // split inflate: the groups of streams (first, count) that share the token pool in turn
   std::vector<std::pair<uint32_t, uint32_t>> tok_groups;
-  uint64_t dst_lo = 0, dst_hi = 0;  // byte range of d_dst covered by the slots
-  bool dst_dense = true;            // the slots tile [dst_lo, dst_hi) without gaps
   uint64_t dst_max_cap = 0;
   uint64_t* out_len = nullptr;
   int32_t* status = nullptr;

@@ -871,15 +871,38 @@ __global__ __launch_bounds__(64) void zh_huffman_kernel(ZhCompressArgs a) {
   KPROF_FLUSH(40, 8);
 }
 
+// Output slots are NOT cleared beforehand (round 6; until then a memset of every slot led each compress run).  Whole
+// bytes -- container header, trailer, stored chunks' LEN / NLEN -- are plain stores; bits that share a word with another
+// writer are OR-ed in (block headers, end-of-block codes, a fragment's first and last word: zh_emit.hip), and every word
+// that is OR-ed into is zeroed first by a kernel -- or by the same wave -- that comes before all its writers:
+//   zh_layout_kernel (a wave a buffer, before everything else): the word of every block's first bit and of the bit two
+//     behind it (a stored block's three header bits and its padding), and the word of the body's last bit -- all clipped
+//     to the body's own bytes: the neighbouring bytes of such a word may be the container header's, the trailer's or
+//     another slot's;
+//   zh_block_layout_kernel (a wave a block): the words strictly between its block's first word and the next block's
+//     (the last block: the word of the body's last bit) that hold a header bit, a fragment's first bit or the end-of-block
+//     code -- nobody else touches those before the emission --, then a fence, then its ORs.
+// Everything else of a stream is whole words or bytes stored by their one owner.
+__device__ inline void zero_word_clipped(uint8_t* d_dst, uint64_t abs_bit, uint64_t lo_byte, uint64_t hi_byte) {
+  const uint64_t w0 = (abs_bit >> 5) << 2;
+  const uint64_t lo = w0 > lo_byte ? w0 : lo_byte, hi = w0 + 4 < hi_byte ? w0 + 4 : hi_byte;
+  if (lo >= hi) return;
+  if (hi - lo == 4) {
+    *reinterpret_cast<uint32_t*>(d_dst + w0) = 0u;
+  } else {
+    for (uint64_t x = lo; x < hi; x++) d_dst[x] = 0;
+  }
+}
+
 // The trailer (after padding to a byte, deflate.nim:473): the source's checksum and, for gzip, its length.
 __device__ inline void write_trailer(uint8_t* out, uint64_t tpos, int fmt, uint32_t crc, uint32_t adler, uint64_t src_len,
                                      unsigned lane) {
   if (fmt == ZH_DF_GZIP) {  // zippy.nim:47-58
     const uint32_t isize = (uint32_t)(src_len & 0xffffffffu);
-    if (lane < 4) or_byte(out, tpos + lane, crc >> (8 * lane));
-    else if (lane < 8) or_byte(out, tpos + lane, isize >> (8 * (lane - 4)));
+    if (lane < 4) out[tpos + lane] = (uint8_t)(crc >> (8 * lane));
+    else if (lane < 8) out[tpos + lane] = (uint8_t)(isize >> (8 * (lane - 4)));
   } else if (fmt == ZH_DF_ZLIB) {  // zippy.nim:71-78 (big-endian)
-    if (lane < 4) or_byte(out, tpos + lane, adler >> (8 * (3 - lane)));
+    if (lane < 4) out[tpos + lane] = (uint8_t)(adler >> (8 * (3 - lane)));
   }
 }
 
@@ -946,21 +969,25 @@ __global__ __launch_bounds__(64) void zh_layout_kernel(uint8_t* __restrict__ d_d
     return;
   }
 
+  // ---- the seams between blocks, zeroed for the kernels that OR into them (see above) ----
+  {
+    const uint64_t body0 = bd.dst_off + hdr_len, body1 = body0 + body_bytes;  // the body's bytes in d_dst
+    for (uint32_t k = lane; k < bd.nblocks; k += 64) {
+      const uint64_t s0 = body0 * 8 + a.b_start[bd.first_block + k];  // (this lane's own store above)
+      zero_word_clipped(d_dst, s0, body0, body1);
+      zero_word_clipped(d_dst, s0 + 2, body0, body1);
+    }
+    if (lane == 0 && cursor) zero_word_clipped(d_dst, body0 * 8 + cursor - 1, body0, body1);
+  }
   // ---- container header ----
-  if (fmt == ZH_DF_GZIP) {  // zippy.nim:22-42
-    if (lane == 0) {
-      or_byte(out, 0, 31);
-      or_byte(out, 1, 139);
-      or_byte(out, 2, 8);
-      or_byte(out, 3, 1u << 3);  // FNAME
-    }
-    if (lane < bd.fname_len) or_byte(out, 10 + lane, 97 + lane);
+  if (fmt == ZH_DF_GZIP) {  // zippy.nim:22-42: 1f 8b 08 08 00 x 6, the FNAME letters, its NUL
+    if (lane < 10) out[lane] = lane == 0 ? 31 : lane == 1 ? 139 : lane == 2 ? 8 : lane == 3 ? (1u << 3) : 0;
+    if (lane < bd.fname_len) out[10 + lane] = (uint8_t)(97 + lane);
+    if (lane == 0) out[10 + bd.fname_len] = 0;
   } else if (fmt == ZH_DF_ZLIB) {  // zippy.nim:61-69
-    if (lane == 0) {
-      const uint32_t cmf = (7u << 4) | 8u;
-      or_byte(out, 0, cmf);
-      or_byte(out, 1, 31u - (cmf * 256u) % 31u);
-    }
+    const uint32_t cmf = (7u << 4) | 8u;
+    if (lane == 0) out[0] = (uint8_t)cmf;
+    if (lane == 1) out[1] = (uint8_t)(31u - (cmf * 256u) % 31u);
   }
 
   if (with_trailer)
@@ -1012,31 +1039,56 @@ __global__ __launch_bounds__(64) void zh_block_layout_kernel(uint8_t* __restrict
       const uint32_t fin = (blk.is_final && c == chunks - 1) ? 1u : 0u;
       const uint64_t clen = (c == chunks - 1) ? blk.len - c * ZH_STORED_MAX : ZH_STORED_MAX;
       const uint64_t len_byte = d0 - 4 + c * (ZH_STORED_MAX + 5ull);
-      if (c == 0) or_bits(out, body_bit0 + cursor, fin, 3);  // BFINAL + BTYPE=00, then pad
-      else or_bits(out, (len_byte - 1) * 8, fin, 3);
-      or_bits(out, len_byte * 8, (uint32_t)clen | ((uint32_t)(ZH_STORED_MAX - clen) << 16), 32);
+      // BFINAL + BTYPE = 00, then padding: the first chunk's three bits share their bytes with the block before (zeroed
+      // by zh_layout_kernel), a later chunk's byte is its own; LEN and NLEN are whole bytes
+      if (c == 0) or_bits(out, body_bit0 + cursor, fin, 3);
+      else out[len_byte - 1] = (uint8_t)fin;
+      const uint32_t ln = (uint32_t)clen | ((uint32_t)(ZH_STORED_MAX - clen) << 16);
+      for (uint32_t i = 0; i < 4; i++) out[len_byte + i] = (uint8_t)(ln >> (8u * i));
     }
     if (lane == 0) a.b_stored_d0[b] = bd.dst_off + d0;
     return;
   }
   const uint32_t hbits = a.b_hdr_bits[b];
   const uint32_t* hdr = a.b_hdr + (size_t)b * ZH_HDR_WORDS;
-  for (uint32_t w = lane; w * 32 < hbits; w += 64) {
-    const uint32_t nb = hbits - w * 32 < 32 ? hbits - w * 32 : 32;
-    or_bits(out, body_bit0 + cursor + (uint64_t)w * 32, hdr[w], nb);
-  }
-  cursor += hbits;
+  const uint32_t eob = a.b_litcode[(size_t)b * 288 + 256];
+  // words of d_dst this wave may zero: strictly between its block's first word and the next block's first word (the last
+  // block of a buffer: the word of the body's last bit); those two are zh_layout_kernel's
+  const uint64_t abs0 = (bd.dst_off + hdr_len) * 8;  // the body's first bit in d_dst
+  const uint64_t w_lo = (abs0 + cursor) >> 5;
+  const uint64_t w_hi = blk.is_final ? (abs0 + a.b_start[a.nblocks + blk.buf] - 1) >> 5 : (abs0 + a.b_start[b + 1]) >> 5;
+  uint32_t* const dwords = reinterpret_cast<uint32_t*>(d_dst);
+  auto zero_inner = [&](uint64_t abs_bit) {
+    const uint64_t w = abs_bit >> 5;
+    if (w > w_lo && w < w_hi) dwords[w] = 0u;
+  };
+  for (uint32_t w = lane; w * 32 < hbits; w += 64) zero_inner(abs0 + cursor + (uint64_t)w * 32);
+  if (lane == 0 && hbits) zero_inner(abs0 + cursor + hbits - 1);
+  uint64_t fcur = cursor + hbits;
   for (uint32_t base = 0; base < blk.nfrag; base += 64) {
     const uint32_t j = base + lane;
     const uint32_t fb = j < blk.nfrag ? a.f_bits[blk.first_frag + j] : 0u;
     // fragment sums fit in 32 bits: 64 fragments * 32 KiB * 15 bits < 2^32
     const uint32_t incl = zh_wave_scan(fb);
-    if (j < blk.nfrag)
-      a.f_bit_start[blk.first_frag + j] = (bd.dst_off + hdr_len) * 8 + cursor + (incl - fb);
-    cursor += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (j < blk.nfrag) {
+      const uint64_t fs = abs0 + fcur + (incl - fb);
+      a.f_bit_start[blk.first_frag + j] = fs;
+      zero_inner(fs);  // the fragment's first word = the last word of what lies before it (zh_emit.hip ORs into both)
+    }
+    fcur += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   }
-  const uint32_t eob = a.b_litcode[(size_t)b * 288 + 256];
-  if (lane == 0) or_bits(out, body_bit0 + cursor, eob & 0xffffu, eob >> 16);  // deflate.nim:471
+  if (lane == 0) {  // the end-of-block code: behind the last fragment, 15 bits at most
+    zero_inner(abs0 + fcur);
+    zero_inner(abs0 + fcur + (eob >> 16) - 1);
+  }
+  // (this wave's zeroes before this wave's ORs: stores and atomics of one wave are not ordered by themselves)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  zh_wave_sync();
+  for (uint32_t w = lane; w * 32 < hbits; w += 64) {
+    const uint32_t nb = hbits - w * 32 < 32 ? hbits - w * 32 : 32;
+    or_bits(out, body_bit0 + cursor + (uint64_t)w * 32, hdr[w], nb);
+  }
+  if (lane == 0) or_bits(out, body_bit0 + fcur, eob & 0xffffu, eob >> 16);  // deflate.nim:471
 }
 
 // zh_debug_huffman: one code from a histogram, by either builder (the tests hold the exact one against the oracle's

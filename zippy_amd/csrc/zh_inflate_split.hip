@@ -712,6 +712,10 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
             if (seg_target == rel && !g.is_sub[seg_tj]) break;  // (the loop above hands over to that segment's decoder)
             if (seg_tj < seg_last && seg_target != kSegNone && seg_target > rel) seg_stop = seg_target;
           }
+          // every wave has read the control words the header reader left (s_c_stored_len above all: a wave that
+          // read wave 0's count instead would skip the chain and leave the others at its barrier) before wave 0
+          // overwrites them for the first round
+          __syncthreads();
           if (tid < 64u) {
             const uint64_t o = (pos >> 3) + (uint64_t)lane * (ZH_STORED_MAX + 5u);  // (from asrc)
             const uint32_t w0 = load_dword(o & ~(uint64_t)3), w1 = load_dword((o & ~(uint64_t)3) + 4u),
@@ -1032,6 +1036,8 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
   __shared__ uint32_t s_val32[kWrRound * sizeof(Sym) / 4];  // a symbol per byte: its value (valid for roots)
   __shared__ uint32_t s_w[6][kWrWaves];       // per-wave partial results
   __shared__ uint32_t s_flag[4];              // round-wide flags (see below)
+  __shared__ uint32_t s_cut[2];               // the round's records that fit and their bytes: written by the ONE thread at the cut
+  __shared__ uint32_t s_carry[kWrWaves];      // (index + 1 of) the record that covers a wave's first byte, written by its owner
   uint16_t* const s_map = reinterpret_cast<uint16_t*>(s_map32);
   Sym* const s_val = reinterpret_cast<Sym*>(s_val32);
   const uint32_t tid = threadIdx.x, wv = tid >> 6;
@@ -1099,14 +1105,24 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
   if (tid < 4) s_flag[tid] = 0;
 #pragma unroll
   for (uint32_t j = 0; j < kB / 2u; j++) s_map32[(kB / 2u) * tid + j] = 0;
-
-  for (uint32_t round = 0;; round++) {
-    if (tid < 4) s_w[5][tid] = 0;  // (the pointer-doubling loop's flags)
+  commit_ahead();
+  fetch_ahead();
+  __syncthreads();
+  // A round ends with ONE barrier that does three things: the round's stores are visible (output_visible), the ring's
+  // next records are in place (a commit never touches records that are still to be read: it is only made when fewer than
+  // kWrRecs + 128 of the ring's 4 kWrRecs are), and everybody is done with the round's LDS.  A round itself: four
+  // barriers (record sums, byte map, pointers and values, the end) + one a pointer-doubling step -- three fewer than
+  // round 5's, which shared the cut (records that fit, their bytes) and the waves' carries in barriers of their own.
+  auto end_round = [&]() {
     if (hi < ti + kWrRecs + 128u) {  // a round looks at kWrRecs records (+ 2 behind a stored-run record)
       commit_ahead();
       fetch_ahead();
     }
-    __syncthreads();
+    output_visible();
+  };
+
+  for (uint32_t round = 0;; round++) {
+    if (tid < 4) s_w[5][tid] = 0;  // (the pointer-doubling loop's flags)
     const uint32_t i0 = kR * tid;
     uint32_t r[kR];
 #pragma unroll
@@ -1130,7 +1146,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
     uint32_t o[kR];
     bool fit[kR];
     {
-      uint32_t at = before + incl - sum, endl = 0, nfit = 0;
+      uint32_t at = before + incl - sum, endl = 0;
       bool bad = false;
 #pragma unroll
       for (uint32_t k = 0; k < kR; k++) {
@@ -1139,24 +1155,44 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
         if (fit[k]) endl = at + len[k];
         // inflate.nim:224-225 `distance > op` (a distance is at most 32768)
         bad = bad || (fit[k] && !((r[k] >> 9) & 1u) && (uint64_t)(r[k] >> 16) > gbase + op + at);
-        nfit += (uint32_t)__popcll(__ballot(fit[k]));
         at += len[k];
       }
-      const uint64_t b0 = __ballot(fit[0]);
-      const uint32_t wend = b0 ? (uint32_t)__builtin_amdgcn_readlane(endl, (uint32_t)__popcll(b0) - 1u) : 0u;
-      if (lane == 0) {
-        s_w[2][wv] = nfit;
-        s_w[3][wv] = wend;
-      }
       if (gbase + op < 32768u && bad) s_flag[round & 1u] = 1;  // (flag words alternate between rounds; the idle one is cleared below)
-    }
-    __syncthreads();
-    uint32_t n = 0, total = 0;
+      // The cut: the records that fit are a prefix of the round's (the sums grow), so exactly ONE thread sees where it
+      // ends -- the thread of the first record that does not fit (what lies before that record is what fits, and it ends
+      // where the record would start), or the last thread when every record fits.
+      {
+        uint32_t cn = 0xffffffffu, ct = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < kWrWaves; w++) {
-      n += s_w[2][w];
-      total = max(total, s_w[3][w]);
+        for (uint32_t k = 0; k < kR; k++)
+          if (cn == 0xffffffffu && !fit[k] && o[k] <= kWrRound) {  // (o[k] <= round: everything before it fits)
+            cn = i0 + k;
+            ct = o[k];
+          }
+        if (cn == 0xffffffffu && tid == kWrThreads - 1u && fit[kR - 1u]) {
+          cn = kWrRecs;
+          ct = endl;
+        }
+        if (cn != 0xffffffffu) {
+          s_cut[0] = cn;
+          s_cut[1] = ct;
+        }
+      }
     }
+    // ---- byte -> record (the map is all zeros here: whoever reads a word clears it), and for every wave the record
+    // that covers its first byte: the records tile the round's live bytes, so a live wave border has exactly one ----
+#pragma unroll
+    for (uint32_t k = 0; k < kR; k++)
+      if (fit[k]) {
+        s_map[o[k]] = (uint16_t)(i0 + k + 1u);
+        // (a record makes at most 258 bytes, a wave owns 64 kB >= 256: two borders at most)
+        constexpr uint32_t kWaveBytes = 64u * kB;
+        const uint32_t b1 = (o[k] + kWaveBytes - 1u) / kWaveBytes;  // the first wave border at or behind the record's start
+        if (b1 * kWaveBytes < o[k] + len[k]) s_carry[b1] = i0 + k + 1u;
+        if ((b1 + 1u) * kWaveBytes < o[k] + len[k]) s_carry[b1 + 1u] = i0 + k + 1u;
+      }
+    __syncthreads();
+    const uint32_t n = s_cut[0], total = s_cut[1];
     const bool bad_dist = s_flag[round & 1u] != 0;
     if (tid == 0) {
       s_flag[(round & 1u) ^ 1u] = 0;
@@ -1264,7 +1300,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
               break;
             }
           }
-          output_visible();
+          end_round();
           continue;
         }
         st = (int)(q0 >> 16);  // end of the stream
@@ -1273,7 +1309,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
       lz_copy(q0 & 0x1ffu, q0 >> 16);  // one copy that does not fit a round
       if (st != ZH_OK) break;
       ti += 1;
-      output_visible();
+      end_round();
       continue;
     }
     if (bad_dist) {
@@ -1284,11 +1320,6 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
       st = ZH_ERR_DST_TOO_SMALL;
       break;
     }
-    // ---- byte -> record (the map is all zeros here: whoever reads a word clears it) ----
-#pragma unroll
-    for (uint32_t k = 0; k < kR; k++)
-      if (fit[k]) s_map[o[k]] = (uint16_t)(i0 + k + 1u);
-    __syncthreads();
     uint32_t t[kB];
     uint32_t starts = 0;  // bit j: a record starts at this thread's byte j
     {
@@ -1305,13 +1336,9 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
       }
     }
     const uint32_t run = zh_wave_scan_max(t[kB - 1u]);
-    if (lane == 63) s_w[4][wv] = run;
     uint32_t carry = (uint32_t)__shfl_up((int)run, 1, 64);
     if (lane == 0) carry = 0;
-    __syncthreads();
-#pragma unroll
-    for (uint32_t w = 0; w < kWrWaves; w++)
-      if (w < wv) carry = max(carry, s_w[4][w]);
+    carry = max(carry, s_carry[wv]);  // (a border that is not live keeps an old value: its bytes are not live either)
     // ---- every byte: literal, copy from before the round (far), or from inside it (near) ----
     // Without a branch a byte (under each byte's own condition the compiler kept an exec mask a byte: a hundred
     // scalar instructions a round), and with the stream's output position in scalar registers -- it is the same in
@@ -1423,7 +1450,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
     }
     op += total;
     ti += n;
-    output_visible();
+    end_round();
   }
   if (kSeg && st == ZH_OK) {
     // the 32 KiB that end the segment, for zh_seg_windows_kernel: symbols of this segment, or --

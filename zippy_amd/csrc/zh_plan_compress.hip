@@ -20,7 +20,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   std::vector<ZhBlockDesc> blocks;
   std::vector<ZhFragDesc> frags;
   std::vector<ZhPieceDesc> pieces;
-  uint64_t lo = ~0ull, hi = 0, cap_sum = 0, cap_max = 0;
+  uint64_t cap_max = 0;
   for (size_t i = 0; i < n; i++) {
     ZhBufDesc& b = bufs[i];
     b.src_off = src_off[i];
@@ -59,9 +59,6 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
     }
     b.nblocks = (uint32_t)blocks.size() - b.first_block;
     b.npieces = (uint32_t)frags.size() - b.first_piece;
-    lo = std::min(lo, b.dst_off);
-    hi = std::max(hi, b.dst_off + b.dst_cap);
-    cap_sum += b.dst_cap;
     cap_max = std::max(cap_max, b.dst_cap);
   }
   if (blocks.size() >= 0xffffffffull || frags.size() >= 0xffffffffull) return ZH_ERR_ARGUMENT;
@@ -72,9 +69,6 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   p->n = n;
   p->level = level;
   p->fmt = data_format;
-  p->dst_lo = n ? lo : 0;
-  p->dst_hi = n ? hi : 0;
-  p->dst_dense = !n || cap_sum >= hi - lo;  // (overlapping slots are the caller's error either way)
   p->dst_max_cap = cap_max;
   const size_t nf = frags.size(), nb = blocks.size();
   const bool chain = level == -1 || level >= 2;
@@ -130,9 +124,17 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   const size_t o_head = ar.reserve(p->head_bytes);
   // one 32 KiB hash table per persistent matcher wave (zh_launch_l1_match: min(fragments, slots) waves)
   // (the parallel parse, zh_launch_l1p_match, keeps 128 KiB of table results per workgroup there instead)
-  const size_t o_l1tab = ar.reserve(level == 1 ? std::max(std::min<size_t>(nf, zh_l1_table_slots()) * 32768,
-                                                          std::min<size_t>(nf, zh_l1p_slots()) * 131072)
-                                               : 0);
+  const size_t l1tab_bytes = level == 1 ? std::max(std::min<size_t>(nf, zh_l1_table_slots()) * 32768,
+                                                   std::min<size_t>(nf, zh_l1p_slots()) * 131072)
+                                        : 0;
+  // ZH_L1_POOL=uncached / fine (measurement): the pool as an allocation of its own in memory the L2 does
+  // not allocate lines for (hipDeviceMallocUncached) / fine-grained memory, instead of a range of the arena
+  const int l1_pool_mode = [] {
+    const char* e = getenv("ZH_L1_POOL");
+    return !e ? 0 : strcmp(e, "uncached") == 0 ? 1 : strcmp(e, "fine") == 0 ? 2 : 0;
+  }();
+  const bool l1_pool_own = l1_pool_mode != 0 && l1tab_bytes != 0;
+  const size_t o_l1tab = ar.reserve(l1_pool_own ? 0 : l1tab_bytes);
   const size_t o_l1ctr = ar.reserve(256);
   const bool l1 = level == 1 || level == -2;
   const size_t o_l1cost = ar.reserve(l1 ? nf * 4 : 4), o_l1order = ar.reserve(l1 ? nf * 4 : 4), o_l1hist = ar.reserve(512 + (l1 ? (nf / 256 + 2) * 4 : 0));
@@ -145,6 +147,20 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
     delete p;
     return ZH_ERR_NOMEM;
   }
+#ifndef ZH_EMU
+  if (l1_pool_own &&
+      hipExtMallocWithFlags(&p->l1_pool_own, l1tab_bytes, l1_pool_mode == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->last_error = "hipExtMallocWithFlags(BestSpeed table pool, " + std::to_string(l1tab_bytes) + " bytes)";
+    zh_plan_destroy(p);
+    return ZH_ERR_NOMEM;
+  }
+#else
+  if (l1_pool_own && hipMalloc(&p->l1_pool_own, l1tab_bytes) != hipSuccess) {
+    zh_plan_destroy(p);
+    return ZH_ERR_NOMEM;
+  }
+#endif
   uint8_t* base = p->arena;
   hipStream_t s = ctx->stream;
   hipError_t up = hipSuccess;
@@ -211,7 +227,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   a.out_len = p->out_len = carve<uint64_t>(base, o_olen);
   a.status = p->status = carve<int32_t>(base, o_st);
   p->head_scratch = carve<uint32_t>(base, o_head);
-  p->l1_tables = carve<uint16_t>(base, o_l1tab);
+  p->l1_tables = p->l1_pool_own ? static_cast<uint16_t*>(p->l1_pool_own) : carve<uint16_t>(base, o_l1tab);
   p->l1_counter = carve<uint32_t>(base, o_l1ctr);
   if (l1) {
     p->l1_cost = carve<uint32_t>(base, o_l1cost);

@@ -117,12 +117,12 @@ extern "C" int zh_plan_pack(zh_plan* plan, const void* d_slots, void* d_packed, 
   }
   if (!d_slots || !d_packed || !d_offsets || plan->indexed) return ZH_ERR_ARGUMENT;
   ZH_HIP(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(zh_pack_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (uint32_t)plan->n, plan->out_len,
-                     plan->status, d_offsets);
   uint32_t pieces;
   uint64_t piece;
   piece_geometry(plan->dst_max_cap, &pieces, &piece);
-  if ((uint64_t)plan->n * pieces > 0x7fffffffull) return ZH_ERR_ARGUMENT;
+  if ((uint64_t)plan->n * pieces > 0x7fffffffull) return ZH_ERR_ARGUMENT;  // (before anything is launched or written)
+  hipLaunchKernelGGL(zh_pack_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (uint32_t)plan->n, plan->out_len,
+                     plan->status, d_offsets);
   hipLaunchKernelGGL((zh_pack_copy_kernel<false>), dim3((uint32_t)plan->n * pieces), dim3(256), 0, ctx->stream,
                      static_cast<const uint8_t*>(d_slots), static_cast<uint8_t*>(d_packed), plan->d_bufs, d_offsets, pieces,
                      piece, packed_cap);
@@ -136,6 +136,10 @@ extern "C" int zh_plan_unpack(zh_plan* plan, const void* d_packed, const uint64_
   if (!plan->n) return ZH_OK;
   if (!d_packed || !d_offsets || !d_slots) return ZH_ERR_ARGUMENT;
   ZH_HIP(ctx, hipSetDevice(ctx->device));
+  uint32_t pieces;
+  uint64_t piece;
+  piece_geometry(plan->src_max_len, &pieces, &piece);
+  if ((uint64_t)plan->n * pieces > 0x7fffffffull) return ZH_ERR_ARGUMENT;  // (before anything is launched or written)
   if (!plan->unpack_lens) {
     void* p = nullptr;
     ZH_HIP(ctx, ctx_malloc(ctx, &p, plan->n * sizeof(uint64_t)));
@@ -143,10 +147,6 @@ extern "C" int zh_plan_unpack(zh_plan* plan, const void* d_packed, const uint64_
   }
   hipLaunchKernelGGL(zh_unpack_lens_kernel, dim3(((uint32_t)plan->n + 255u) / 256u), dim3(256), 0, ctx->stream,
                      (uint32_t)plan->n, plan->d_bufs, d_offsets, plan->unpack_lens);
-  uint32_t pieces;
-  uint64_t piece;
-  piece_geometry(plan->src_max_len, &pieces, &piece);
-  if ((uint64_t)plan->n * pieces > 0x7fffffffull) return ZH_ERR_ARGUMENT;
   hipLaunchKernelGGL((zh_pack_copy_kernel<true>), dim3((uint32_t)plan->n * pieces), dim3(256), 0, ctx->stream,
                      static_cast<const uint8_t*>(d_packed), static_cast<uint8_t*>(d_slots), plan->d_bufs, d_offsets, pieces,
                      piece, ~0ull);

@@ -61,8 +61,11 @@ extern "C" int zh_plan_kernel_times(zh_plan* p, const char** names, float* ms, i
 extern "C" void zh_plan_destroy(zh_plan* p) {
   if (!p) return;
   // (nothing useful can be done about a failure while tearing down)
+  (void)hipSetDevice(p->ctx->device);
   (void)hipStreamSynchronize(p->ctx->stream);
+  if (p->ctx->aux_stream) (void)hipStreamSynchronize(p->ctx->aux_stream);  // (joined by every run; cheap when idle)
   if (p->arena) ctx_free(p->ctx, p->arena);
+  if (p->l1_pool_own) (void)hipFree(p->l1_pool_own);
   if (p->seg_arena) ctx_free(p->ctx, p->seg_arena);
   if (p->tok_pool && !p->tok_borrowed) ctx_free(p->ctx, p->tok_pool);
   if (p->sg_arena) ctx_free(p->ctx, p->sg_arena);
@@ -89,14 +92,9 @@ bool inflate_split_enabled(const zh_ctx* ctx) {
   }();
   return ctx->inflate_mode < 0 ? on : ctx->inflate_mode == 0;
 }
-// The context's second stream and its two events, made when first asked for; ZH_CHECKSUM_ASIDE=0 keeps a compress run's
-// checksum kernels in line on the context's stream (measurement).  Anything that fails leaves them in line as well.
-static bool checksum_aside(zh_ctx* ctx) {
-  static const bool on = [] {
-    const char* e = getenv("ZH_CHECKSUM_ASIDE");
-    return !(e && strcmp(e, "0") == 0);
-  }();
-  if (!on) return false;
+// The context's second stream and its two events, made when first asked for.  Anything that fails leaves the work in
+// line on the context's stream.
+static bool second_stream(zh_ctx* ctx) {
   if (!ctx->aux_stream) {
     if (hipStreamCreate(&ctx->aux_stream) != hipSuccess) {
       ctx->aux_stream = nullptr;
@@ -108,6 +106,33 @@ static bool checksum_aside(zh_ctx* ctx) {
   if (!ctx->aux_join && hipEventCreate(&ctx->aux_join) != hipSuccess) ctx->aux_join = nullptr;
   return ctx->aux_fork && ctx->aux_join;
 }
+// ZH_CHECKSUM_ASIDE=0 keeps a compress run's checksum kernels in line on the context's stream (measurement); it says
+// nothing about the uncompress batch's two halves, which have their own switch (ZH_INFLATE_HALVES)
+static bool checksum_aside(zh_ctx* ctx) {
+  static const bool on = [] {
+    const char* e = getenv("ZH_CHECKSUM_ASIDE");
+    return !(e && strcmp(e, "0") == 0);
+  }();
+  return on && second_stream(ctx);
+}
+// Work that was forked onto the second stream is joined on every way out of a run: an early return (a failed HIP
+// call between fork and join) must not leave kernels of the second stream reading the caller's buffers unordered
+// with the caller's stream -- the caller may free or reuse them as soon as its own stream has drained.
+namespace {
+struct AuxJoinGuard {
+  zh_ctx* ctx;
+  hipStream_t s;
+  bool forked = false;
+  ~AuxJoinGuard() {
+    if (!forked) return;
+    if (hipEventRecord(ctx->aux_join, ctx->aux_stream) != hipSuccess ||
+        hipStreamWaitEvent(s, ctx->aux_join, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(ctx->aux_stream);
+    }
+  }
+};
+}  // namespace
 // ZH_L1_ORDER=0: fragments as numbered in every run (measurement: what a plan's first run costs)
 static bool l1_longest_first() {
   static const bool on = [] {
@@ -175,30 +200,6 @@ void plan_lend_token_pool(zh_plan* p, uint32_t* pool, uint64_t words) {
   if (p->tok_pool || p->tok_failed || !p->tok_words || p->tok_words > words) return;
   p->tok_pool = pool;
   p->tok_borrowed = true;
-}
-
-// Output slots start out zeroed (every shared output word is OR-ed into place).  Slots that tile
-// one range are cleared with a single memset; slots with gaps between them are cleared one by
-// one, byte-exact, so that caller data lying between two slots is never touched.
-__global__ __launch_bounds__(256) void zh_zero_slots_kernel(uint8_t* __restrict__ d_dst,
-                                                            const ZhBufDesc* __restrict__ bufs,
-                                                            uint32_t parts) {
-  // `parts` workgroups share a slot
-  const uint32_t part = blockIdx.x % parts;
-  const ZhBufDesc b = bufs[blockIdx.x / parts];
-  uint8_t* const base = d_dst + b.dst_off;
-  const uint64_t cap = b.dst_cap;
-  uint64_t head = (16u - ((uintptr_t)base & 15u)) & 15u;
-  if (head > cap) head = cap;
-  const uint64_t nvec = (cap - head) >> 4;
-  uint4* const body = reinterpret_cast<uint4*>(base + head);
-  for (uint64_t i = (uint64_t)part * 256u + threadIdx.x; i < nvec; i += (uint64_t)parts * 256u)
-    body[i] = make_uint4(0, 0, 0, 0);
-  if (part == 0) {
-    if (threadIdx.x < head) base[threadIdx.x] = 0;
-    const uint64_t t0 = head + (nvec << 4);
-    if (t0 + threadIdx.x < cap) base[t0 + threadIdx.x] = 0;
-  }
 }
 
 // ZH_TRACE_SEG: why a large stream was not decoded segment-wise (the run waits for the chain kernel and reads its
@@ -277,22 +278,15 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
   uint8_t* d_dst = (uint8_t*)d_dst_v;
   p->k_names.clear();
   if (!p->n) return ZH_OK;
+  // (a caller that drives two contexts' plans from one thread: the launches below go to the current device)
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
+  AuxJoinGuard aux{ctx, s};
   if (p->is_compress) {
     const ZhCompressArgs& a = p->ca;
     const int want_crc = p->fmt == ZH_DF_GZIP || p->force_crc, want_adler = p->fmt == ZH_DF_ZLIB;
-    // every shared output word is OR-ed into place, so the slots start out zeroed
-    // zh_emit_kernel and zh_layout_kernel address the output as aligned 32-bit words
+    // zh_emit_kernel and the layout kernels address the output as aligned 32-bit words.  Nothing is cleared beforehand:
+    // every word that is OR-ed into is zeroed by the layout kernels first, everything else is stored whole (zh_huffman.hip)
     if ((uintptr_t)d_dst & 3u) return ZH_ERR_ARGUMENT;
-    prof_mark(p, "memset_dst");
-    if (p->dst_dense) {
-      ZH_HIP(ctx, hipMemsetAsync(d_dst + p->dst_lo, 0, p->dst_hi - p->dst_lo, s));
-    } else {
-      uint32_t gy = (uint32_t)std::min<uint64_t>(64, (p->dst_max_cap >> 16) + 1);
-      while (gy > 1 && (uint64_t)p->n * gy > 0x7fffffffull) gy >>= 1;  // (a grid has fewer than 2^31 workgroups)
-      if ((uint64_t)p->n * gy > 0x7fffffffull) return ZH_ERR_ARGUMENT;
-      hipLaunchKernelGGL(zh_zero_slots_kernel, dim3((uint32_t)p->n * gy), dim3(256), 0, s, d_dst, p->d_bufs, gy);
-      ZH_HIP(ctx, hipGetLastError());
-    }
     if (p->level == 1 && l1_parallel(ctx)) {
       prof_mark(p, "zh_l1p_match_kernel");
       zh_launch_l1p_match(s, d_src, a, p->l1_tables, p->l1_counter);
@@ -339,6 +333,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
         cs = ctx->aux_stream;
         ZH_HIP(ctx, hipEventRecord(ctx->aux_fork, s));
         ZH_HIP(ctx, hipStreamWaitEvent(cs, ctx->aux_fork, 0));
+        aux.forked = true;
         if (p->profiling) {
           for (hipEvent_t& e : p->k_aux)
             if (!e && hipEventCreate(&e) != hipSuccess) p->profiling = false;
@@ -366,7 +361,10 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       // its own --, and the checksum has the emission to run beside as well: it takes three times as long there, the
       // emission 5 % longer, and the pair ends 0.25 ms sooner)
       trailer_late = aside && p->trailer_late;
-      if (aside && !trailer_late) ZH_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_join, 0));
+      if (aside && !trailer_late) {
+        ZH_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_join, 0));
+        aux.forked = false;
+      }
     } else {
       prof_mark(p, "zh_huffman_kernel");
       // (contract mode -- zh_set_l1_parse(ctx, 1), BestSpeed only -- also builds the block's codes without the
@@ -380,6 +378,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     if (trailer_late) {
       prof_mark(p, "zh_trailer_kernel");
       ZH_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_join, 0));
+      aux.forked = false;
       zh_launch_trailer(s, d_dst, a, p->buf_crc, p->buf_adler);
     }
     prof_mark(p, "end");
@@ -415,14 +414,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
         zh_launch_seg_tokens(s, d_src, a, p->tok_pool, p->sg, 5);
         zh_launch_seg_chain(s, a, p->sg, 1);
       }
-      if (!ctx->d_seg_stats) {
-        void* q = nullptr;
-        if (ctx_malloc(ctx, &q, 16) == hipSuccess) {
-          ctx->d_seg_stats = static_cast<uint64_t*>(q);
-          ZH_HIP(ctx, hipMemsetAsync(q, 0, 16, s));
-        }
-      }
-      zh_launch_seg_stats(s, p->sg, ctx->d_seg_stats);
+      zh_launch_seg_stats(s, p->sg, ctx->d_seg_stats);  // (the context's two counters: made and zeroed by zh_create)
       if (p->sg_trace) seg_trace(p, s);
       if (!a.count_only) {
         prof_mark(p, "zh_seg_write_kernel");
@@ -443,7 +435,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     } else if (split) {
       // two kernels: tokens (parallel over each stream), then bytes (zh_inflate_split.hip)
       p->k_half_used = false;
-      if (p->tok_groups.size() <= 1 && p->halves_min >= 2u && a1.nbufs >= p->halves_min && checksum_aside(ctx)) {
+      if (p->tok_groups.size() <= 1 && p->halves_min >= 2u && a1.nbufs >= p->halves_min && second_stream(ctx)) {
         // Two halves, the second on the context's second stream: 4096 workgroups are 3.2 rounds of the machine for
         // either kernel, and both wait more than they work -- side by side a half's writer fills what
         // the other half's tokens kernel leaves idle, and only the last tail is nobody's to fill (own streams 20.8 ->
@@ -456,6 +448,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
         hipStream_t s2 = ctx->aux_stream;
         ZH_HIP(ctx, hipEventRecord(ctx->aux_fork, s));
         ZH_HIP(ctx, hipStreamWaitEvent(s2, ctx->aux_fork, 0));
+        aux.forked = true;
         if (p->profiling) {
           for (hipEvent_t& e : p->k_half)
             if (!e && hipEventCreate(&e) != hipSuccess) p->profiling = false;
@@ -473,6 +466,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
         zh_launch_inflate_write(s, d_src, d_dst, ah[0], p->tok_pool, p->tok_off);
         prof_mark(p, "(waiting for the other half)");
         ZH_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_join, 0));
+        aux.forked = false;
       } else if (p->tok_groups.size() <= 1) {
         prof_mark(p, "zh_inflate_tokens_kernel");
         zh_launch_inflate_tokens(s, d_src, a1, p->tok_pool, p->tok_off, p->tok_cap);
@@ -517,6 +511,7 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
 extern "C" int zh_plan_results(zh_plan* p, uint64_t* out_lens, int32_t* statuses) {
   if (!p) return ZH_ERR_ARGUMENT;
   zh_ctx* ctx = p->ctx;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
   if (out_lens) ZH_HIP(ctx, hipMemcpyAsync(out_lens, p->out_len, p->n * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (statuses) ZH_HIP(ctx, hipMemcpyAsync(statuses, p->status, p->n * 4, hipMemcpyDeviceToHost, ctx->stream));
   ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -542,6 +537,7 @@ extern "C" int zh_plan_request_crc32(zh_plan* p, int on) {
 extern "C" int zh_plan_crc32(zh_plan* p, uint32_t* crcs) {
   if (!p || !crcs || !p->buf_crc) return ZH_ERR_ARGUMENT;
   zh_ctx* ctx = p->ctx;
+  ZH_HIP(ctx, hipSetDevice(ctx->device));
   ZH_HIP(ctx, hipMemcpyAsync(crcs, p->buf_crc, p->n * 4, hipMemcpyDeviceToHost, ctx->stream));
   ZH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZH_OK;

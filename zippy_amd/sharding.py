@@ -135,15 +135,32 @@ def scatter_variable(batch_bytes, lens, n_buffers, root=0, group=None, device=No
     return mine, lens[lo:hi]
 
 
+def _engine_stream(plan, device):
+    """The stream the plan's engine launches on, as a torch stream (zh_stream; None for CPU tensors: the emulator's
+    launches are synchronous).  It need not be torch's current stream -- an Engine made without one owns its own --, so
+    the two functions below order the two explicitly instead of assuming they are the same."""
+    if device.type != "cuda":
+        return None
+    ptr = plan.engine.stream()
+    return torch.cuda.ExternalStream(ptr, device=device) if ptr else torch.cuda.default_stream(device)
+
+
 def pack_plan(plan, slots, n_buffers):
     """The results of a device-resident plan (zippy_amd Plan; `slots`: the uint8 tensor its run wrote into) packed back
     to back on the device -- zh_plan_pack: two launches on the engine's stream, no per-buffer copy, the lengths are
     the ones the run left on the device -> (bytes, lens) as gather_variable takes them.  One host read: the total."""
     packed = torch.empty(max(1, slots.numel()), dtype=torch.uint8, device=slots.device)
     offs = torch.zeros(n_buffers + 1, dtype=torch.int64, device=slots.device)
+    es = _engine_stream(plan, slots.device)
+    if es is not None:
+        cur = torch.cuda.current_stream(slots.device)
+        es.wait_stream(cur)  # `offs` is zeroed, `slots` may have been produced, on torch's stream
+        packed.record_stream(es)
+        offs.record_stream(es)
     plan.pack(slots.data_ptr(), packed.data_ptr(), packed.numel(), offs.data_ptr())
-    if slots.is_cuda:
-        torch.cuda.current_stream(slots.device).synchronize()
+    if es is not None:
+        cur.wait_stream(es)  # what follows on torch's stream (the reads below, the sends) sees the packed bytes
+        es.synchronize()
     total = int(offs[n_buffers].item())
     assert total <= packed.numel()
     return packed[:total], offs[1:] - offs[:-1]
@@ -154,5 +171,10 @@ def unpack_into_plan(plan, packed, lens, slots):
     lengths with them (zh_plan_unpack)."""
     offs = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=slots.device)
     offs[1:] = torch.cumsum(lens.to(slots.device), 0)
+    es = _engine_stream(plan, slots.device)
+    if es is not None:
+        es.wait_stream(torch.cuda.current_stream(slots.device))  # `offs` and `packed` were made on torch's stream
+        offs.record_stream(es)
+        packed.record_stream(es)
     plan.unpack(packed.data_ptr(), offs.data_ptr(), slots.data_ptr())
     return offs  # (kept alive by the caller until the plan has run)
