@@ -486,7 +486,44 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
         pplan.close()
     cplan.close()
     uplan.close()
+    out["unsized"] = unsized_streams(eng, api, synth, min(256, nb))
     return out
+
+
+def unsized_streams(eng, api, synth, n, size=1 << 20, reps=3):
+    """Streams that carry no size (dfZlib: zippy.nim:130-165, the reference grows `dst` as it inflates) through the
+    HOST-buffer call zh_uncompress_batch, next to the same data as gzip members (ISIZE sizes the output up front).
+    Markup that compresses ~ 6 x: every stream outgrows the 4 x guess, so what is timed is the guess's failure, the
+    sizing pass (the tokens kernel's count-only form) and the second decode -- PCIe both ways included, like every
+    host-buffer number (tools/bench_unsized.py is the same measurement at 1024 streams)."""
+    import ctypes as c
+    bufs = [b.tobytes() for b in synth.gen_batch("html", n, size)]
+
+    def call(blobs, fmt):
+        k = len(blobs)
+        srcs = (c.c_void_p * k)(*[c.cast(c.c_char_p(z), c.c_void_p) for z in blobs])
+        lens = (c.c_size_t * k)(*[len(z) for z in blobs])
+        dsts, dlens, sts = (c.c_void_p * k)(), (c.c_size_t * k)(), (c.c_int32 * k)()
+        t = time.perf_counter()
+        rc = eng.lib.zh_uncompress_batch(eng._h, srcs, lens, k, fmt, dsts, dlens, sts)
+        dt = time.perf_counter() - t
+        ok = rc == 0 and not any(sts) and c.string_at(dsts[0], dlens[0]) == bufs[0] and \
+            c.string_at(dsts[k - 1], dlens[k - 1]) == bufs[k - 1]
+        for i in range(k):
+            eng.lib.zh_free(dsts[i])
+        assert ok, "unsized streams: zh_uncompress_batch"
+        return dt
+    res = {"workload": "%dx%dB html slices, host buffers, zh_uncompress_batch: zlib (no size field) vs gzip" % (n, size)}
+    for name, fmt in (("gzip", api.dfGzip), ("zlib", api.dfZlib)):
+        blobs, sts = eng.compress_batch(bufs, 1, fmt)
+        assert all(x == 0 for x in sts)
+        ts = [call(blobs, fmt) for _ in range(reps + 1)][1:]  # (the first call warms the context's device blocks up)
+        res[name + "_ms"] = round(min(ts) * 1e3, 3)
+        res["ratio"] = round(n * size / sum(len(z) for z in blobs), 3)
+    res["value"] = round(n * size / GIB / (res["zlib_ms"] * 1e-3), 3)
+    res["unit"] = "GiB/s"
+    res["zlib_vs_gzip"] = round(res["zlib_ms"] / res["gzip_ms"], 3)
+    return res
 
 
 def pp_fields(pp, N, comp_rank_exact, roof):
@@ -890,7 +927,7 @@ def main():
             "value_pp": out.get("value_parallel_parse"), "pp_ms": out.get("parallel_parse", {}).get("ms_per_step"),
             "frac": out["roofline"]["frac"], "dom": out["roofline"].get("kernel"), "dom_ms": out["roofline"]["avg_launch_ms"],
             "c2": cv("c2"), "c2_pp": cv("c2_parallel_parse"), "c3_own": cv("c3_own"), "c3_zlib6": cv("c3_zlib6"),
-            "c3_zlib_unsized": cv("c3_zlib_unsized"), "c4_share": cv("c4_share"), "c5": cv("c5"),
+            "unsized_zlib_vs_gzip": cv("unsized", "zlib_vs_gzip"), "c4_share": cv("c4_share"), "c5": cv("c5"),
             "share512_ms": cv("share512", "ms_per_step"), "share512_eff": cv("share512", "efficiency_vs_perfect_eighth"),
             "share512_pp_ms": cv("share512_parallel_parse", "ms_per_step"),
             "share512_pp_eff": cv("share512_parallel_parse", "efficiency_vs_perfect_eighth"),

@@ -120,6 +120,15 @@ def gen_batch(kind, n_buffers, size, first_index=0):
                 off = int(rng.integers(0, data.size - take + 1))
                 out[i, pos:pos + take] = data[off:off + take]
                 pos += take
+        elif kind == "html":  # markup only (slices of html_x_4): compresses 6-7 x -- streams that outgrow a 4 x size guess
+            rng = np.random.default_rng(SEED_BASE + 0x100000 + idx)
+            data = np.frombuffer(corpus_file("html_x_4"), dtype=np.uint8)
+            pos = 0
+            while pos < size:
+                take = min(int(rng.integers(16384, 65537)), size - pos)
+                off = int(rng.integers(0, data.size - take + 1))
+                out[i, pos:pos + take] = data[off:off + take]
+                pos += take
         else:
             raise ValueError(kind)
     return out

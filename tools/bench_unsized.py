@@ -19,21 +19,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def html_buffers(n, size):
-    """n buffers of `size` bytes: random-offset slices (16-64 KiB) of html_x_4, seeded."""
-    import numpy as np
+    """n buffers of `size` bytes: random-offset slices (16-64 KiB) of html_x_4, seeded (synth.gen_batch "html")."""
     import synth
-    base = np.frombuffer(synth.corpus_file("html_x_4"), dtype=np.uint8)
-    out = []
-    for i in range(n):
-        rng = np.random.default_rng(synth.SEED_BASE + 0x100000 + i)
-        parts, have = [], 0
-        while have < size:
-            ln = int(rng.integers(16384, 65537))
-            at = int(rng.integers(0, base.size - ln))
-            parts.append(base[at:at + ln])
-            have += ln
-        out.append(np.concatenate(parts)[:size].tobytes())
-    return out
+    return [b.tobytes() for b in synth.gen_batch("html", n, size)]
 
 
 def call_uncompress(eng, blobs, fmt):

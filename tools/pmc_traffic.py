@@ -70,9 +70,12 @@ def main():
         doc = None
     if doc is None:
         doc = {"source_sha": source_sha(),  # bench.py quotes these numbers only while the kernel sources are the ones measured
-               "calibration": "zh_checksum_pieces_kernel reads a known number of bytes once (dwordx4, coalesced)",
-               "note": "FETCH corrected by the dwordx4-stream factor (an upper bound for narrow gathers, whose requests are "
-                       "64 B and counted as such); WRITE_SIZE as reported (uncalibrated)",
+               "calibration": "zh_checksum_pieces_kernel reads a known number of bytes once (dwordx4, coalesced): the factor "
+                              "is only used for a kernel that has no sized pass",
+               "note": "hbm_bytes_per_launch = read requests counted by size (32 n32 + 64 n64 + 128 n128, "
+                       "fetch_by_request_size) + WRITE_SIZE as reported; hbm_bytes_per_launch_uncorrected = FETCH_SIZE + "
+                       "WRITE_SIZE as reported (FETCH_SIZE tallies a 128-byte request at 64 on gfx950).  Bytes across the "
+                       "L2's memory side, Infinity Cache hits included",
                "workloads": {}}
     calls, kib = fetch.get("zh_checksum_pieces_kernel", (0, 0))
     if a.known_bytes and calls and kib:

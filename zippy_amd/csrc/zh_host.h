@@ -42,6 +42,7 @@ void zh_launch_inflate_tokens(hipStream_t, const uint8_t* d_src, ZhInflateArgs a
                               const uint64_t* tok_off, const uint64_t* tok_cap);
 void zh_launch_inflate_write(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhInflateArgs a,
                              const uint32_t* tok_pool, const uint64_t* tok_off);
+void zh_launch_inflate_count(hipStream_t, const uint8_t* d_src, ZhInflateArgs a);
 void zh_launch_segments_reduce(hipStream_t, ZhInflateArgs seg, ZhInflateArgs whole);
 void zh_launch_seg_find(hipStream_t, const uint8_t* d_src, ZhInflateArgs a, ZhSegArgs g);
 void zh_launch_seg_fake_start(hipStream_t, ZhSegArgs g, uint64_t bit);

@@ -108,7 +108,11 @@ struct RunResult {
 // kSeg: a workgroup takes a SEGMENT of a stream (ZhSegArgs, zh_inflate_seg.hip): it starts at the
 // block the segment's search found, stops at the first block boundary at or behind the next found
 // start, and reports where that was, how many bytes its tokens make and whether the stream ended.
-template <uint32_t kSplitThreads, bool kSeg>
+// kCount: a SIZING pass (ZhInflateArgs::count_only: streams that carry no size and outgrew the guess made for them,
+// zippy.nim:130-165, zh_host_batch.hip): the same decode, but no record is written and no room is asked for -- the
+// stream's output bytes are summed and left in out_len.  An instantiation of its own: the batches' kernel keeps its
+// registers and its code.
+template <uint32_t kSplitThreads, bool kSeg, bool kCount = false>
 __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : kSplitThreads < 256 ? 4 : 1) void zh_inflate_tokens_kernel(const uint8_t* __restrict__ d_src,
                                                                 ZhInflateArgs a,
                                                                 uint32_t* __restrict__ tok_pool,
@@ -193,8 +197,8 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
     const bool one_block = ((load_dword(b0 & ~(uint64_t)3) >> (8u * (uint32_t)(b0 & 3u))) & 1u) != 0u;
     if (one_block != (route == 9)) return;
   }
-  uint32_t* const tok = tok_pool + (kSeg ? g.eff_tok_off[sid] : tok_off[sid]);
-  const uint64_t cap = kSeg ? g.eff_tok_cap[sid] : tok_cap[sid];  // records this stream may write (the end record included)
+  uint32_t* const tok = kCount ? nullptr : tok_pool + (kSeg ? g.eff_tok_off[sid] : tok_off[sid]);
+  const uint64_t cap = kCount ? ~0ull : kSeg ? g.eff_tok_cap[sid] : tok_cap[sid];  // records this stream may write (the end record included)
   __shared__ uint32_t s_wbytes[kWaves];
 
   // stream position in bits (from asrc)
@@ -369,7 +373,9 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
         p += tb2;
         rec += rec2;
       }
-      if (out && !last) {
+      if (kCount) {
+        if (!last) r.bytes += rec & 0x1ffu;
+      } else if (out && !last) {
         out[r.n] = rec;
         if (kSeg) r.bytes += rec & 0x1ffu;
       }
@@ -681,11 +687,11 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
       const uint32_t len = s_c_stored_len;
       const uint64_t byte_pos = pos >> 3;  // from asrc
       if (len) {  // (an empty stored block leaves no record: every record group makes output)
-        if (ntok + 3 + 1 > cap) {
+        if (!kCount && ntok + 3 + 1 > cap) {
           st = ZH_ERR_DST_TOO_SMALL;
           break;
         }
-        if (tid == 0) {
+        if (!kCount && tid == 0) {
           const uint64_t off = byte_pos - mis;  // from the stream's first byte
           tok[ntok] = kRecSpecial | kRecStored | (len << 16);
           tok[ntok + 1] = (uint32_t)off;
@@ -734,10 +740,10 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
             // empty block
             const uint32_t tail_len = (uint32_t)__shfl((int)blen, (int)(m < 64u ? m : 0u), 64);
             const uint32_t nrec = cnt - (tail_ok && tail_len == 0u ? 1u : 0u);
-            const uint64_t room = cap > ntok + 4u ? (cap - ntok - 4u) / 3u + 1u : (cap == ntok + 4u ? 1u : 0u);
+            const uint64_t room = kCount ? 64u : cap > ntok + 4u ? (cap - ntok - 4u) / 3u + 1u : (cap == ntok + 4u ? 1u : 0u);
             const bool over = nrec > room;
             const uint32_t nfit = over ? (uint32_t)room : nrec;
-            if (lane < nfit) {
+            if (!kCount && lane < nfit) {
               const uint64_t off = o + 5u - mis;
               tok[ntok + 3u * lane] = kRecSpecial | kRecStored | (blen << 16);
               tok[ntok + 3u * lane + 1u] = (uint32_t)off;
@@ -754,13 +760,13 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
               s_c_pos = (o + 5u + blen) * 8u;                             // behind the last block taken
               s_c_final = h & 1u;
             }
-            if (kSeg) {  // the bytes the records make (blocks 0 .. nfit - 1; an empty last one adds nothing)
+            if (kSeg || kCount) {  // the bytes the records make (blocks 0 .. nfit - 1; an empty last one adds nothing)
               const uint32_t made = zh_wave_sum(lane < nfit ? blen : 0u);
               if (lane == 0) s_wbytes[0] = made;
             }
           }
           __syncthreads();
-          if (kSeg) out_bytes += s_wbytes[0];
+          if (kSeg || kCount) out_bytes += s_wbytes[0];
           const uint32_t took = s_c_stored_len, nrec = s_c_endrel;
           const bool over = s_c_term != 0u;
           if (took) {
@@ -954,7 +960,7 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
         if (w < (tid >> 6)) before += ws;
         total += ws;
       }
-      if (ntok + total + 1 > cap) {  // more tokens than output bytes fit the slot
+      if (!kCount && ntok + total + 1 > cap) {  // more tokens than output bytes fit the slot
         st = ZH_ERR_DST_TOO_SMALL;
         break;
       }
@@ -966,8 +972,8 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
       // (parking every run's records in HBM and copying them into place here was tried: the
       // scattered 4-byte stores of the speculative turns cost more than this second decode)
       uint32_t made = 0;
-      if (active && r.n) made = run(std::true_type{}, my_start, limit, end_rel, tok + ntok + before).bytes;
-      if (kSeg) {
+      if (active && r.n) made = run(std::true_type{}, my_start, limit, end_rel, kCount ? nullptr : tok + ntok + before).bytes;
+      if (kSeg || kCount) {
         made = zh_wave_sum(made);
         if (lane == 0) s_wbytes[tid >> 6] = made;
         __syncthreads();
@@ -986,7 +992,11 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
     if (kSeg && seg_landed) break;
   }
   if (tid == 0) {
-    tok[ntok] = kRecSpecial | kRecEnd | ((uint32_t)st << 16);
+    if (!kCount) tok[ntok] = kRecSpecial | kRecEnd | ((uint32_t)st << 16);
+    if (kCount) {  // the sizing pass's answer (what zh_inflate_kernel leaves when it only counts)
+      a.out_len[sid] = out_bytes;
+      a.status[sid] = st;
+    }
     if (kSeg) {
       g.end_bit[sid] = pos - (uint64_t)mis * 8;
       g.final_block[sid] = final_block && !seg_landed ? 1u : 0u;  // (a decoder that hands over inside the last block has not ended the stream)
@@ -1010,6 +1020,11 @@ __global__ __launch_bounds__(kSplitThreads, kSplitThreads == 256 ? ZH_TOK_OCC : 
 // LDS and L2 round trips: wide rounds are what shortens it (64-byte rounds by one wave: 13 ms for
 // a 1 MiB stream whatever the batch).  A single copy that does not fit a round goes alone.
 // ---------------------------------------------------------------------------
+// (Round 6 measured a round with FEWER BARRIERS -- the cut (records that fit, their bytes) and the waves' carries written by
+// the threads that own them instead of through per-wave sums and a barrier each, the ring's commit merged into the round's
+// last barrier: 4 + k barriers a round instead of 7 + k, byte-identical -- and it was SLOWER, 12.00 -> 12.42 ms for 4096 x
+// 1 MiB in one launch (the merged barrier alone: 12.11; the owner-written cut alone: 12.44): with five workgroups a CU a
+// barrier is time another workgroup fills, the two dozen instructions that replaced two of them are not.  profiles/r06_d_*.)
 // kWrThreads: 256 (batches), 512 (a few hundred streams) or 1024 (up to a stream per CU); a round is kB bytes a thread.
 // (Round 4 measured the same kernel on ONE wave a stream -- 512-byte rounds, no barrier that costs anything, all 4096
 // streams of the bench batch resident at once, 16 a CU --: 15.95 ms against 13.57 on the same box, and 7.8 ms against
@@ -1036,8 +1051,6 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
   __shared__ uint32_t s_val32[kWrRound * sizeof(Sym) / 4];  // a symbol per byte: its value (valid for roots)
   __shared__ uint32_t s_w[6][kWrWaves];       // per-wave partial results
   __shared__ uint32_t s_flag[4];              // round-wide flags (see below)
-  __shared__ uint32_t s_cut[2];               // the round's records that fit and their bytes: written by the ONE thread at the cut
-  __shared__ uint32_t s_carry[kWrWaves];      // (index + 1 of) the record that covers a wave's first byte, written by its owner
   uint16_t* const s_map = reinterpret_cast<uint16_t*>(s_map32);
   Sym* const s_val = reinterpret_cast<Sym*>(s_val32);
   const uint32_t tid = threadIdx.x, wv = tid >> 6;
@@ -1105,24 +1118,14 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
   if (tid < 4) s_flag[tid] = 0;
 #pragma unroll
   for (uint32_t j = 0; j < kB / 2u; j++) s_map32[(kB / 2u) * tid + j] = 0;
-  commit_ahead();
-  fetch_ahead();
-  __syncthreads();
-  // A round ends with ONE barrier that does three things: the round's stores are visible (output_visible), the ring's
-  // next records are in place (a commit never touches records that are still to be read: it is only made when fewer than
-  // kWrRecs + 128 of the ring's 4 kWrRecs are), and everybody is done with the round's LDS.  A round itself: four
-  // barriers (record sums, byte map, pointers and values, the end) + one a pointer-doubling step -- three fewer than
-  // round 5's, which shared the cut (records that fit, their bytes) and the waves' carries in barriers of their own.
-  auto end_round = [&]() {
+
+  for (uint32_t round = 0;; round++) {
+    if (tid < 4) s_w[5][tid] = 0;  // (the pointer-doubling loop's flags)
     if (hi < ti + kWrRecs + 128u) {  // a round looks at kWrRecs records (+ 2 behind a stored-run record)
       commit_ahead();
       fetch_ahead();
     }
-    output_visible();
-  };
-
-  for (uint32_t round = 0;; round++) {
-    if (tid < 4) s_w[5][tid] = 0;  // (the pointer-doubling loop's flags)
+    __syncthreads();
     const uint32_t i0 = kR * tid;
     uint32_t r[kR];
 #pragma unroll
@@ -1146,7 +1149,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
     uint32_t o[kR];
     bool fit[kR];
     {
-      uint32_t at = before + incl - sum, endl = 0;
+      uint32_t at = before + incl - sum, endl = 0, nfit = 0;
       bool bad = false;
 #pragma unroll
       for (uint32_t k = 0; k < kR; k++) {
@@ -1155,44 +1158,24 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
         if (fit[k]) endl = at + len[k];
         // inflate.nim:224-225 `distance > op` (a distance is at most 32768)
         bad = bad || (fit[k] && !((r[k] >> 9) & 1u) && (uint64_t)(r[k] >> 16) > gbase + op + at);
+        nfit += (uint32_t)__popcll(__ballot(fit[k]));
         at += len[k];
       }
+      const uint64_t b0 = __ballot(fit[0]);
+      const uint32_t wend = b0 ? (uint32_t)__builtin_amdgcn_readlane(endl, (uint32_t)__popcll(b0) - 1u) : 0u;
+      if (lane == 0) {
+        s_w[2][wv] = nfit;
+        s_w[3][wv] = wend;
+      }
       if (gbase + op < 32768u && bad) s_flag[round & 1u] = 1;  // (flag words alternate between rounds; the idle one is cleared below)
-      // The cut: the records that fit are a prefix of the round's (the sums grow), so exactly ONE thread sees where it
-      // ends -- the thread of the first record that does not fit (what lies before that record is what fits, and it ends
-      // where the record would start), or the last thread when every record fits.
-      {
-        uint32_t cn = 0xffffffffu, ct = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < kR; k++)
-          if (cn == 0xffffffffu && !fit[k] && o[k] <= kWrRound) {  // (o[k] <= round: everything before it fits)
-            cn = i0 + k;
-            ct = o[k];
-          }
-        if (cn == 0xffffffffu && tid == kWrThreads - 1u && fit[kR - 1u]) {
-          cn = kWrRecs;
-          ct = endl;
-        }
-        if (cn != 0xffffffffu) {
-          s_cut[0] = cn;
-          s_cut[1] = ct;
-        }
-      }
     }
-    // ---- byte -> record (the map is all zeros here: whoever reads a word clears it), and for every wave the record
-    // that covers its first byte: the records tile the round's live bytes, so a live wave border has exactly one ----
-#pragma unroll
-    for (uint32_t k = 0; k < kR; k++)
-      if (fit[k]) {
-        s_map[o[k]] = (uint16_t)(i0 + k + 1u);
-        // (a record makes at most 258 bytes, a wave owns 64 kB >= 256: two borders at most)
-        constexpr uint32_t kWaveBytes = 64u * kB;
-        const uint32_t b1 = (o[k] + kWaveBytes - 1u) / kWaveBytes;  // the first wave border at or behind the record's start
-        if (b1 * kWaveBytes < o[k] + len[k]) s_carry[b1] = i0 + k + 1u;
-        if ((b1 + 1u) * kWaveBytes < o[k] + len[k]) s_carry[b1 + 1u] = i0 + k + 1u;
-      }
     __syncthreads();
-    const uint32_t n = s_cut[0], total = s_cut[1];
+    uint32_t n = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kWrWaves; w++) {
+      n += s_w[2][w];
+      total = max(total, s_w[3][w]);
+    }
     const bool bad_dist = s_flag[round & 1u] != 0;
     if (tid == 0) {
       s_flag[(round & 1u) ^ 1u] = 0;
@@ -1300,7 +1283,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
               break;
             }
           }
-          end_round();
+          output_visible();
           continue;
         }
         st = (int)(q0 >> 16);  // end of the stream
@@ -1309,7 +1292,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
       lz_copy(q0 & 0x1ffu, q0 >> 16);  // one copy that does not fit a round
       if (st != ZH_OK) break;
       ti += 1;
-      end_round();
+      output_visible();
       continue;
     }
     if (bad_dist) {
@@ -1320,6 +1303,11 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
       st = ZH_ERR_DST_TOO_SMALL;
       break;
     }
+    // ---- byte -> record (the map is all zeros here: whoever reads a word clears it) ----
+#pragma unroll
+    for (uint32_t k = 0; k < kR; k++)
+      if (fit[k]) s_map[o[k]] = (uint16_t)(i0 + k + 1u);
+    __syncthreads();
     uint32_t t[kB];
     uint32_t starts = 0;  // bit j: a record starts at this thread's byte j
     {
@@ -1336,9 +1324,13 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
       }
     }
     const uint32_t run = zh_wave_scan_max(t[kB - 1u]);
+    if (lane == 63) s_w[4][wv] = run;
     uint32_t carry = (uint32_t)__shfl_up((int)run, 1, 64);
     if (lane == 0) carry = 0;
-    carry = max(carry, s_carry[wv]);  // (a border that is not live keeps an old value: its bytes are not live either)
+    __syncthreads();
+#pragma unroll
+    for (uint32_t w = 0; w < kWrWaves; w++)
+      if (w < wv) carry = max(carry, s_w[4][w]);
     // ---- every byte: literal, copy from before the round (far), or from inside it (near) ----
     // Without a branch a byte (under each byte's own condition the compiler kept an exec mask a byte: a hundred
     // scalar instructions a round), and with the stream's output position in scalar registers -- it is the same in
@@ -1450,7 +1442,7 @@ __global__ __launch_bounds__(kWrThreads, kWrThreads == 256 ? ZH_WR_OCC : kWrThre
     }
     op += total;
     ti += n;
-    end_round();
+    output_visible();
   }
   if (kSeg && st == ZH_OK) {
     // the 32 KiB that end the segment, for zh_seg_windows_kernel: symbols of this segment, or --
@@ -1507,6 +1499,16 @@ extern "C" void zh_launch_inflate_tokens(hipStream_t stream, const uint8_t* d_sr
   else {  // (phase 9: the streams of one block, 8: the others -- see the kernel)
     hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, false>), dim3(a.nbufs), dim3(256), 0, stream, d_src, a, tok_pool, tok_off, tok_cap, ZhSegArgs{}, 9);
     hipLaunchKernelGGL((zh_inflate_tokens_kernel<128, false>), dim3(a.nbufs), dim3(128), 0, stream, d_src, a, tok_pool, tok_off, tok_cap, ZhSegArgs{}, 8);
+  }
+}
+// A sizing pass over a batch (count_only): the same routing, no token pool.
+extern "C" void zh_launch_inflate_count(hipStream_t stream, const uint8_t* d_src, ZhInflateArgs a) {
+  if (!a.nbufs) return;
+  if (zh_tokens_width(a.nbufs) == 1024u) {
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<1024, false, true>), dim3(a.nbufs), dim3(1024), 0, stream, d_src, a, nullptr, nullptr, nullptr, ZhSegArgs{}, 1);
+  } else {
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<256, false, true>), dim3(a.nbufs), dim3(256), 0, stream, d_src, a, nullptr, nullptr, nullptr, ZhSegArgs{}, 9);
+    hipLaunchKernelGGL((zh_inflate_tokens_kernel<128, false, true>), dim3(a.nbufs), dim3(128), 0, stream, d_src, a, nullptr, nullptr, nullptr, ZhSegArgs{}, 8);
   }
 }
 // phase 0: sub-starts for the segments inside long blocks

@@ -483,6 +483,10 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
           zh_launch_inflate_write(s, d_src, d_dst, ag, p->tok_pool, p->tok_off);
         }
       }
+    } else if (a.count_only && !p->indexed && inflate_split_enabled(ctx)) {
+      // a sizing pass: the tokens kernel without its records (the serial decoder took several times the decode itself)
+      prof_mark(p, "zh_inflate_tokens_kernel");
+      zh_launch_inflate_count(s, d_src, a1);
     } else {
       prof_mark(p, "zh_inflate_kernel");
       zh_launch_inflate(s, d_src, d_dst, a1);
