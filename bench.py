@@ -363,6 +363,116 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
         return {"pack_ms": round(tp / reps, 4), "unpack_ms": round(tu / reps, 4), "packed_bytes": packed_bytes,
                 "slot_bytes": n * slot}
 
+    def pcie_times(d_src, n, size, cap, slot, level, chunks=4):
+        """The alternative to the RCCL scatter / gather when the batch lives in HOST memory ("report both"):
+        every GPU pulls its own shard over its own PCIe link.  One GPU's share, pinned host buffers: the four legs alone
+        (raw in, streams out, streams in, raw out), and both directions as ONE pipeline of `chunks` chunks -- copies on a
+        second stream beside the kernels of the chunk before, the streams packed on the device (zh_plan_pack), the host
+        only ever waiting for a chunk's byte count.  Never `value`: PCIe-inclusive."""
+        k = max(1, min(chunks, n))
+        bounds = [n * i // k for i in range(k + 1)]
+        h_raw = torch.empty(n * size, dtype=torch.uint8, pin_memory=True)
+        h_raw.copy_(d_src)
+        h_back = torch.empty(n * size, dtype=torch.uint8, pin_memory=True)
+        h_pack = torch.empty(n * slot, dtype=torch.uint8, pin_memory=True)
+        h_tot = torch.zeros(k, dtype=torch.int64, pin_memory=True)
+        d_in = torch.empty(n * size, dtype=torch.uint8, device="cuda")
+        d_comp = torch.empty(n * slot, dtype=torch.uint8, device="cuda")
+        d_pack = torch.empty(n * slot, dtype=torch.uint8, device="cuda")
+        d_comp2 = torch.empty(n * slot, dtype=torch.uint8, device="cuda")
+        d_out = torch.empty(n * size, dtype=torch.uint8, device="cuda")
+        d_offs = [torch.zeros(bounds[i + 1] - bounds[i] + 1, dtype=torch.int64, device="cuda") for i in range(k)]
+        cps, ups = [], []
+        for i in range(k):
+            idx = range(bounds[i], bounds[i + 1])
+            m = len(idx)
+            cps.append(eng.plan_compress([j * size for j in idx], [size] * m, [j * slot for j in idx], [cap] * m, level, api.dfGzip))
+            ups.append(eng.plan_uncompress([j * slot for j in idx], [cap] * m, [j * size for j in idx], [size] * m, api.dfGzip))
+        copy = torch.cuda.Stream()
+
+        def ev():
+            return torch.cuda.Event(enable_timing=True)
+
+        def trip():
+            """-> (wall ms of the whole pipeline, packed bytes a chunk)"""
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e_in, e_c, e_t = [ev() for _ in range(k)], [ev() for _ in range(k)], [ev() for _ in range(k)]
+            with torch.cuda.stream(copy):  # raw in: all chunks queued, in order
+                for i in range(k):
+                    lo, hi = bounds[i] * size, bounds[i + 1] * size
+                    d_in[lo:hi].copy_(h_raw[lo:hi], non_blocking=True)
+                    e_in[i].record(copy)
+            for i in range(k):  # compress + pack a chunk as soon as it is in; its byte count follows on the copy stream
+                stream.wait_event(e_in[i])
+                cps[i].run(d_in.data_ptr(), d_comp.data_ptr())
+                cps[i].pack(d_comp.data_ptr(), d_pack.data_ptr() + bounds[i] * slot, (bounds[i + 1] - bounds[i]) * slot,
+                            d_offs[i].data_ptr())
+                e_c[i].record(stream)
+                with torch.cuda.stream(copy):
+                    copy.wait_event(e_c[i])
+                    h_tot[i:i + 1].copy_(d_offs[i][-1:], non_blocking=True)
+                    e_t[i].record(copy)
+            tot = []
+            for i in range(k):  # streams out, chunk by chunk (the kernels of the chunks behind it are running)
+                e_t[i].synchronize()
+                tot.append(int(h_tot[i]))
+                lo = bounds[i] * slot
+                with torch.cuda.stream(copy):
+                    h_pack[lo:lo + tot[i]].copy_(d_pack[lo:lo + tot[i]], non_blocking=True)
+            copy.synchronize()
+            # ... and back: streams in, unpack + uncompress a chunk as soon as it is in, raw out
+            e_in2, e_u = [ev() for _ in range(k)], [ev() for _ in range(k)]
+            with torch.cuda.stream(copy):
+                for i in range(k):
+                    lo = bounds[i] * slot
+                    d_pack[lo:lo + tot[i]].copy_(h_pack[lo:lo + tot[i]], non_blocking=True)
+                    e_in2[i].record(copy)
+            for i in range(k):
+                stream.wait_event(e_in2[i])
+                ups[i].unpack(d_pack.data_ptr() + bounds[i] * slot, d_offs[i].data_ptr(), d_comp2.data_ptr())
+                ups[i].run(d_comp2.data_ptr(), d_out.data_ptr())
+                e_u[i].record(stream)
+                with torch.cuda.stream(copy):
+                    copy.wait_event(e_u[i])
+                    lo, hi = bounds[i] * size, bounds[i + 1] * size
+                    h_back[lo:hi].copy_(d_out[lo:hi], non_blocking=True)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3, tot
+        trip()  # warm-up (plans' first runs, pinned pages touched)
+        assert torch.equal(h_back, h_raw), "PCIe pipeline: round trip"
+        wall = min(trip()[0] for _ in range(3))
+        _, tot = trip()
+        for pl in ups:
+            _, usts = pl.results()
+            assert all(x == 0 for x in usts)
+        assert torch.equal(h_back, h_raw), "PCIe pipeline: round trip"
+        # the four legs alone, whole share at a time
+        e = [ev() for _ in range(5)]
+        packed = sum(tot)
+        legs = [0.0] * 4
+        for _ in range(3):
+            e[0].record(stream)
+            d_in.copy_(h_raw, non_blocking=True)
+            e[1].record(stream)
+            h_pack[:packed].copy_(d_pack[:packed], non_blocking=True)
+            e[2].record(stream)
+            d_pack[:packed].copy_(h_pack[:packed], non_blocking=True)
+            e[3].record(stream)
+            h_back.copy_(d_out, non_blocking=True)
+            e[4].record(stream)
+            e[4].synchronize()
+            legs = [legs[j] + e[j].elapsed_time(e[j + 1]) / 3.0 for j in range(4)]
+        for pl in cps + ups:
+            pl.close()
+        del d_in, d_comp, d_pack, d_comp2, d_out, h_raw, h_back, h_pack
+        torch.cuda.empty_cache()
+        return {"h2d_raw_ms": round(legs[0], 3), "d2h_streams_ms": round(legs[1], 3), "h2d_streams_ms": round(legs[2], 3),
+                "d2h_raw_ms": round(legs[3], 3), "legs_ms": round(sum(legs), 3), "packed_bytes": packed, "chunks": k,
+                "pipelined_trip_ms": round(wall, 3),
+                "note": "pinned host memory <-> this GPU, both directions of the share; pipelined = copies on a second "
+                        "stream beside the chunks' kernels, compress then uncompress (PCIe-inclusive: never `value`)"}
+
     def batch(tag, workload, n, size, level, do_c, do_u, foreign=None, nsteps=steps, l1_parse=-1, sample=0, pack=False):
         """sample: that many of the streams against oracle.compress at the same level, byte for byte (outside the
         timed region; the exact parse only); pack: time zh_plan_pack / zh_plan_unpack on the batch's streams."""
@@ -429,6 +539,21 @@ def side_configs(torch, eng, api, synth, stream, host, steps):
             out[tag]["parity_sample"] = oracle_sample(cplan, d_comp, data, comp_off, level, sample)
         if pack and cplan is not None and uplan is not None:
             out[tag].update(pack_times(cplan, uplan, d_comp, d_back, d_src, n, slot))
+            cplan.close()
+            uplan.close()
+            cplan = uplan = None
+            del d_comp, d_back
+            torch.cuda.empty_cache()
+            d_comp = d_back = None
+            # the trip as 1 (nothing overlaps: the baseline on equal footing), 2 and 4 chunks: a chunk's kernels are a
+            # smaller batch's -- latency chains that do not shrink with it --, so more chunks overlap more and compute slower
+            trips = {c: pcie_times(d_src, n, size, cap, slot, level, chunks=c) for c in (1, 2, 4)}
+            best = min(trips, key=lambda c: trips[c]["pipelined_trip_ms"])
+            pc = trips[best]
+            pc["trip_ms_by_chunks"] = {str(c): t["pipelined_trip_ms"] for c, t in trips.items()}
+            pc["value_incl_pcie"] = round(n * size / GIB / ((out[tag]["ms_per_step"] + pc["legs_ms"]) * 1e-3), 3)
+            pc["value_pipelined"] = round(n * size / GIB / (pc["pipelined_trip_ms"] * 1e-3), 3)
+            out[tag]["own_pcie_link"] = pc
         for pl in (cplan, uplan):
             if pl is not None:
                 pl.close()
@@ -931,6 +1056,7 @@ def main():
             "share512_ms": cv("share512", "ms_per_step"), "share512_eff": cv("share512", "efficiency_vs_perfect_eighth"),
             "share512_pp_ms": cv("share512_parallel_parse", "ms_per_step"),
             "share512_pp_eff": cv("share512_parallel_parse", "efficiency_vs_perfect_eighth"),
+            "share512_pcie_pipelined_ms": (cv("share512", "own_pcie_link") or {}).get("pipelined_trip_ms"),
             "cpu_GiBps": out.get("cpu_baseline", {}).get("value"), "cpu_cores": out.get("cpu_baseline", {}).get("cores"),
             "parity": (parity_sample or {}).get("identical"),
         }

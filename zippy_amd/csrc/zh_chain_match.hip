@@ -506,6 +506,13 @@ namespace {
 constexpr uint32_t kWalkThreads = 256u;
 }  // namespace
 // kChunk: positions a walk starts at the first of (512 x 1 MiB, this kernel in ms: 16: 40.3, 32: 36.8, 64: 40.7, 128: 47.4)
+// (Round 6: a WAVE's lanes taking the wave's chunks first come, first served -- a ballot and a count when a lane is done, the
+// wave's positions and so an XCD's footprint unchanged -- to keep more than two lanes in five alive: byte-identical, and
+// slower in every shape.  Walk + parse, ms, against 29.1 + 3.0 with one 32-position chunk a lane: two 16-position chunks a
+// lane 31.8 + 10.9 with walks ending 64 positions behind their chunk, 33.4 + 3.0 with the usual 16 384; four of 8: 40.4 + 10.3;
+// two of 32 / four of 16 / four of 32 (a wave over 4096 / 8192 positions): 40.1 / 47.2 / 51.1.  Shorter chunks pay more
+// walks that are not yet in step, wider waves pay locality -- what round 3 found for the workgroup-wide form.
+// profiles/r06_e_chain_walk_dynamic_chunks_ab.log)
 template <uint32_t kChunk, bool kNarrow>
 __global__ __launch_bounds__(kWalkThreads) void zh_chain_walk_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
                                                             int good, int nice, int max_chain,

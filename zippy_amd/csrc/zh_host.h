@@ -222,6 +222,7 @@ struct zh_plan {
   uint64_t* unpack_lens = nullptr;  // ... and the device-side lengths zh_plan_unpack leaves (allocated by its first call)
   // block index (zh_plan_block_index): host copies of the geometry
   std::vector<ZhBufDesc> h_bufs;
+  uint32_t half_piece = 0;  // uncompress plans: the first checksum piece of buffer n / 2 (the batch as two halves, zh_plan_run)
   std::vector<ZhBlockDesc> h_blocks;
   // block-parallel decode (zh_plan_uncompress_indexed): `ia` describes the one stream, `seg` its blocks
   bool force_crc = false;  // CRC-32 of the uncompressed side whatever the container (ZIP entries)

@@ -389,6 +389,10 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     const bool split_ok = !p->indexed && inflate_split_enabled(ctx) && plan_token_pool(p);
     const bool split = split_ok && !a.count_only;
     ZhInflateArgs a1 = a;
+    // both checksums: with dfDetect the format is only known per stream on the device
+    const int want_crc_u = p->fmt == ZH_DF_GZIP || p->fmt == ZH_DF_DETECT || p->force_crc;
+    const int want_adler_u = p->fmt == ZH_DF_ZLIB || p->fmt == ZH_DF_DETECT;
+    uint32_t ck_done = 0;  // checksum pieces already taken care of (the first half's, below)
     if (split_ok && p->segmented) {
       // a handful of large streams: many workgroups per stream (zh_inflate_seg.hip); streams whose
       // chain of segments does not hold are left to the ordinary kernels below.  A sizing pass
@@ -464,6 +468,14 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
         zh_launch_inflate_tokens(s, d_src, ah[0], p->tok_pool, p->tok_off, p->tok_cap);
         prof_mark(p, "zh_inflate_write_kernel");
         zh_launch_inflate_write(s, d_src, d_dst, ah[0], p->tok_pool, p->tok_off);
+        // (the first half's output is complete: its checksum pieces fill what the second half's tail leaves idle
+        // instead of waiting for it)
+        if ((want_crc_u || want_adler_u) && a1.first_buf == 0 && a1.nbufs == (uint32_t)p->n && p->half_piece) {
+          prof_mark(p, "zh_checksum_pieces_kernel");
+          zh_launch_checksum_pieces(s, ctx->cktabs, d_dst, p->d_pieces, p->half_piece, p->out_len, want_crc_u, want_adler_u,
+                                    p->piece_crc, p->piece_adler, p->piece_len);
+          ck_done = p->half_piece;
+        }
         prof_mark(p, "(waiting for the other half)");
         ZH_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_join, 0));
         aux.forked = false;
@@ -492,13 +504,12 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
       zh_launch_inflate(s, d_src, d_dst, a1);
     }
     if (!a.count_only) {
-      // both checksums: with dfDetect the format is only known per stream on the device
-      const int want_crc = p->fmt == ZH_DF_GZIP || p->fmt == ZH_DF_DETECT || p->force_crc;
-      const int want_adler = p->fmt == ZH_DF_ZLIB || p->fmt == ZH_DF_DETECT;
+      const int want_crc = want_crc_u, want_adler = want_adler_u;
       if (want_crc || want_adler) {
         prof_mark(p, "zh_checksum_pieces_kernel");
-        zh_launch_checksum_pieces(s, ctx->cktabs, d_dst, p->d_pieces, p->npieces, p->out_len,
-                                  want_crc, want_adler, p->piece_crc, p->piece_adler, p->piece_len);
+        zh_launch_checksum_pieces(s, ctx->cktabs, d_dst, p->d_pieces + ck_done, p->npieces - ck_done, p->out_len,
+                                  want_crc, want_adler, p->piece_crc + ck_done, p->piece_adler + ck_done,
+                                  p->piece_len + ck_done);
         prof_mark(p, "zh_checksum_combine_kernel");
         zh_launch_checksum_combine(s, ctx->cktabs, p->d_bufs, (uint32_t)p->n, p->piece_crc, p->piece_adler,
                                    p->piece_len, want_crc, want_adler, p->buf_crc, p->buf_adler);

@@ -198,6 +198,7 @@ extern "C" int zh_plan_uncompress(zh_ctx* ctx, size_t n, const uint64_t* src_off
   zh_plan* p = new zh_plan;
   p->ctx = ctx;
   p->is_compress = false;
+  p->half_piece = n >= 2 ? bufs[n / 2].first_piece : 0;
   p->n = n;
   p->fmt = data_format;
   for (const ZhBufDesc& b : bufs) {
