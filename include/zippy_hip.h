@@ -240,9 +240,9 @@ int zh_plan_uncompress(zh_ctx *ctx, size_t n, const uint64_t *src_off, const uin
  * Preconditions and side effects (compress plans):
  *  - d_dst must be 4-byte aligned (the encoder addresses the output as 32-bit words; slot
  *    offsets themselves may be any byte); a misaligned d_dst returns ZH_ERR_ARGUMENT;
- *  - every slot [dst_off, dst_off + dst_cap) is zeroed before encoding -- the whole slot, not
- *    only the bytes the stream ends up using.  Bytes of d_dst outside the slots are never
- *    modified (slots that tile one range are cleared by one memset, others one by one);
+ *  - nothing is cleared beforehand and nothing but a stream's own bytes is written: of slot i only
+ *    [dst_off, dst_off + out_len) changes -- whatever the slot held before --, the rest of the slot and
+ *    the bytes of d_dst between slots keep their contents (until round 6 the whole slot was zeroed first);
  *  - slots must not overlap.
  * Both directions read whole aligned 32-bit words around a source buffer, i.e. up to 3 bytes
  * before src_off and after src_off + src_len: those bytes must be mapped (true inside any

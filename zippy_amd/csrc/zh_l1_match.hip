@@ -97,6 +97,15 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
     table_size <<= 1;
     shift--;
   }
+  // (Round 6, two probes of what this kernel waits for, both byte-identical, both measured and taken out again.
+  // READS: a SECOND tag bit a slot kept in LDS (2 KiB more a wave, 17 waves a CU) and looked at BEFORE the table, so that a
+  // probe whose bit differs skips the 128-byte read of an entry that could only say "no": the fabric's read requests fell
+  // 645 M -> 529 M a GiB of input (- 18 %) and the kernel took 62.9-66.1 ms against 64.1-64.5.  WRITES: match records
+  // gathered in an LDS ring and written 64 at a time as whole lines instead of a partial write a batch: write requests
+  // 455 M -> 365 M (- 20 %), 62.0 / 62.1 / 64.7 ms against 63.5 / 63.6 / 63.4, and one GPU's share 8.9 -> 9.8 ms (the flush
+  // sits in the walk).  Neither the reads nor the writes are what a step waits for: it is the three DEPENDENT trips through
+  // a CU's in-order vector memory pipeline, each as long as the pipeline's oldest miss, and the walk behind them.
+  // profiles/r06_h_*, r06_i_*.)
   // A table entry is position | tag << 15: the tag is one more bit of the hash product of the
   // position's four bytes, so a probe whose tag differs cannot match and need not fetch the
   // candidate's bytes (half of the non-matching gathers, which are what this kernel's memory
