@@ -105,7 +105,11 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   // 455 M -> 365 M (- 20 %), 62.0 / 62.1 / 64.7 ms against 63.5 / 63.6 / 63.4, and one GPU's share 8.9 -> 9.8 ms (the flush
   // sits in the walk).  Neither the reads nor the writes are what a step waits for: it is the three DEPENDENT trips through
   // a CU's in-order vector memory pipeline, each as long as the pipeline's oldest miss, and the walk behind them.
-  // profiles/r06_h_*, r06_i_*.)
+  // ... and the first of the three is not what it seems either: the NEXT step's source bytes asked for before this step's
+  // walk -- 1 KiB a wave in registers, wherever the walk ends the step behind it reads inside it, the lanes' 16 bytes cut
+  // out by eight ds_bpermute -- took the trip off the chain and made the kernel SLOWER, 64.4 -> 68.95 ms (a share 9.07 ->
+  // 9.49, config 2 2.34 -> 2.49): the L1 serves that load quickly enough, as round 1's LDS ring had already said.
+  // profiles/r06_h_*, r06_i_*, r06_j_*.)
   // A table entry is position | tag << 15: the tag is one more bit of the hash product of the
   // position's four bytes, so a probe whose tag differs cannot match and need not fetch the
   // candidate's bytes (half of the non-matching gathers, which are what this kernel's memory
