@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_bench.json (BASELINE metric + configs 2-5 + the parallel-parse leg + cpu_baseline),
 #    _c4.json / _c4share.json (DefaultCompression, whole batch on one GPU / 512 x 1 MiB), _share512.json (one GPU's share of eight),
 #    _kernel_stats.csv (rocprofv3 --kernel-trace --stats of the bench command), _pytest_gpu.log,
-#    _host_api*.json, _single_call.json, _one_stream.json, _big_buffer.json (ONE buffer of 4 GiB + 12345 bytes; 1 GiB streams), _fuzz*.log, hbm_traffic.json (tools/prof/pmc_passes.sh: two --pmc passes a workload)
+#    _host_api*.json, _single_call.json, _one_stream.json, _unsized.json, _big_buffer.json (ONE buffer of 4 GiB + 12345 bytes; 1 GiB streams), _fuzz*.log, hbm_traffic.json (tools/prof/pmc_passes.sh: two --pmc passes a workload)
 R=$(pwd); T=${1:-r03}
 O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
@@ -27,6 +27,8 @@ timeout 300 python tools/bench_host_api.py --reps 2 2>/dev/null | tail -1 > $O/$
 timeout 300 python tools/bench_host_api.py --reps 2 --buffers 4096 2>/dev/null | tail -1 > $O/${T}_host_api_4096.json
 timeout 300 python tools/bench_single_call.py 2>/dev/null | tail -1 > $O/${T}_single_call.json
 timeout 600 python tools/bench_one_stream.py 2>/dev/null | tail -1 > $O/${T}_one_stream.json
+# streams without a size field (zlib / raw deflate that outgrow the 4 x guess) next to the same data as gzip members
+timeout 600 python tools/bench_unsized.py 2>/dev/null | tail -1 > $O/${T}_unsized.json
 # ONE buffer of more than 4 GiB against the oracle, byte for byte; 1 GiB streams of other kinds: decoded segment-wise?
 (timeout 400 python tools/gpu_big_buffer.py --mib 4100 2>/dev/null | tail -1
  for k in "--kind text" "--level -2" "--level 6" "--kind rand"; do timeout 200 python tools/gpu_big_buffer.py --mib 1024 --no-oracle --no-zlib $k 2>/dev/null | tail -1; done) > $O/${T}_big_buffer.json
