@@ -670,8 +670,13 @@ def check_unsized_streams(eng):
     import zlib
     import synth
     text = synth.corpus_file("alice29.txt")[:90000]
+    rnd = np.random.default_rng(11).integers(0, 256, 140001, dtype=np.uint8).tobytes()
     plain = [b"", b"a", text, b"\x00" * 300000, bytes(range(256)) * 40, b"ab" * 70000, text[:777],
-             b"\xff" * 1000000]
+             b"\xff" * 1000000,
+             # (round 6: the sizing pass runs on the tokens kernel's count-only form) markup that compresses 6-7 x in many
+             # dynamic blocks (system zlib's); three stored blocks and then a long run: stored chains and codes in one sized stream
+             rnd + b"\x07" * 2000003,
+             synth.corpus_file("html_x_4") + synth.corpus_file("html_x_4")[:190001]]
     for fmt, wb in ((oracle.dfZlib, 15), (oracle.dfDeflate, -15)):
         blobs = []
         for k, b in enumerate(plain):
