@@ -81,6 +81,30 @@ def test_gpu_cross_check_kernels():
     assert not any(n in syms(build.build()) for n in names), "a cross-check kernel in the product library"
 
 
+def test_gpu_l1_pool_memory_switch():
+    """ZH_L1_POOL=uncached / fine (read when a plan is made: child processes): the BestSpeed matcher's table pool as an
+    allocation of its own in uncached / fine-grained memory (the measurement switch of DESIGN.md 4.1) -- the oracle's
+    bytes either way, more fragments than waves so that tables are reused across fragments."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch; torch.cuda.init()\n"
+            "import oracle, synth, parity_cases as pc\n"
+            "from zippy_amd import api\n"
+            "eng = api.engine(); eng.set_gzip_fname_len(0)\n"
+            "bufs = [b.tobytes() for b in synth.gen_batch('mix', 200, 1 << 20)]\n"
+            "outs, sts = eng.compress_batch(bufs, 1, oracle.dfGzip)\n"
+            "assert all(s == 0 for s in sts)\n"
+            "for i in range(0, 200, 9): assert outs[i] == oracle.compress(bufs[i], 1, oracle.dfGzip, fname_len=0), i\n"
+            % (os.path.join(root, "tests"), root))
+    for mode in ("uncached", "fine"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZH_L1_POOL=mode), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, (mode, r.stdout[-1000:], r.stderr[-3000:])
+
+
 def test_gpu_damaged_headers(eng, inflate_mode):
     """Every bit of three dynamic headers flipped in turn (2 160 raw deflate streams): the wave-parallel header
     reader, its fall-back to the serial one and the workgroup-built tables against the oracle."""
