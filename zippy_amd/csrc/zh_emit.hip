@@ -231,6 +231,13 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
     KPROF_MARK(2);
     uint64_t val[kPos];
     uint32_t nb[kPos], lane_bits = 0;
+    // the eight literal codes asked for together, whatever the positions turn out to be: under a position's own condition
+    // the compiler waits for each look-up where it is issued -- eight LDS trips one behind the other (round 6: 5.60 -> 5.34
+    // ms; the lane's matches hoisted the same way: nothing more; every position's ORs without a branch: 8.0 ms,
+    // profiles/r06_n_*)
+    uint32_t lcs[kPos];
+#pragma unroll
+    for (uint32_t k = 0; k < kPos; k++) lcs[k] = s_lit[(w[k / 4] >> (8u * (k & 3u))) & 255u];
 #pragma unroll
     for (uint32_t k = 0; k < kPos; k++) {
       uint64_t v = 0;
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
         nbits = s_mbits[mj];
         mj++;
       } else if (!((skip4 >> k) & 1u)) {
-        const uint32_t lc = s_lit[(w[k / 4] >> (8u * (k & 3u))) & 255u];
+        const uint32_t lc = lcs[k];
         v = lc & 0xffffu;
         nbits = lc >> 16;
       }
