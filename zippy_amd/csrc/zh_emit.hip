@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   const uint32_t nmatch = a.f_nmatch[f];
   const uint32_t spill = a.f_spill[f];  // bytes covered by a match begun in the previous fragment
   uint32_t mnext = 0;                   // first match that starts at or behind the current chunk
+  uint32_t prev_s = 0, prev_l = 0;      // the match before it (start, length): what reaches into the chunk from before
   // [p, e) is inside a match: noted as the two places where "inside" flips, clipped to the chunk [c0, c1), as bits
   // relative to c0 (matches do not overlap and a match covers at least two bytes behind its start: no two flips
   // share a bit); build_chunk turns the flips into the bitmap with a prefix parity
@@ -104,8 +105,9 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
     zh_wave_sync();
     // what reaches in from before the chunk: the previous match (matches do not overlap), or
     // for the first chunk the match begun in the previous fragment
+    // (kept from the chunk before: two dependent global loads by one lane at the head of every chunk otherwise)
     if (lane == 0) {
-      if (mnext) cover(m_pos[mnext - 1] + 1u, (uint32_t)m_pos[mnext - 1] + m_len[mnext - 1], c0, c1);
+      if (mnext) cover(prev_s + 1u, prev_s + prev_l, c0, c1);
       else cover(0, spill, c0, c1);
     }
     // (the next 64 matches' fields are asked for before these are filed: unconditional loads at clamped
@@ -125,6 +127,10 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
         cover(s + 1u, s + l, c0, c1);  // (chain levels: a match may run past the fragment)
       }
       const uint32_t cnt = (uint32_t)__popcll(__ballot(here));
+      if (cnt) {  // (the lanes that are `here` are a prefix: matches come in position order)
+        prev_s = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)(cnt - 1u));
+        prev_l = (uint32_t)__builtin_amdgcn_readlane((int)l, (int)(cnt - 1u));
+      }
       mnext += cnt;
       if (cnt < 64u) break;
     }
@@ -190,8 +196,9 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
     const uint32_t p0 = base + kPos * lane;  // this lane's positions p0 .. p0 + kPos - 1
     const bool in = p0 < n;
     const uint32_t bw = in ? (p0 & (kChunk - 1u)) >> 5 : 0u, bs = p0 & 31u;  // p0 is a multiple of kPos: one bitmap word
-    const uint32_t st4 = in ? (s_start[bw] >> bs) & kPosMask : 0u;
-    uint32_t skip4 = in ? (s_cover[bw] >> bs) & kPosMask : kPosMask;
+    const uint32_t sw = s_start[bw], cw = s_cover[bw];  // (unconditional: bw is 0 for a lane past the fragment)
+    const uint32_t st4 = in ? (sw >> bs) & kPosMask : 0u;
+    uint32_t skip4 = in ? (cw >> bs) & kPosMask : kPosMask;
     if (in && n - p0 < kPos) skip4 |= (kPosMask << (n - p0)) & kPosMask;  // positions past the fragment
     uint32_t w[kPos / 4];
 #pragma unroll
