@@ -26,8 +26,14 @@ namespace {
 constexpr uint32_t kPos = ZH_EMIT_POS;                 // positions per lane and pass (4 or 8: one bitmap word a lane)
 constexpr uint32_t kPass = 64 * kPos;                  // positions per pass
 constexpr uint32_t kPosMask = (1u << kPos) - 1u;
-constexpr uint32_t kChunk = 4096;                      // positions per match-bitmap chunk
-constexpr uint32_t kStageWords = 512;                  // 2 KiB staging window
+#ifndef ZH_EMIT_CHUNK
+#define ZH_EMIT_CHUNK 2048  // (round 6, ms for 4096 x 1 MiB: 8192: 5.11, 4096: 5.27, 2048: 5.03, 1024: 5.26, 512: 5.82)
+#endif
+constexpr uint32_t kChunk = ZH_EMIT_CHUNK;             // positions per match-bitmap chunk
+#ifndef ZH_EMIT_STAGE
+#define ZH_EMIT_STAGE 512
+#endif
+constexpr uint32_t kStageWords = ZH_EMIT_STAGE;        // 2 KiB staging window
 // flush threshold: a position adds at most 16 bits (a 15-bit literal, or 48 bits for a match of >= 3)
 constexpr uint32_t kFlushBits = (kStageWords - kPass / 2 - 16) * 32;
 constexpr uint32_t kPassMatches = kPass / 3 + 3;       // a pass starts at most kPass / 3 + 1 matches
@@ -135,19 +141,21 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
       if (cnt < 64u) break;
     }
     zh_wave_sync();
-    // flips -> "inside": bit i = parity of the flips at or before i; a lane the words `lane` and `lane + 64`
-    static_assert(kChunk / 32 == 128, "two bitmap words a lane");
-    uint32_t x0 = s_cover[lane], x1 = s_cover[lane + 64u];
+    // flips -> "inside": bit i = parity of the flips at or before i; a lane the words `lane`, `lane + 64`, ...
+    constexpr uint32_t kWords = kChunk / 32, kWordsLane = (kWords + 63u) / 64u;
+    static_assert(kChunk % kPass == 0 && kChunk >= kPass, "whole passes a chunk");
+    uint32_t carry_odd = 0;
 #pragma unroll
-    for (uint32_t sh = 1; sh < 32; sh <<= 1) {
-      x0 ^= x0 << sh;
-      x1 ^= x1 << sh;
+    for (uint32_t k = 0; k < kWordsLane; k++) {
+      const bool have = lane + 64u * k < kWords;
+      uint32_t x = have ? s_cover[lane + 64u * k] : 0u;
+#pragma unroll
+      for (uint32_t sh = 1; sh < 32; sh <<= 1) x ^= x << sh;
+      const uint64_t odd = __ballot((x >> 31) != 0u);
+      if ((carry_odd + (uint32_t)__popcll(odd & zh_lanemask_lt())) & 1u) x = ~x;
+      if (have) s_cover[lane + 64u * k] = x;
+      carry_odd += (uint32_t)__popcll(odd);
     }
-    const uint64_t odd0 = __ballot((x0 >> 31) != 0u), odd1 = __ballot((x1 >> 31) != 0u);
-    if (__popcll(odd0 & zh_lanemask_lt()) & 1) x0 = ~x0;
-    if ((__popcll(odd0) + __popcll(odd1 & zh_lanemask_lt())) & 1) x1 = ~x1;
-    s_cover[lane] = x0;
-    s_cover[lane + 64u] = x1;
     zh_wave_sync();
   };
 
