@@ -71,6 +71,9 @@ struct ZhCompressArgs {
   uint32_t* f_nlit;
   uint32_t* f_extra_bits;  // sum of length+distance extra bits of the fragment's matches
   uint16_t* f_hist;        // [nfrags][320]
+  // [nfrags][1024] levels 1 (exact parse) and -2, else null: bit p of a fragment's 4 KiB = byte p lies inside a match,
+  // behind its first byte -- written by zh_l1_match_kernel in whole groups of 64 words, read by zh_emit_kernel
+  uint32_t* f_cover;
   uint32_t* f_crc;         // CRC-32 (gzip) or adler s1 | s2<<16 pieces, see zh_checksum
   uint32_t* f_adler;
   // per fragment, written by the Huffman / layout kernels

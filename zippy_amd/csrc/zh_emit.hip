@@ -41,6 +41,13 @@ constexpr uint32_t kAhead = kPos / 4;                  // match fields asked for
 static_assert(kPos == 4 || kPos == 8, "one bitmap word and whole source dwords per lane");
 }  // namespace
 
+// kCoverIn: the matcher has left the fragment's coverage bitmap in a.f_cover (zh_l1_match_kernel: bit p = byte p is
+// inside a match, behind its first byte), a chunk's 64 words are one load a lane -- asked for two chunks ahead -- and a
+// match's first byte is the clear bit in front of a set one.  Otherwise (parallel parse, chain levels) the bitmaps are
+// made here from the match list, chunk by chunk.  (Round 6, ms for 4096 x 1 MiB: 4.99 -> 4.38, the matcher's 64.8 unchanged;
+// the parallel matcher leaving the same bitmap -- two LDS flips a match in its output walk, a workgroup-wide parity -- cost it
+// 23.7 -> 24.7 ms for 5.2 -> 4.55 here: not adopted.  profiles/r06_ab_*, r06_ad_*)
+template <bool kCoverIn>
 __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__ d_src,
                                                      uint8_t* __restrict__ d_dst, ZhCompressArgs a) {
   __shared__ uint32_t s_lit[288];
@@ -101,7 +108,31 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
     atomicOr(&s_cover[(p - c0) >> 5], 1u << ((p - c0) & 31u));
     if (e < c1) atomicOr(&s_cover[(e - c0) >> 5], 1u << ((e - c0) & 31u));
   };
+  // (kCoverIn) the lane's word of the current chunk's bitmap and of the next chunk's; a chunk that starts behind the
+  // fragment reads as zero (the matcher writes whole chunks' worth of words)
+  const uint32_t* fcov = kCoverIn ? a.f_cover + (size_t)f * (ZH_FRAG_SIZE / 32u) : nullptr;
+  auto cover_words = [&](uint32_t c0) -> uint32_t { return c0 < n ? fcov[(c0 >> 5) + lane] : 0u; };
+  uint32_t cov_a = 0, cov_b = 0;
+  if (kCoverIn) {
+    static_assert(!kCoverIn || kChunk == 2048u, "a bitmap word a lane and chunk");
+    cov_a = cover_words(0);
+    cov_b = cover_words(kChunk);
+  }
   auto build_chunk = [&](uint32_t c0) {
+    if (kCoverIn) {
+      const uint32_t cw = cov_a;
+      // the bit behind the word's last: the next lane's first, the next chunk's for lane 63
+      const uint32_t nb0 = (uint32_t)__builtin_amdgcn_readlane((int)cov_b, 0);
+      uint32_t nx = (uint32_t)__shfl_down((int)cw, 1, 64);
+      if (lane == 63u) nx = nb0;
+      zh_wave_sync();
+      s_cover[lane] = cw;
+      s_start[lane] = ~cw & ((cw >> 1) | (nx << 31));
+      cov_a = cov_b;
+      cov_b = cover_words(c0 + 2u * kChunk);
+      zh_wave_sync();
+      return;
+    }
     const uint32_t c1 = c0 + kChunk < n ? c0 + kChunk : n;
     zh_wave_sync();
     for (uint32_t i = lane; i < kChunk / 32; i += 64) {
@@ -326,8 +357,12 @@ __global__ __launch_bounds__(64) void zh_emit_kernel(const uint8_t* __restrict__
   KPROF_FLUSH(32, 8);
 }
 
+// cover_in: a.f_cover holds this run's bitmaps (the matcher was zh_l1_match_kernel)
 extern "C" void zh_launch_emit(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst,
-                               ZhCompressArgs a) {
+                               ZhCompressArgs a, int cover_in) {
   if (!a.nfrags) return;
-  hipLaunchKernelGGL(zh_emit_kernel, dim3(a.nfrags), dim3(64), 0, stream, d_src, d_dst, a);
+  if (cover_in && a.f_cover)
+    hipLaunchKernelGGL(zh_emit_kernel<true>, dim3(a.nfrags), dim3(64), 0, stream, d_src, d_dst, a);
+  else
+    hipLaunchKernelGGL(zh_emit_kernel<false>, dim3(a.nfrags), dim3(64), 0, stream, d_src, d_dst, a);
 }

@@ -77,7 +77,7 @@ void zh_launch_huffman_probe(hipStream_t, const uint32_t* freq, int num_freq, in
 void zh_launch_layout(hipStream_t, uint8_t* d_dst, ZhCompressArgs a, const uint32_t* buf_crc,
                       const uint32_t* buf_adler, int with_trailer);
 void zh_launch_trailer(hipStream_t, uint8_t* d_dst, ZhCompressArgs a, const uint32_t* buf_crc, const uint32_t* buf_adler);
-void zh_launch_emit(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhCompressArgs a);
+void zh_launch_emit(hipStream_t, const uint8_t* d_src, uint8_t* d_dst, ZhCompressArgs a, int cover_in);
 }
 
 // internal.nim:177-189 configurationTable (good, nice, chain); `lazy` is unused by the reference

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
   // parse: 4096 byte-wide counters (4 per dword) of the probes per table slot in one step,
   // all zero between steps; afterwards the first 4 KiB are the coverage bitmap (bit p set:
-  // byte p lies inside a match)
+  // byte p lies inside a match, behind its first byte)
   __shared__ uint32_t s_scr[kCntWords];
   // one bit per table slot: written while parsing this fragment.  A slot that was not holds the
   // reference's initial zero, which needs no load -- and the pooled table needs no clearing.
@@ -516,9 +516,11 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
   KPROF_MARK(3);
   const uint32_t nmatch = s_nmatch;
 
-  // ---- match histograms, and the coverage bitmap as the places where "inside a match" flips: a match's first
-  // byte and the byte behind its last (xor: a match that starts where the one before it ends flips the same bit
-  // twice).  The next 64 matches' fields are asked for before these are filed (clamped, unconditional loads) ----
+  // ---- match histograms, and the coverage bitmap as the places where "inside a match, behind its first byte" flips:
+  // the match's second byte and the byte behind its last (a match is four bytes at least: no two flips share a bit).
+  // A match's first byte is then the clear bit in front of a set one -- which is how the emission reads the same bitmap
+  // (zh_emit_kernel: it gets the bitmap, a.f_cover, instead of filing the match list a second time).
+  // The next 64 matches' fields are asked for before these are filed (clamped, unconditional loads) ----
   uint32_t extra_bits = 0, covered = 0;
   {
     const uint32_t mlast = nmatch ? nmatch - 1u : 0u;
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
         atomicAdd(&s_hist[ZH_NUM_LITLEN + di], 1u);
         extra_bits += zh_len_extra_bits(li) + zh_dist_extra_bits(di);
         covered += l;
-        atomicXor(&s_cover[p >> 5], 1u << (p & 31u));
+        atomicXor(&s_cover[(p + 1u) >> 5], 1u << ((p + 1u) & 31u));
         if (p + l < kCntWords * 32u) atomicXor(&s_cover[(p + l) >> 5], 1u << ((p + l) & 31u));
       }
     }
@@ -555,8 +557,14 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
     }
   }
   zh_wave_sync();
+  // the bitmap for the emission: whole groups of 64 words (2048 positions: its chunk), zero behind the fragment
+  if (a.f_cover) {
+    uint32_t* cov_out = a.f_cover + (size_t)f * kCntWords;
+    for (uint32_t w0 = 0; w0 * 32u < n; w0 += 64) cov_out[w0 + lane] = s_cover[w0 + lane];
+  }
   // ---- literal histogram (lanes over positions): four positions a lane and pass, four passes' source words in
-  // flight together ----
+  // flight together.  A literal is a byte that is neither behind a match's first byte nor one itself: its bit and
+  // the next are clear ----
   for (uint32_t base = 0; base < n; base += 1024) {
     uint32_t wq[4];
 #pragma unroll
@@ -568,10 +576,14 @@ __global__ __launch_bounds__(64) void zh_l1_match_kernel(const uint8_t* __restri
     for (uint32_t u = 0; u < 4; u++) {
       const uint32_t p = base + 256u * u + 4u * lane;
       if (p < n) {
-        const uint32_t cov = s_cover[p >> 5] >> (p & 31u);  // p is a multiple of 4: same word for all four
+        // p is a multiple of 4: one word for all four, and the next word's first bit behind position 31
+        const uint32_t wi = p >> 5;
+        const uint32_t c_lo = s_cover[wi], c_hi = wi + 1u < kCntWords ? s_cover[wi + 1u] : 0u;
+        const uint32_t cov = (uint32_t)((((uint64_t)c_hi << 32) | c_lo) >> (p & 31u));
+        const uint32_t notlit = cov | (cov >> 1);
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++)
-          if (p + k < n && !((cov >> k) & 1u)) atomicAdd(&s_hist[(wq[u] >> (8u * k)) & 255u], 1u);
+          if (p + k < n && !((notlit >> k) & 1u)) atomicAdd(&s_hist[(wq[u] >> (8u * k)) & 255u], 1u);
       }
     }
   }

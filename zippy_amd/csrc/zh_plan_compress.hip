@@ -85,6 +85,9 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
                o_fex = ar.reserve(nf * 4), o_fhist = ar.reserve(nf * ZH_HIST_STRIDE * 2),
                o_fbits = ar.reserve(nf * 4), o_fstart = ar.reserve(nf * 8);
   const size_t o_pcrc = ar.reserve(nf * 4), o_pad = ar.reserve(nf * 4), o_plen = ar.reserve(nf * 4);
+  // (the exact BestSpeed parse and level -2 hand the emission their coverage bitmap: 4 KiB a fragment)
+  const bool cover_out = level == 1 || level == -2;
+  const size_t o_fcov = ar.reserve(cover_out ? nf * 4096 : 0);
   const size_t o_bmode = ar.reserve(nb * 4), o_blit = ar.reserve(nb * 288 * 4),
                o_bdist = ar.reserve(nb * 32 * 4), o_bhdr = ar.reserve(nb * ZH_HDR_WORDS * 4),
                o_bhb = ar.reserve(nb * 4), o_bbits = ar.reserve(nb * 8), o_bd0 = ar.reserve(nb * 8),
@@ -209,6 +212,7 @@ extern "C" int zh_plan_compress_blocks(zh_ctx* ctx, size_t n, const uint64_t* sr
   a.f_nlit = carve<uint32_t>(base, o_fnl);
   a.f_extra_bits = carve<uint32_t>(base, o_fex);
   a.f_hist = carve<uint16_t>(base, o_fhist);
+  a.f_cover = cover_out ? carve<uint32_t>(base, o_fcov) : nullptr;
   a.f_crc = p->piece_crc = carve<uint32_t>(base, o_pcrc);
   a.f_adler = p->piece_adler = carve<uint32_t>(base, o_pad);
   p->piece_len = carve<uint32_t>(base, o_plen);

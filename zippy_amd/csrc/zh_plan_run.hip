@@ -374,7 +374,9 @@ extern "C" int zh_plan_run(zh_plan* p, const void* d_src_v, void* d_dst_v) {
     prof_mark(p, "zh_layout_kernel");
     zh_launch_layout(s, d_dst, a, p->buf_crc, p->buf_adler, trailer_late ? 0 : 1);
     prof_mark(p, "zh_emit_kernel");
-    zh_launch_emit(s, d_src, d_dst, a);
+    // (the exact BestSpeed parse and level -2 have left their coverage bitmaps for it; ZH_EMIT_COVER=0: measurement)
+    static const bool cover_ok = [] { const char* e = getenv("ZH_EMIT_COVER"); return !(e && strcmp(e, "0") == 0); }();
+    zh_launch_emit(s, d_src, d_dst, a, cover_ok && ((p->level == 1 && !l1_parallel(ctx)) || p->level == -2) ? 1 : 0);
     if (trailer_late) {
       prof_mark(p, "zh_trailer_kernel");
       ZH_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_join, 0));
