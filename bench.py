@@ -933,9 +933,12 @@ def main():
     # ---- N > 1: the batch lives on rank 0 and comes home to rank 0 (RCCL over xGMI) ----
     transfer = None
     if use_dist and scaling == "strong" and not args.no_transfer and do_c and do_u:
-        transfer = transfer_leg(torch, dist, sharding, synth, rank, world, args.buffers, size, slot, lo, hi,
-                                d_src, d_comp, d_back, cplan, uplan, stream, t_comp / args.steps,
-                                t_unc / args.steps)
+        try:  # (a side measurement, never run on more than one GPU before the driver does: it must not cost the line)
+            transfer = transfer_leg(torch, dist, sharding, synth, rank, world, args.buffers, size, slot, lo, hi,
+                                    d_src, d_comp, d_back, cplan, uplan, stream, t_comp / args.steps,
+                                    t_unc / args.steps)
+        except Exception as e:  # noqa: BLE001
+            transfer = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     if rank == 0:
         avg, launches = kernel_averages(kernel_ms)  # a kernel's launches of a step together, and how many they are
@@ -1006,7 +1009,7 @@ def main():
             out["roofline_passes"]["uncompress"] = roof(N + C, t_unc / args.steps, nl=1)
         if transfer:
             out["transfer"] = transfer
-            out["value_incl_transfer"] = transfer["value_incl_transfer"]
+            out["value_incl_transfer"] = transfer.get("value_incl_transfer")
         headline = (world == 1 and do_c and do_u and args.foreign is None and args.level == 1
                     and size == 1 << 20 and n >= 8)
         if pp:
