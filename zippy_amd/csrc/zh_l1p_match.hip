@@ -61,6 +61,7 @@ __global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __re
   __shared__ uint32_t s_big[kSrcWords + 8192];
   __shared__ uint32_t s_hist[ZH_HIST_STRIDE];
   __shared__ uint32_t s_exit[kT];
+  __shared__ uint32_t s_ring[kT];    // P1: a block of wave 0's results on its way out (the other block: s_exit)
   __shared__ uint32_t s_wsum[kT / 64][3];
   __shared__ uint32_t s_misc[4];     // 0: next fragment, 1: "some entry changed"
   uint32_t* const s_tab = s_big;
@@ -83,51 +84,71 @@ __global__ __launch_bounds__(kT, 8) void zh_l1p_match_kernel(const uint8_t* __re
     for (uint32_t i = t; i < ZH_HIST_STRIDE; i += kT) s_hist[i] = 0;
     __syncthreads();
     KPROF_MARK(0);
-    // ---- P1: candidate links (wave 0; the other waves wait at the barrier).  A step is 64
+    // ---- P1: candidate links (wave 0; the other waves carry its results out).  A step is 64
     // consecutive positions and ONE returning atomicMax a lane on the table: what comes back is the
     // latest position with the lane's hash that entered before it -- in an earlier step, or (the LDS
     // unit serves a wave's lanes in ascending order) in a lower lane of this one.  Anything else a
     // lane might get back is thrown away below (a candidate must lie before its position), so the
     // stream is valid whatever the order; the four bytes at a position come straight from the
-    // stream (coalesced, any byte address), fetched 32 steps ahead ----
-    if (wave == 0 && n >= 16u) {
-#ifndef ZH_EMU
-      __builtin_amdgcn_s_setprio(3);  // the one serial phase: first pick of the SIMD's issue slots
-#endif
-      // No lane is masked: position 0's atomicMax changes nothing (and a candidate must lie before
-      // its position: it gets none), positions behind n - 4 hash bytes of the last word and are
-      // never looked at by P2 (no match starts in the last 15 bytes), positions behind n enter the
-      // table when nobody reads it any more.  Only the loads are kept inside the fragment.
+    // stream (coalesced, any byte address), fetched 16 steps ahead ----
+    // (Round 6: the wave's results used to go out to the pool by its own stores -- and with loads AND stores in flight the
+    // compiler can only wait for all of them (one counter, two kinds of operation: `s_waitcnt vmcnt(0)` at the head of every
+    // block of steps), so the loads fetched "ahead" were waited for as soon as they were asked, and the stores with them.
+    // Now wave 0 leaves a block's results in LDS and the waves that wait for it anyway carry them out: wave 0 has loads only,
+    // waited for one by one: 23.65 -> 23.05 ms for 4096 x 1 MiB, the same streams -- the rest of a step's 150 cycles is the LDS
+    // pipe the CU's other workgroup's walks share, as round 4 found.  profiles/r06_al_*)
+    if (n >= 16u) {
       const uint32_t steps = (n + 63u) >> 6;
-      constexpr uint32_t kAhead = 16;  // source words are fetched this many steps ahead
+      constexpr uint32_t kAhead = 16;  // source words are fetched this many steps ahead; steps a block
+      static_assert(kAhead * 64u == kT, "a block of results is the size of s_exit");
       auto fetch = [&](uint32_t step) -> uint32_t {
         const uint32_t p = step * 64u + lane;
         return (uint32_t) * reinterpret_cast<const Word32*>(src + (p + 4u <= n ? p : n - 4u));
       };
       uint32_t wq[kAhead];
-#pragma unroll
-      for (uint32_t k = 0; k < kAhead; k++) wq[k] = fetch(k);
-      for (uint32_t s0 = 0; s0 < steps; s0 += kAhead) {
-        uint32_t raw[kAhead];  // the atomics of a block are issued back to back, their results stored afterwards
-#pragma unroll
-        for (uint32_t k = 0; k < kAhead; k++) {
-          const uint32_t step = s0 + k;
-          const uint32_t p = step * 64u + lane;
-          // a table entry is position << 16 | the 16 bits of the hash product below the slot's 14:
-          // the maximum is still the latest position, and a candidate whose 30 bits agree has the
-          // position's four bytes but for one case in 65 536 -- which P2's compare settles
-          const uint32_t h = wq[k] * kHashMul;
-          wq[k] = fetch(step + kAhead);
-          raw[k] = atomicMax(&s_tab[h >> kShift], (p << 16) | ((h >> 2) & 0xffffu));
-#ifdef ZH_EMU
-          zh_wave_sync();  // (the emulator runs a lane at a time: keep the steps in step)
+      if (wave == 0) {
+#ifndef ZH_EMU
+        __builtin_amdgcn_s_setprio(3);  // the one serial phase: first pick of the SIMD's issue slots
 #endif
-        }
 #pragma unroll
-        for (uint32_t k = 0; k < kAhead; k++) raws[((s0 + k) * 64u + lane) & (ZH_FRAG_SIZE - 1u)] = raw[k];
+        for (uint32_t k = 0; k < kAhead; k++) wq[k] = fetch(k);
+      }
+      for (uint32_t s0 = 0; s0 < steps; s0 += kAhead) {
+        uint32_t* const ring = ((s0 / kAhead) & 1u) ? s_exit : s_ring;  // (two blocks: one being carried out, one being made)
+        if (wave == 0) {
+          // No lane is masked: position 0's atomicMax changes nothing (and a candidate must lie before its position: it
+          // gets none), positions behind n - 4 hash bytes of the last word and are never looked at by P2 (no match starts
+          // in the last 15 bytes), positions behind n enter the table when nobody reads it any more.  Only the loads are
+          // kept inside the fragment.
+          // (the atomics of half a block are issued back to back, their results left in the ring afterwards)
+#pragma unroll
+          for (uint32_t half = 0; half < 2; half++) {
+            uint32_t raw[kAhead / 2];
+#pragma unroll
+            for (uint32_t k = 0; k < kAhead / 2; k++) {
+              const uint32_t j = half * (kAhead / 2) + k, step = s0 + j;
+              const uint32_t p = step * 64u + lane;
+              // a table entry is position << 16 | the 16 bits of the hash product below the slot's 14:
+              // the maximum is still the latest position, and a candidate whose 30 bits agree has the
+              // position's four bytes but for one case in 65 536 -- which P2's compare settles
+              const uint32_t h = wq[j] * kHashMul;
+              wq[j] = fetch(step + kAhead);
+              raw[k] = atomicMax(&s_tab[h >> kShift], (p << 16) | ((h >> 2) & 0xffffu));
+#ifdef ZH_EMU
+              zh_wave_sync();  // (the emulator runs a lane at a time: keep the steps in step)
+#endif
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kAhead / 2; k++) ring[(half * (kAhead / 2) + k) * 64u + lane] = raw[k];
+          }
+        }
+        __syncthreads();
+        if (wave != 0)
+          for (uint32_t i = t - 64u; i < kAhead * 64u; i += kT - 64u)
+            raws[(s0 * 64u + i) & (ZH_FRAG_SIZE - 1u)] = ring[i];
       }
 #ifndef ZH_EMU
-      __builtin_amdgcn_s_setprio(0);
+      if (wave == 0) __builtin_amdgcn_s_setprio(0);
 #endif
     }
     __syncthreads();
