@@ -237,6 +237,16 @@ __global__ __launch_bounds__(64) void zh_chain_prev_ldst_kernel(const uint8_t* _
 #ifndef ZH_CHAIN_LINK_TURNS
 #define ZH_CHAIN_LINK_TURNS 3
 #endif
+// classes of a block that one workgroup links in step, and the positions a tile of that step (zh_chain_class_links_kernel;
+// 512 x 1 MiB at level -1, the three link kernels together, ms: a wave a class at its own pace 11.9-12.7; 4 classes a
+// workgroup 12.1; 8: 10.2-11.1 at 8192 positions a tile, 11.3 at 4096, 10.4-11.0 at 16 384, 10.6-11.1 at 32 768, 10.9-11.6
+// at 65 536; 64 classes, 16 / 8 a workgroup: 11.8 / 13.0.  16 of 32 do not fit the LDS.  profiles/r06_an_*, r06_ao_*)
+#ifndef ZH_CHAIN_LINKS_GROUP
+#define ZH_CHAIN_LINKS_GROUP 8
+#endif
+#ifndef ZH_CHAIN_LINKS_TILE
+#define ZH_CHAIN_LINKS_TILE 16384
+#endif
 #ifndef ZH_CHAIN_CHUNK
 #define ZH_CHAIN_CHUNK 32  // positions a walk starts at the first of
 #endif
@@ -328,25 +338,32 @@ __global__ __launch_bounds__(512) void zh_chain_class_scan_kernel(ZhCompressArgs
 // is ONE LDS atomic: positions grow along the list and the lanes of an LDS atomic are served in ascending order,
 // so atomicMax hands every lane what the slot held just before it -- the previous position of equal hash, be
 // it an earlier lane of the step or an earlier step -- and leaves the step's last one there.
-template <bool kNarrow>
-__global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
-                                                                  const uint32_t* __restrict__ cls_scratch,
-                                                                  uint32_t* __restrict__ lists,
-                                                                  uint64_t* __restrict__ prevw, uint32_t ngroups) {
+template <bool kNarrow, uint32_t kGroup>
+__global__ __launch_bounds__(64 * kGroup) void zh_chain_class_links_kernel(const uint8_t* __restrict__ d_src, ZhCompressArgs a,
+                                                                           const uint32_t* __restrict__ cls_scratch,
+                                                                           uint32_t* __restrict__ lists,
+                                                                           uint64_t* __restrict__ prevw, uint32_t ngroups) {
   constexpr uint32_t kAhead = 4;                 // steps whose positions and bytes are on their way
   constexpr uint32_t kSlots = 1u << (kHashBits - kClassBits);
-  __shared__ uint32_t s_head[kSlots];            // lz77.nim:5-6 `head`, this class's slots
-  const unsigned lane = zh_lane();
+  __shared__ uint32_t s_head_all[kGroup][kSlots];  // lz77.nim:5-6 `head`, a class's slots a wave
+  const unsigned lane = zh_lane(), wave = threadIdx.x >> 6;
+  uint32_t* const s_head = s_head_all[wave];
   // (the classes of a block on ONE XCD: their stores fill the same lines of prevw)
-  const uint32_t bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  if (bid >= ngroups) return;
+  // kGroup > 1 (round 6): kGroup classes of a block are the waves of one workgroup and cross the block tile by tile, a
+  // barrier a tile.  A 128-byte line of prevw holds 32 positions of as many classes; with a wave a class, each at its own
+  // pace, 92 % of the 4-byte stores went on to the fabric alone (396 M writes for 512 MiB: what this kernel's time was);
+  // what a workgroup's classes write into a line now arrives while the L2 still holds it, and leaves as one write.
+  static_assert(kClasses % kGroup == 0, "a workgroup's classes belong to one block");
+  const uint32_t wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint32_t bid = wg * kGroup + wave;
+  if (wg * kGroup >= ngroups) return;
   const uint32_t b = bid >> kClassBits, c = bid & (kClasses - 1u);  // (b: of the range)
   const ZhBlockDesc bd = a.blocks[a.first_block + b];
   const uint8_t* src = d_src + bd.src_off;
   const uint32_t block_len = (uint32_t)bd.len;
   const uint32_t* cls = cls_scratch + (size_t)b * kClsStride;
   const uint32_t n = cls[kClsInfo + kClasses + c];
-  if (!n) return;
+  if (kGroup == 1 && !n) return;
   uint32_t* list_rw = lists + (size_t)(bd.first_frag - a.first_frag) * ZH_FRAG_SIZE + cls[kClsInfo + c];
   const uint32_t* list = list_rw;
   typedef typename ChainRec<kNarrow>::T Rec;
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t*
   for (uint32_t i = lane; i < kSlots; i += 64) s_head[i] = 0;
   zh_wave_sync();
   // the eight bytes at a listed position (zeros behind the block's end); every load is unconditional
-  auto pos_at = [&](uint32_t i) -> uint32_t { return list[i < n ? i : n - 1u]; };
+  auto pos_at = [&](uint32_t i) -> uint32_t { return n ? list[i < n ? i : n - 1u] : 0u; };
   auto bytes_at = [&](uint32_t P) -> uint64_t {
     if (block_len < 8u) {
       uint64_t v = 0;
@@ -374,7 +391,10 @@ __global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t*
   }
 #pragma unroll
   for (uint32_t k = 0; k < kAhead; k++) wq[k] = bytes_at(pq[k]);
-  for (uint32_t base0 = 0; base0 < n; base0 += 64u * kAhead) {
+  constexpr uint32_t kTile = ZH_CHAIN_LINKS_TILE;  // positions a tile (kGroup > 1)
+  uint32_t base0 = 0;
+  for (uint32_t tile_end = kGroup == 1 ? 0xffffffffu : kTile;; tile_end += kTile) {
+  for (; base0 < n && (kGroup == 1 || (uint32_t)__builtin_amdgcn_readfirstlane((int)pq[0]) < tile_end); base0 += 64u * kAhead) {
     uint32_t P[kAhead], old[kAhead];
     uint64_t w8[kAhead];
 #pragma unroll
@@ -399,6 +419,9 @@ __global__ __launch_bounds__(64) void zh_chain_class_links_kernel(const uint8_t*
         list_rw[i] = 0;  // best[] goes back the way the walks expect it: nothing worked out
       }
     }
+  }
+  if (kGroup == 1 || tile_end >= block_len) break;
+  __syncthreads();
   }
 }
 
@@ -1094,12 +1117,14 @@ extern "C" void zh_launch_chain_prev(hipStream_t stream, const uint8_t* d_src, Z
     hipLaunchKernelGGL(zh_chain_class_scan_kernel, dim3(a.nblocks), dim3(512), 0, stream, a, head_scratch);
     hipLaunchKernelGGL(zh_chain_class_kernel<true>, dim3(ngrid), dim3(64 * kClsWaves), 0, stream, d_src, a, head_scratch, lists);
     const uint32_t ng = a.nblocks * kClasses;
+    constexpr uint32_t kGroup = ZH_CHAIN_LINKS_GROUP;
+    const uint32_t nwg = ng / kGroup;
     if (chain_narrow(links_serial, good))
-      hipLaunchKernelGGL(zh_chain_class_links_kernel<true>, dim3((ng + 7u) & ~7u), dim3(64), 0, stream, d_src, a, head_scratch,
-                         lists, prevw, ng);
+      hipLaunchKernelGGL((zh_chain_class_links_kernel<true, kGroup>), dim3((nwg + 7u) & ~7u), dim3(64 * kGroup), 0, stream, d_src, a,
+                         head_scratch, lists, prevw, ng);
     else
-      hipLaunchKernelGGL(zh_chain_class_links_kernel<false>, dim3((ng + 7u) & ~7u), dim3(64), 0, stream, d_src, a, head_scratch,
-                         lists, prevw, ng);
+      hipLaunchKernelGGL((zh_chain_class_links_kernel<false, kGroup>), dim3((nwg + 7u) & ~7u), dim3(64 * kGroup), 0, stream, d_src, a,
+                         head_scratch, lists, prevw, ng);
     return;
   }
   const uint32_t slice = zh_chain_prev_slice();
